@@ -1,0 +1,204 @@
+/*
+ * rvcmi.h -- C ABI of the MI355X-native RVC hot path (librvcmi.so).
+ *
+ * The reference (fumiama/Retrieval-based-Voice-Conversion-WebUI) has no C ABI of its own: its
+ * boundary for this path is two Python objects,
+ *
+ *   (1) the faiss index held by the pipeline
+ *         faiss.read_index(path)                infer/modules/vc/pipeline.py:214, infer/lib/rtrvc.py:56
+ *         index.reconstruct_n(0, index.ntotal)  infer/modules/vc/pipeline.py:215, infer/lib/rtrvc.py:57
+ *         index.search(npy, k=8)                infer/modules/vc/pipeline.py:126, infer/lib/rtrvc.py:172
+ *         the (1/score)^2 blend                 infer/modules/vc/pipeline.py:129-138
+ *   (2) the generator module `net_g.dec`
+ *         NSFGenerator.forward(x, f0, g, n_res) rvc/layers/nsf.py:145-191
+ *         Generator.forward(x, g, n_res)        rvc/layers/generators.py:70-98
+ *         built / weight-norm-folded by         rvc/synthesizer.py:10-28
+ *
+ * Each entry point below names the reference call it stands in for.  The Python mirror of those
+ * objects (package `retrieval-based-voice-conversion-webui_amd`, imported as `rvc_amd`) binds this
+ * header with ctypes; INTEGRATION.md shows the two-line patch on the reference side.
+ *
+ * Conventions
+ *   - extern "C", opaque handles, plain pointers and sizes, no C++/torch types.
+ *   - every function returns 0 on success and a negative rvcmi_status on failure; the message is
+ *     available from rvcmi_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - all `*_dev` pointers are DEVICE pointers owned by the caller (hipMalloc / torch.cuda);
+ *     all work is enqueued on the caller's `stream` (a hipStream_t passed as void*); no hidden
+ *     synchronisation, no allocation after create  =>  every forward/search is hipGraph-capturable.
+ *   - handles are immutable after create except for their private workspace: one in-flight
+ *     forward per handle (use one handle per stream for concurrency).
+ */
+#ifndef RVCMI_H
+#define RVCMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVCMI_VERSION 1
+
+typedef enum {
+    RVCMI_OK = 0,
+    RVCMI_ERR_INVALID = -1,     /* bad argument / unsupported configuration            */
+    RVCMI_ERR_HIP = -2,         /* a HIP runtime call failed                            */
+    RVCMI_ERR_IO = -3,          /* file missing / truncated / not an IVF-Flat L2 index  */
+    RVCMI_ERR_NOMEM = -4,       /* shape exceeds the handle's max_B / max_T             */
+    RVCMI_ERR_MISSING = -5      /* a required weight tensor was not supplied            */
+} rvcmi_status;
+
+const char* rvcmi_last_error(void);
+int rvcmi_version(void);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Generator (NSF-HiFi-GAN)                                                                      */
+/* ------------------------------------------------------------------------------------------- */
+
+#define RVCMI_MAX_UPS 8
+#define RVCMI_MAX_RB 4
+#define RVCMI_MAX_DIL 4
+
+typedef enum {
+    RVCMI_OPERAND_F32 = 0,   /* exact-fp32 VALU convolutions (bring-up / highest fidelity) */
+    RVCMI_OPERAND_BF16 = 1,  /* bf16 MFMA operands, fp32 accumulate + fp32 residual stream */
+    RVCMI_OPERAND_F16 = 2    /* fp16 MFMA operands, fp32 accumulate + fp32 residual stream */
+} rvcmi_operand;
+
+/* Mirrors the positional `cpt["config"]` list consumed by rvc/synthesizer.py:10-22
+ * (written by infer/lib/train/process_ckpt.py:23-42). */
+typedef struct {
+    int inter_channels;                       /* 192                                          */
+    int upsample_initial_channel;             /* 512                                          */
+    int gin_channels;                         /* 256 (0 = no speaker conditioning)            */
+    int sr;                                   /* 32000 / 40000 / 48000                        */
+    int use_f0;                               /* 1 = NSFGenerator, 0 = Generator              */
+    int n_ups;
+    int upsample_rates[RVCMI_MAX_UPS];
+    int upsample_kernel_sizes[RVCMI_MAX_UPS];
+    int n_resblock_kernels;                   /* 3                                            */
+    int resblock_kernel_sizes[RVCMI_MAX_RB];
+    int n_dilations[RVCMI_MAX_RB];
+    int resblock_dilation_sizes[RVCMI_MAX_RB][RVCMI_MAX_DIL];
+    int operand;                              /* rvcmi_operand                                */
+} rvcmi_nsf_config;
+
+/* One fp32 host tensor; `name` is the state_dict key under "dec." after remove_weight_norm()
+ * (e.g. "ups.0.weight", "resblocks.3.convs1.0.bias").                                         */
+typedef struct {
+    const char* name;
+    const float* data;      /* host pointer, C-contiguous                                       */
+    int ndim;
+    int64_t shape[4];
+} rvcmi_tensor;
+
+typedef struct rvcmi_nsf rvcmi_nsf;
+
+/* Stands in for rvc/synthesizer.py:10-28 (construction + weight prep of `net_g.dec`).
+ * Packs the weights into MFMA fragment order on `device` and allocates a workspace sized for
+ * max_B utterances of max_T frames.                                                            */
+int rvcmi_nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights, int n_weights,
+                     int device, int max_B, int max_T, rvcmi_nsf** out);
+int rvcmi_nsf_destroy(rvcmi_nsf* h);
+
+/* Stands in for NSFGenerator.forward (rvc/layers/nsf.py:145-191) / Generator.forward
+ * (rvc/layers/generators.py:70-98).
+ *   x_dev      [B, inter, T] fp32 (the reference's channel-first layout)
+ *   f0_dev     [B, T] fp32 Hz, 0 = unvoiced; NULL iff use_f0 == 0
+ *   g_dev      [B, gin] fp32 speaker embedding (emb_g(sid)), or NULL
+ *   noise_dev  [B, T*upp] fp32 N(0,1) -- the draw the reference makes at generators.py:192 --
+ *              or NULL for zeros.  (The reference's rand_ini at :164-166 is forced to 0 for the
+ *              only harmonic there is, so it never reaches the output.)
+ *   n_res      -1 = none; otherwise the realtime "return_length2" resample target, nsf.py:155-162
+ *   out_dev    [B, T_out*upp] fp32, T_out = n_res if n_res >= 0 else T
+ */
+int rvcmi_nsf_forward(rvcmi_nsf* h, int B, int T, const float* x_dev, const float* f0_dev,
+                      const float* g_dev, const float* noise_dev, int n_res, float* out_dev,
+                      void* stream);
+
+int rvcmi_nsf_upp(const rvcmi_nsf* h);               /* prod(upsample_rates)                    */
+size_t rvcmi_nsf_workspace_bytes(const rvcmi_nsf* h);
+
+/* Stage taps for bring-up and per-layer parity tests (not on the product path): runs the forward
+ * up to the named activation and copies it to the host in the reference's channel-first layout
+ * [B, C, L].  `what`: "har" ([B,1,T*upp]), "pre", "up<i>" (after ups+noise_convs), "stage<i>"
+ * (the SUM of the stage's ResBlocks, i.e. before the /num_kernels of nsf.py:186).
+ * Synchronises the stream.                                                                       */
+int rvcmi_nsf_debug_forward(rvcmi_nsf* h, int B, int T, const float* x_dev, const float* f0_dev,
+                            const float* g_dev, const float* noise_dev, int n_res, const char* what,
+                            float* out_host, size_t capacity_floats, int64_t shape_out[3],
+                            void* stream);
+
+/* Per-kernel HIP-event timing (bench.py's roofline leg).  When enabled, every launch of the
+ * forward is bracketed by hipEvents on the caller's stream; not usable under graph capture.
+ * rvcmi_nsf_profile_read returns, for kernel class i < *n, its name, launch count, total ms
+ * and algorithmic flops/bytes accumulated since the last reset.                                */
+typedef struct {
+    char name[48];
+    int64_t launches;
+    double ms;
+    double flops;      /* 2*Cin*Cout*k*L summed over launches                                  */
+    double bytes;      /* algorithmic bytes moved to/from global memory                        */
+} rvcmi_kernel_stat;
+int rvcmi_nsf_profile_enable(rvcmi_nsf* h, int enable);
+int rvcmi_nsf_profile_read(rvcmi_nsf* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset);
+
+/* ------------------------------------------------------------------------------------------- */
+/* IVF-Flat retrieval (faiss IndexIVFFlat, METRIC_L2)                                           */
+/* ------------------------------------------------------------------------------------------- */
+
+typedef struct rvcmi_ivf rvcmi_ivf;
+
+/* faiss.read_index(path)  (pipeline.py:214).  Parses the IwFl/IxF2/ilar on-disk layout.       */
+int rvcmi_ivf_create_from_file(const char* path, int device, rvcmi_ivf** out);
+/* faiss.write_index(index, path)  (web.py:571) -- so indices round-trip with stock RVC.       */
+int rvcmi_ivf_write_file(const rvcmi_ivf* h, const char* path);
+
+/* Direct construction from host arrays (what index.train()+index.add() leave behind, web.py:553-563):
+ * centroids [nlist,d], list_offsets [nlist+1], ids [n] and vecs [n,d] in list-major order.     */
+int rvcmi_ivf_create(int d, int64_t n, int64_t nlist, int nprobe, const float* centroids,
+                     const int64_t* list_offsets, const int64_t* ids, const float* vecs,
+                     int device, rvcmi_ivf** out);
+int rvcmi_ivf_destroy(rvcmi_ivf* h);
+
+int rvcmi_ivf_d(const rvcmi_ivf* h);
+int64_t rvcmi_ivf_ntotal(const rvcmi_ivf* h);            /* index.ntotal                         */
+int64_t rvcmi_ivf_nlist(const rvcmi_ivf* h);
+int rvcmi_ivf_nprobe(const rvcmi_ivf* h);                /* extract_index_ivf(index).nprobe      */
+int rvcmi_ivf_set_nprobe(rvcmi_ivf* h, int nprobe);      /* web.py:551-552                       */
+
+/* Pre-size the search workspace for up to max_nq queries (searches with nq above the current
+ * reservation grow it, which allocates: reserve before hipGraph capture).                      */
+int rvcmi_ivf_reserve(rvcmi_ivf* h, int64_t max_nq);
+
+/* index.search(x, k)  (pipeline.py:126): q_dev [nq,d] fp32 -> D_dev [nq,k] fp32 squared-L2
+ * ascending, I_dev [nq,k] int64 (-1 / FLT_MAX padded).  k <= 8.  Distances are evaluated in fp64
+ * on the fp32 inputs; ties break to the lowest id.                                             */
+int rvcmi_ivf_search(rvcmi_ivf* h, int64_t nq, const float* q_dev, int k, float* D_dev,
+                     int64_t* I_dev, void* stream);
+
+/* search + pipeline.py:129-138 fused, everything device-resident:
+ *   w = (1/D)^2 / sum; feats = (sum_k w_k * big_npy[I_k]) * index_rate + (1-index_rate) * feats
+ * feats_dev [nq,d] fp32 is updated in place.  skip_if_short != 0 reproduces the realtime guard
+ * `if (ix >= 0).all()` of infer/lib/rtrvc.py:173 (per call, not per row).                       */
+int rvcmi_ivf_search_blend(rvcmi_ivf* h, int64_t nq, float* feats_dev, float index_rate, int k,
+                           int skip_if_short, void* stream);
+
+/* index.reconstruct_n(i0, n) -> out_host [n,d] rows in id order (pipeline.py:215).             */
+int rvcmi_ivf_reconstruct_n(const rvcmi_ivf* h, int64_t i0, int64_t n, float* out_host);
+
+/* The whole index as ONE device blob (header + centroids + offsets + ids + vectors) so that a
+ * single RCCL broadcast replicates it across the GPUs of a node.                */
+int rvcmi_ivf_blob(const rvcmi_ivf* h, void** dev_ptr, size_t* bytes);
+int rvcmi_ivf_create_from_blob(void* dev_ptr, size_t bytes, int device, int take_ownership,
+                               rvcmi_ivf** out);
+
+/* Per-phase HIP-event timing for bench.py (coarse / scan / blend), same contract as the nsf one. */
+int rvcmi_ivf_profile_enable(rvcmi_ivf* h, int enable);
+int rvcmi_ivf_profile_read(rvcmi_ivf* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVCMI_H */

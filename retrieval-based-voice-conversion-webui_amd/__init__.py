@@ -1,0 +1,17 @@
+"""MI355X-native hot path of RVC inference (imported as ``rvc_amd``).
+
+faiss IVF-Flat retrieval + NSF-HiFi-GAN generator as hand-written HIP for gfx950 behind the
+reference's own Python call surface.  See DESIGN.md / INTEGRATION.md.
+"""
+from . import _lib
+from ._lib import RvcmiError, build
+from .ivf import IVFFlatHIP, read_index, write_index
+from .nsf import GeneratorHIP, NSFGeneratorHIP, config_from_reference
+from .pipeline import retrieve_blend
+from .synthesizer import accelerate_synthesizer, get_synthesizer, load_synthesizer
+from . import dist
+
+__all__ = [
+    "RvcmiError", "build", "IVFFlatHIP", "read_index", "write_index", "GeneratorHIP", "NSFGeneratorHIP",
+    "config_from_reference", "retrieve_blend", "accelerate_synthesizer", "get_synthesizer", "load_synthesizer", "dist",
+]

@@ -1,0 +1,149 @@
+"""ctypes binding of ``include/rvcmi.h`` (librvcmi.so).
+
+There is deliberately NO fallback: if the shared library has not been built, or a call fails,
+this module raises.  A silent CPU/PyTorch fallback would void every parity and performance claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+from typing import List
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librvcmi.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["nsf.hip", "ivf.hip"]
+
+RVCMI_MAX_UPS, RVCMI_MAX_RB, RVCMI_MAX_DIL = 8, 4, 4
+OPERANDS = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2}
+
+
+class NsfConfig(C.Structure):
+    _fields_ = [
+        ("inter_channels", C.c_int),
+        ("upsample_initial_channel", C.c_int),
+        ("gin_channels", C.c_int),
+        ("sr", C.c_int),
+        ("use_f0", C.c_int),
+        ("n_ups", C.c_int),
+        ("upsample_rates", C.c_int * RVCMI_MAX_UPS),
+        ("upsample_kernel_sizes", C.c_int * RVCMI_MAX_UPS),
+        ("n_resblock_kernels", C.c_int),
+        ("resblock_kernel_sizes", C.c_int * RVCMI_MAX_RB),
+        ("n_dilations", C.c_int * RVCMI_MAX_RB),
+        ("resblock_dilation_sizes", (C.c_int * RVCMI_MAX_DIL) * RVCMI_MAX_RB),
+        ("operand", C.c_int),
+    ]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+# every symbol include/rvcmi.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("rvcmi_last_error", C.c_char_p, []),
+    ("rvcmi_version", C.c_int, []),
+    ("rvcmi_nsf_create", C.c_int, [C.POINTER(NsfConfig), C.POINTER(Tensor), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("rvcmi_nsf_destroy", C.c_int, [_P]),
+    ("rvcmi_nsf_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P]),
+    ("rvcmi_nsf_upp", C.c_int, [_P]),
+    ("rvcmi_nsf_workspace_bytes", C.c_size_t, [_P]),
+    ("rvcmi_nsf_debug_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_char_p, _P, C.c_size_t,
+                                          C.POINTER(C.c_int64), _P]),
+    ("rvcmi_nsf_profile_enable", C.c_int, [_P, C.c_int]),
+    ("rvcmi_nsf_profile_read", C.c_int, [_P, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int), C.c_int]),
+    ("rvcmi_ivf_create_from_file", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
+    ("rvcmi_ivf_write_file", C.c_int, [_P, C.c_char_p]),
+    ("rvcmi_ivf_create", C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(_P)]),
+    ("rvcmi_ivf_destroy", C.c_int, [_P]),
+    ("rvcmi_ivf_d", C.c_int, [_P]),
+    ("rvcmi_ivf_ntotal", C.c_int64, [_P]),
+    ("rvcmi_ivf_nlist", C.c_int64, [_P]),
+    ("rvcmi_ivf_nprobe", C.c_int, [_P]),
+    ("rvcmi_ivf_set_nprobe", C.c_int, [_P, C.c_int]),
+    ("rvcmi_ivf_reserve", C.c_int, [_P, C.c_int64]),
+    ("rvcmi_ivf_search", C.c_int, [_P, C.c_int64, _P, C.c_int, _P, _P, _P]),
+    ("rvcmi_ivf_search_blend", C.c_int, [_P, C.c_int64, _P, C.c_float, C.c_int, C.c_int, _P]),
+    ("rvcmi_ivf_reconstruct_n", C.c_int, [_P, C.c_int64, C.c_int64, _P]),
+    ("rvcmi_ivf_blob", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("rvcmi_ivf_create_from_blob", C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("rvcmi_ivf_profile_enable", C.c_int, [_P, C.c_int]),
+    ("rvcmi_ivf_profile_read", C.c_int, [_P, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int), C.c_int]),
+]
+
+
+class RvcmiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(verbose: bool = True, force: bool = False) -> str:
+    """Compile librvcmi.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps.append(os.path.join(_HERE, "..", "include", "rvcmi.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for s in srcs:  # compile the translation units in parallel
+        o = os.path.join(CSRC, os.path.basename(s) + ".o")
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        if verbose:
+            print("[rvcmi build]", " ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode:
+            raise RvcmiError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if verbose:
+        print("[rvcmi build]", " ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode:
+        raise RvcmiError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RvcmiError(
+                "librvcmi.so is not built (%s).  Run `python __graft_entry__.py build`.  "
+                "There is no CPU fallback for the HIP hot path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(l, name)  # AttributeError if the header and the library drift apart
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().rvcmi_last_error()
+        raise RvcmiError("rvcmi error %d: %s" % (rc, msg.decode(errors="replace") if msg else "?"))
+
+
+def read_stats(read_fn, handle, reset: bool = True) -> List[dict]:
+    n = C.c_int(0)
+    buf = (KernelStat * 64)()
+    check(read_fn(handle, buf, 64, C.byref(n), 1 if reset else 0))
+    return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), ms=float(buf[i].ms),
+                 flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(min(n.value, 64))]

@@ -1,0 +1,694 @@
+// IVF-Flat (faiss IndexIVFFlat, METRIC_L2) retrieval for gfx950: nearest-centroid probe, in-list
+// squared-L2 scan with a per-wave top-k, and the reference's inverse-square blend
+// (infer/modules/vc/pipeline.py:126-138, infer/lib/rtrvc.py:172-185; index recipe web.py:544-563).
+//
+// This half of the hot path is HBM/L2-bound byte movement (a few dozen 1-3 KB rows per query), so it
+// is written as coalesced 16-byte row reads + wavefront-level reductions, NOT reshaped into a GEMM.
+// Distances are evaluated in fp64 on the fp32 inputs as sum((q-v)^2) -- the arithmetic cost is
+// irrelevant next to the row traffic, and it makes the ranking independent of summation order, which
+// is what allows bit-exact indices against the CPU oracle (ties -> lowest id).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace rvcmi {
+
+struct BlobHeader {  // first 128 bytes of the device blob; everything the kernels need is offset-addressed
+    uint64_t magic;  // "RVCMIIVF"
+    uint32_t version;
+    int32_t d;
+    int32_t nprobe;
+    int32_t pad0;
+    int64_t ntotal;
+    int64_t nlist;
+    int64_t pos_last;  // list-major position of the row whose id == ntotal-1 (numpy's big_npy[-1])
+    uint64_t off_centroids, off_list_offsets, off_ids, off_vecs;
+    uint64_t total_bytes;
+    uint64_t reserved[5];
+};
+static_assert(sizeof(BlobHeader) == 128, "blob header must be 128 bytes");
+static const uint64_t kMagic = 0x465649494d435652ull;  // "RVCMIIVF" little-endian
+
+__host__ __device__ static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+
+constexpr int QT = 8;  // queries per coarse block
+
+// Coarse quantiser, nprobe == 1: for QT queries (LDS, broadcast reads) every lane owns one centroid
+// at a time and accumulates QT fp64 distances for it -- no cross-lane reduction in the hot loop.
+// Each lane keeps its running best; one wave-level (dist, id) argmin per query at the end.
+__global__ void __launch_bounds__(256) k_coarse1(const float* __restrict__ q, const float* __restrict__ cent,
+                                                 int64_t nq, int64_t nlist, int d, int64_t* __restrict__ assign) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* qs = (float*)smem_raw;                               // [QT][d]
+    double* bd = (double*)(smem_raw + align_up((size_t)QT * d * 4, 16));  // [4 waves][QT]
+    int64_t* bi = (int64_t*)(bd + 4 * QT);
+    const int64_t q0 = (int64_t)blockIdx.x * QT;
+    const int nqb = (int)min((int64_t)QT, nq - q0);
+    for (int i = threadIdx.x; i < QT * d; i += 256) {
+        int qi = i / d;
+        qs[i] = qi < nqb ? q[(q0 + qi) * d + (i - qi * d)] : 0.f;
+    }
+    __syncthreads();
+    double best[QT];
+    int64_t besti[QT];
+#pragma unroll
+    for (int k = 0; k < QT; ++k) { best[k] = INFINITY; besti[k] = INT64_MAX; }
+    const int d4 = d >> 2;
+    for (int64_t c = threadIdx.x; c < nlist; c += 256) {
+        const float4* row = (const float4*)(cent + c * d);
+        double acc[QT];
+#pragma unroll
+        for (int k = 0; k < QT; ++k) acc[k] = 0.0;
+        for (int e = 0; e < d4; ++e) {
+            const float4 v = row[e];
+#pragma unroll
+            for (int k = 0; k < QT; ++k) {
+                const float4 qq = *(const float4*)(qs + k * d + e * 4);
+                double t0 = (double)qq.x - (double)v.x, t1 = (double)qq.y - (double)v.y;
+                double t2 = (double)qq.z - (double)v.z, t3 = (double)qq.w - (double)v.w;
+                acc[k] = fma(t0, t0, acc[k]);
+                acc[k] = fma(t1, t1, acc[k]);
+                acc[k] = fma(t2, t2, acc[k]);
+                acc[k] = fma(t3, t3, acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QT; ++k)
+            if (acc[k] < best[k]) { best[k] = acc[k]; besti[k] = c; }  // c ascending per lane: ties keep the lower id
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < QT; ++k) {
+        double bdv = best[k];
+        int64_t biv = besti[k];
+        for (int off = 32; off >= 1; off >>= 1) {
+            double od = __shfl_xor(bdv, off, 64);
+            int64_t oi = __shfl_xor(biv, off, 64);
+            if (od < bdv || (od == bdv && oi < biv)) { bdv = od; biv = oi; }
+        }
+        if (lane == 0) { bd[wave * QT + k] = bdv; bi[wave * QT + k] = biv; }
+    }
+    __syncthreads();
+    if (threadIdx.x < nqb) {
+        const int k = threadIdx.x;
+        double bdv = bd[k];
+        int64_t biv = bi[k];
+        for (int w = 1; w < 4; ++w) {
+            double od = bd[w * QT + k];
+            int64_t oi = bi[w * QT + k];
+            if (od < bdv || (od == bdv && oi < biv)) { bdv = od; biv = oi; }
+        }
+        assign[q0 + k] = biv;
+    }
+}
+
+// General nprobe: full fp64 distance rows into scratch, then one wave per query extracts the nprobe
+// smallest (dist, id) by repeated argmin.  Legacy indices only (tools/cmd/train-index.py used nprobe=9).
+__global__ void __launch_bounds__(256) k_coarse_dist(const float* __restrict__ q, const float* __restrict__ cent,
+                                                     int64_t nq, int64_t nlist, int d, double* __restrict__ dist) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * nlist) return;
+    const int64_t qi = i / nlist, c = i - qi * nlist;
+    const float* a = q + qi * d;
+    const float* b = cent + c * d;
+    double acc = 0.0;
+    for (int e = 0; e < d; ++e) {
+        double t = (double)a[e] - (double)b[e];
+        acc = fma(t, t, acc);
+    }
+    dist[i] = acc;
+}
+__global__ void __launch_bounds__(64) k_coarse_select(double* __restrict__ dist, int64_t nlist, int nprobe,
+                                                      int64_t* __restrict__ assign) {
+    const int64_t qi = blockIdx.x;
+    double* row = dist + qi * nlist;
+    const int lane = threadIdx.x;
+    for (int p = 0; p < nprobe; ++p) {
+        double bdv = INFINITY;
+        int64_t biv = INT64_MAX;
+        for (int64_t c = lane; c < nlist; c += 64) {
+            double v = row[c];
+            if (v < bdv) { bdv = v; biv = c; }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            double od = __shfl_xor(bdv, off, 64);
+            int64_t oi = __shfl_xor(biv, off, 64);
+            if (od < bdv || (od == bdv && oi < biv)) { bdv = od; biv = oi; }
+        }
+        if (lane == 0) {
+            assign[qi * nprobe + p] = biv == INT64_MAX ? -1 : biv;
+            if (biv != INT64_MAX) row[biv] = INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int KMAX = 8;
+
+struct TopK {
+    double d[KMAX];
+    int64_t id[KMAX];
+    int64_t pos[KMAX];
+};
+__device__ __forceinline__ bool before(double da, int64_t ia, double db, int64_t ib) { return da < db || (da == db && ia < ib); }
+__device__ __forceinline__ void topk_insert(TopK& t, double dv, int64_t idv, int64_t posv) {
+    // The list always carries KMAX sorted slots (static register indices); callers emit the first k.
+    if (!before(dv, idv, t.d[KMAX - 1], t.id[KMAX - 1])) return;
+    t.d[KMAX - 1] = dv;
+    t.id[KMAX - 1] = idv;
+    t.pos[KMAX - 1] = posv;
+#pragma unroll
+    for (int s = KMAX - 1; s >= 1; --s) {
+        if (before(t.d[s], t.id[s], t.d[s - 1], t.id[s - 1])) {
+            const double td = t.d[s]; t.d[s] = t.d[s - 1]; t.d[s - 1] = td;
+            const int64_t ti = t.id[s]; t.id[s] = t.id[s - 1]; t.id[s - 1] = ti;
+            const int64_t tp = t.pos[s]; t.pos[s] = t.pos[s - 1]; t.pos[s - 1] = tp;
+        }
+    }
+}
+
+// List scan: one wave per query.  The wave is split into 4 groups of 16 lanes; group g takes rows
+// g, g+4, ... of the probed list(s); inside a group lane s reads float4 chunks s, s+16, ... of the row
+// (16 lanes x 16 B = 256 contiguous bytes per load) and the 16 partial fp64 sums are combined with four
+// xor-shuffles.  Every lane of a group carries the group's sorted top-k; lane 0 merges the 4 groups.
+__global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const int64_t* __restrict__ assign, int nprobe,
+                                              const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
+                                              const float* __restrict__ vecs, int64_t nq, int d, int k,
+                                              float* __restrict__ D, int64_t* __restrict__ I, int64_t* __restrict__ P,
+                                              int* __restrict__ any_short) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    float* qs = (float*)smem_raw + (size_t)wave * d;
+    TopK* merge = (TopK*)(smem_raw + align_up((size_t)4 * d * 4, 16)) + wave * 4;
+    const bool active = qi < nq;
+    if (active)
+        for (int e = lane; e < d; e += 64) qs[e] = q[qi * d + e];
+    __syncthreads();
+    TopK t;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { t.d[s] = INFINITY; t.id[s] = INT64_MAX; t.pos[s] = -1; }
+    const int grp = lane >> 4, sub = lane & 15;
+    const int d4 = d >> 2;
+    if (active) {
+        for (int p = 0; p < nprobe; ++p) {
+            const int64_t l = assign[qi * nprobe + p];
+            if (l < 0) continue;
+            const int64_t beg = list_off[l], end = list_off[l + 1];
+            for (int64_t r = beg + grp; r < end; r += 4) {
+                const float4* row = (const float4*)(vecs + r * d);
+                double acc = 0.0;
+                for (int c = sub; c < d4; c += 16) {
+                    const float4 v = row[c];
+                    const float4 qq = *(const float4*)(qs + c * 4);
+                    double t0 = (double)qq.x - (double)v.x, t1 = (double)qq.y - (double)v.y;
+                    double t2 = (double)qq.z - (double)v.z, t3 = (double)qq.w - (double)v.w;
+                    acc = fma(t0, t0, acc);
+                    acc = fma(t1, t1, acc);
+                    acc = fma(t2, t2, acc);
+                    acc = fma(t3, t3, acc);
+                }
+                for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                topk_insert(t, acc, ids[r], r);
+            }
+        }
+        if (sub == 0) merge[grp] = t;
+    }
+    __syncthreads();
+    if (active && lane == 0) {
+        int idx[4] = {0, 0, 0, 0};
+        bool short_list = false;
+        for (int s = 0; s < k; ++s) {
+            int bg = -1;
+            for (int g = 0; g < 4; ++g) {
+                if (idx[g] >= KMAX) continue;
+                const double dv = merge[g].d[idx[g]];
+                const int64_t iv = merge[g].id[idx[g]];
+                if (iv == INT64_MAX) continue;
+                if (bg < 0 || before(dv, iv, merge[bg].d[idx[bg]], merge[bg].id[idx[bg]])) bg = g;
+            }
+            if (bg < 0) {  // fewer than k candidates: faiss pads with -1 / FLT_MAX
+                D[qi * k + s] = FLT_MAX;
+                I[qi * k + s] = -1;
+                P[qi * k + s] = -1;
+                short_list = true;
+            } else {
+                D[qi * k + s] = (float)merge[bg].d[idx[bg]];
+                I[qi * k + s] = merge[bg].id[idx[bg]];
+                P[qi * k + s] = merge[bg].pos[idx[bg]];
+                idx[bg]++;
+            }
+        }
+        if (short_list) atomicOr(any_short, 1);
+    }
+}
+
+// pipeline.py:129-138 with numpy's fp32 operation order:
+//   weight = np.square(1/score); weight /= weight.sum(axis=1, keepdims=True)      (pairwise sum of 8)
+//   npy = np.sum(big_npy[ix] * weight[..., None], axis=1)                          (sequential over k)
+//   feats = npy*index_rate + (1-index_rate)*feats
+// One block per query, threads over d.  id -1 gathers big_npy[-1] exactly like numpy does.
+__global__ void __launch_bounds__(256) k_blend(float* __restrict__ feats, const float* __restrict__ D,
+                                               const int64_t* __restrict__ P, const float* __restrict__ vecs, int d, int k,
+                                               int64_t pos_last, float rate, float omr, const int* __restrict__ any_short,
+                                               int skip_if_short) {
+#pragma clang fp contract(off)
+    if (skip_if_short && *any_short) return;
+    const int64_t qi = blockIdx.x;
+    float w[KMAX];
+    for (int s = 0; s < k; ++s) {
+        const float inv = __fdiv_rn(1.0f, D[qi * k + s]);
+        w[s] = __fmul_rn(inv, inv);
+    }
+    float sum;
+    if (k == 8) {
+        sum = __fadd_rn(__fadd_rn(__fadd_rn(w[0], w[1]), __fadd_rn(w[2], w[3])),
+                        __fadd_rn(__fadd_rn(w[4], w[5]), __fadd_rn(w[6], w[7])));
+    } else {
+        sum = w[0];
+        for (int s = 1; s < k; ++s) sum = __fadd_rn(sum, w[s]);
+    }
+    for (int s = 0; s < k; ++s) w[s] = __fdiv_rn(w[s], sum);
+    for (int e = threadIdx.x; e < d; e += 256) {
+        float acc = 0.f;
+        for (int s = 0; s < k; ++s) {
+            int64_t p = P[qi * k + s];
+            if (p < 0) p = pos_last;
+            const float prod = __fmul_rn(vecs[p * d + e], w[s]);
+            acc = s == 0 ? prod : __fadd_rn(acc, prod);
+        }
+        const float f = feats[qi * d + e];
+        feats[qi * d + e] = __fadd_rn(__fmul_rn(acc, rate), __fmul_rn(omr, f));
+    }
+}
+
+}  // namespace rvcmi
+
+using namespace rvcmi;
+
+struct rvcmi_ivf {
+    int device = 0;
+    BlobHeader hdr;
+    char* blob = nullptr;  // device
+    bool owns_blob = false;
+    // search workspace (grown on demand; see rvcmi_ivf_reserve)
+    int64_t cap_nq = 0;
+    int cap_nprobe = 0;
+    DevBuf assign, P, Dtmp, Itmp, flag, cdist;
+    Profiler prof;
+    const float* centroids() const { return (const float*)(blob + hdr.off_centroids); }
+    const int64_t* list_off() const { return (const int64_t*)(blob + hdr.off_list_offsets); }
+    const int64_t* ids() const { return (const int64_t*)(blob + hdr.off_ids); }
+    const float* vecs() const { return (const float*)(blob + hdr.off_vecs); }
+    ~rvcmi_ivf() {
+        if (owns_blob && blob) (void)hipFree(blob);
+    }
+};
+
+namespace rvcmi {
+
+static void validate(int d, int64_t n, int64_t nlist, int nprobe) {
+    if (d < 4 || (d & 3)) RVCMI_FAIL(RVCMI_ERR_INVALID, "dimension %d must be a positive multiple of 4", d);
+    if (n < 0 || nlist < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "bad sizes n=%lld nlist=%lld", (long long)n, (long long)nlist);
+    if (nprobe < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "nprobe must be >= 1");
+}
+
+static std::vector<char> build_blob(int d, int64_t n, int64_t nlist, int nprobe, const float* centroids,
+                                    const int64_t* list_offsets, const int64_t* ids, const float* vecs) {
+    validate(d, n, nlist, nprobe);
+    if (list_offsets[0] != 0 || list_offsets[nlist] != n) RVCMI_FAIL(RVCMI_ERR_INVALID, "list_offsets do not cover [0, n)");
+    for (int64_t l = 0; l < nlist; ++l)
+        if (list_offsets[l + 1] < list_offsets[l]) RVCMI_FAIL(RVCMI_ERR_INVALID, "list_offsets not monotone at %lld", (long long)l);
+    BlobHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = kMagic;
+    h.version = 1;
+    h.d = d;
+    h.nprobe = nprobe;
+    h.ntotal = n;
+    h.nlist = nlist;
+    h.pos_last = -1;
+    for (int64_t i = 0; i < n; ++i)
+        if (ids[i] == n - 1) h.pos_last = i;
+    if (h.pos_last < 0) h.pos_last = n > 0 ? n - 1 : 0;
+    uint64_t off = sizeof(BlobHeader);
+    h.off_centroids = off;
+    off = align_up(off + (uint64_t)nlist * d * 4, 256);
+    h.off_list_offsets = off;
+    off = align_up(off + (uint64_t)(nlist + 1) * 8, 256);
+    h.off_ids = off;
+    off = align_up(off + (uint64_t)std::max<int64_t>(n, 1) * 8, 256);
+    h.off_vecs = off;
+    off = align_up(off + (uint64_t)std::max<int64_t>(n, 1) * d * 4, 256);
+    h.total_bytes = off;
+    std::vector<char> blob(off, 0);
+    memcpy(blob.data(), &h, sizeof(h));
+    memcpy(blob.data() + h.off_centroids, centroids, (size_t)nlist * d * 4);
+    memcpy(blob.data() + h.off_list_offsets, list_offsets, (size_t)(nlist + 1) * 8);
+    if (n) {
+        memcpy(blob.data() + h.off_ids, ids, (size_t)n * 8);
+        memcpy(blob.data() + h.off_vecs, vecs, (size_t)n * d * 4);
+    }
+    return blob;
+}
+
+static rvcmi_ivf* from_host_blob(const std::vector<char>& blob, int device) {
+    HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<rvcmi_ivf> h(new rvcmi_ivf());
+    h->device = device;
+    memcpy(&h->hdr, blob.data(), sizeof(BlobHeader));
+    HIP_CHECK(hipMalloc((void**)&h->blob, blob.size()));
+    h->owns_blob = true;
+    HIP_CHECK(hipMemcpy(h->blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    return h.release();
+}
+
+// ---- faiss on-disk format (impl/index_write.cpp / index_read.cpp of faiss, as recalled; see
+//      oracle/ivf_oracle.py for the independent python twin used to cross-check this reader) ----
+struct Reader {
+    FILE* f;
+    const char* path;
+    void read(void* dst, size_t n) {
+        if (n && fread(dst, 1, n, f) != n) RVCMI_FAIL(RVCMI_ERR_IO, "%s: truncated file", path);
+    }
+    template <typename T>
+    T get() {
+        T v;
+        read(&v, sizeof(T));
+        return v;
+    }
+    void fourcc(char out[5]) {
+        read(out, 4);
+        out[4] = 0;
+    }
+};
+struct FileCloser {
+    FILE* f;
+    ~FileCloser() {
+        if (f) fclose(f);
+    }
+};
+
+static void read_index_header(Reader& r, int& d, int64_t& ntotal, int& metric) {
+    d = r.get<int32_t>();
+    ntotal = r.get<int64_t>();
+    (void)r.get<int64_t>();
+    (void)r.get<int64_t>();
+    (void)r.get<uint8_t>();  // is_trained
+    metric = r.get<int32_t>();
+    if (metric > 1) (void)r.get<float>();
+}
+
+static rvcmi_ivf* read_faiss(const char* path, int device) {
+    FILE* f = fopen(path, "rb");
+    if (!f) RVCMI_FAIL(RVCMI_ERR_IO, "cannot open '%s'", path);
+    FileCloser fc{f};
+    Reader r{f, path};
+    char cc[5];
+    r.fourcc(cc);
+    if (strcmp(cc, "IwFl")) RVCMI_FAIL(RVCMI_ERR_IO, "%s: fourcc '%s' is not an IndexIVFFlat (IwFl)", path, cc);
+    int d, metric;
+    int64_t ntotal;
+    read_index_header(r, d, ntotal, metric);
+    if (metric != 1) RVCMI_FAIL(RVCMI_ERR_IO, "%s: metric %d; only METRIC_L2 (web.py:547) is supported", path, metric);
+    const uint64_t nlist = r.get<uint64_t>();
+    const uint64_t nprobe = r.get<uint64_t>();
+    r.fourcc(cc);
+    if (strcmp(cc, "IxF2") && strcmp(cc, "IxFl")) RVCMI_FAIL(RVCMI_ERR_IO, "%s: quantizer '%s' is not a flat L2 index", path, cc);
+    int qd, qmetric;
+    int64_t qn;
+    read_index_header(r, qd, qn, qmetric);
+    const uint64_t nfl = r.get<uint64_t>();
+    if (qd != d || (uint64_t)qn != nlist || nfl != nlist * (uint64_t)d) RVCMI_FAIL(RVCMI_ERR_IO, "%s: quantizer shape mismatch", path);
+    std::vector<float> cent(nfl);
+    r.read(cent.data(), nfl * 4);
+    (void)r.get<int8_t>();  // direct map type
+    const uint64_t dmn = r.get<uint64_t>();
+    if (fseek(f, (long)(dmn * 8), SEEK_CUR)) RVCMI_FAIL(RVCMI_ERR_IO, "%s: truncated direct map", path);
+    r.fourcc(cc);
+    if (strcmp(cc, "ilar")) RVCMI_FAIL(RVCMI_ERR_IO, "%s: inverted lists '%s' are not ArrayInvertedLists", path, cc);
+    const uint64_t nl2 = r.get<uint64_t>(), code_size = r.get<uint64_t>();
+    if (nl2 != nlist || code_size != 4ull * d) RVCMI_FAIL(RVCMI_ERR_IO, "%s: inverted-list header mismatch", path);
+    r.fourcc(cc);
+    std::vector<int64_t> off(nlist + 1, 0);
+    std::vector<uint64_t> sizes(nlist, 0);
+    const uint64_t cnt = r.get<uint64_t>();
+    if (!strcmp(cc, "full")) {
+        if (cnt != nlist) RVCMI_FAIL(RVCMI_ERR_IO, "%s: 'full' size vector length", path);
+        r.read(sizes.data(), cnt * 8);
+    } else if (!strcmp(cc, "sprs")) {
+        std::vector<uint64_t> pairs(cnt);
+        r.read(pairs.data(), cnt * 8);
+        for (uint64_t i = 0; i + 1 < cnt; i += 2) {
+            if (pairs[i] >= nlist) RVCMI_FAIL(RVCMI_ERR_IO, "%s: sparse list id out of range", path);
+            sizes[pairs[i]] = pairs[i + 1];
+        }
+    } else {
+        RVCMI_FAIL(RVCMI_ERR_IO, "%s: unknown list size encoding '%s'", path, cc);
+    }
+    for (uint64_t l = 0; l < nlist; ++l) off[l + 1] = off[l] + (int64_t)sizes[l];
+    const int64_t n = off[nlist];
+    if (n != ntotal) RVCMI_FAIL(RVCMI_ERR_IO, "%s: lists hold %lld rows, header says %lld", path, (long long)n, (long long)ntotal);
+    std::vector<float> vecs((size_t)std::max<int64_t>(n, 1) * d);
+    std::vector<int64_t> ids(std::max<int64_t>(n, 1));
+    for (uint64_t l = 0; l < nlist; ++l) {
+        if (!sizes[l]) continue;
+        r.read(vecs.data() + (size_t)off[l] * d, sizes[l] * d * 4);
+        r.read(ids.data() + off[l], sizes[l] * 8);
+    }
+    auto blob = build_blob(d, n, (int64_t)nlist, (int)std::max<uint64_t>(1, nprobe), cent.data(), off.data(), ids.data(), vecs.data());
+    return from_host_blob(blob, device);
+}
+
+static void write_faiss(const rvcmi_ivf* h, const char* path) {
+    std::vector<char> blob(h->hdr.total_bytes);
+    HIP_CHECK(hipMemcpy(blob.data(), h->blob, blob.size(), hipMemcpyDeviceToHost));
+    const BlobHeader& b = h->hdr;
+    FILE* f = fopen(path, "wb");
+    if (!f) RVCMI_FAIL(RVCMI_ERR_IO, "cannot create '%s'", path);
+    FileCloser fc{f};
+    auto put = [&](const void* p, size_t n) {
+        if (n && fwrite(p, 1, n, f) != n) RVCMI_FAIL(RVCMI_ERR_IO, "%s: short write", path);
+    };
+    auto header = [&](int32_t d, int64_t nt) {
+        int64_t dummy = 1 << 20;
+        uint8_t trained = 1;
+        int32_t metric = 1;
+        put(&d, 4); put(&nt, 8); put(&dummy, 8); put(&dummy, 8); put(&trained, 1); put(&metric, 4);
+    };
+    const uint64_t nlist = b.nlist, nprobe = b.nprobe;
+    put("IwFl", 4);
+    header(b.d, b.ntotal);
+    put(&nlist, 8); put(&nprobe, 8);
+    put("IxF2", 4);
+    header(b.d, b.nlist);
+    const uint64_t nfl = nlist * (uint64_t)b.d;
+    put(&nfl, 8);
+    put(blob.data() + b.off_centroids, nfl * 4);
+    int8_t dm = 0;
+    uint64_t zero = 0;
+    put(&dm, 1); put(&zero, 8);
+    put("ilar", 4);
+    const uint64_t code_size = 4ull * b.d;
+    put(&nlist, 8); put(&code_size, 8);
+    const int64_t* off = (const int64_t*)(blob.data() + b.off_list_offsets);
+    uint64_t nonzero = 0;
+    for (uint64_t l = 0; l < nlist; ++l) nonzero += off[l + 1] > off[l];
+    if (nonzero > nlist / 2) {
+        put("full", 4);
+        put(&nlist, 8);
+        for (uint64_t l = 0; l < nlist; ++l) { uint64_t s = off[l + 1] - off[l]; put(&s, 8); }
+    } else {
+        put("sprs", 4);
+        uint64_t cnt = nonzero * 2;
+        put(&cnt, 8);
+        for (uint64_t l = 0; l < nlist; ++l)
+            if (off[l + 1] > off[l]) { uint64_t s = off[l + 1] - off[l]; put(&l, 8); put(&s, 8); }
+    }
+    for (uint64_t l = 0; l < nlist; ++l) {
+        const uint64_t s = off[l + 1] - off[l];
+        if (!s) continue;
+        put(blob.data() + b.off_vecs + (size_t)off[l] * b.d * 4, s * b.d * 4);
+        put(blob.data() + b.off_ids + (size_t)off[l] * 8, s * 8);
+    }
+}
+
+static void reserve(rvcmi_ivf* h, int64_t nq) {
+    const int np = (int)std::min<int64_t>(h->hdr.nprobe, h->hdr.nlist);
+    if (nq <= h->cap_nq && np <= h->cap_nprobe && h->flag.p) return;
+    HIP_CHECK(hipSetDevice(h->device));
+    nq = std::max<int64_t>(nq, h->cap_nq);
+    h->assign.alloc((size_t)std::max<int64_t>(nq, 1) * np * 8);
+    h->P.alloc((size_t)std::max<int64_t>(nq, 1) * KMAX * 8);
+    h->Dtmp.alloc((size_t)std::max<int64_t>(nq, 1) * KMAX * 4);
+    h->Itmp.alloc((size_t)std::max<int64_t>(nq, 1) * KMAX * 8);
+    if (!h->flag.p) h->flag.alloc(256);
+    if (np > 1) h->cdist.alloc((size_t)std::max<int64_t>(nq, 1) * h->hdr.nlist * 8);
+    h->cap_nq = nq;
+    h->cap_nprobe = np;
+}
+
+static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, int64_t* I, hipStream_t st) {
+    if (!h || nq < 0 || (nq && (!q || !D || !I))) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+    if (k < 1 || k > KMAX) RVCMI_FAIL(RVCMI_ERR_INVALID, "k=%d outside [1,%d]", k, KMAX);
+    if (nq == 0) return;
+    reserve(h, nq);
+    const BlobHeader& b = h->hdr;
+    const int d = b.d;
+    const int np = (int)std::min<int64_t>(b.nprobe, b.nlist);
+    HIP_CHECK(hipMemsetAsync(h->flag.p, 0, 4, st));
+    const double cflops = 3.0 * (double)nq * b.nlist * d;
+    if (np == 1) {
+        const size_t smem = align_up((size_t)QT * d * 4, 16) + 4 * QT * 16;
+        h->prof.launch("ivf_coarse", cflops, (double)nq * d * 4 + (double)b.nlist * d * 4, st, [&] {
+            hipLaunchKernelGGL(k_coarse1, dim3((unsigned)((nq + QT - 1) / QT)), dim3(256), smem, st, q, h->centroids(), nq,
+                               b.nlist, d, h->assign.as<int64_t>());
+        });
+    } else {
+        h->prof.launch("ivf_coarse", cflops, (double)nq * b.nlist * 8, st, [&] {
+            const int64_t tot = nq * b.nlist;
+            hipLaunchKernelGGL(k_coarse_dist, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, q, h->centroids(), nq,
+                               b.nlist, d, h->cdist.as<double>());
+            hipLaunchKernelGGL(k_coarse_select, dim3((unsigned)nq), dim3(64), 0, st, h->cdist.as<double>(), b.nlist, np,
+                               h->assign.as<int64_t>());
+        });
+    }
+    const double rows = b.nlist ? (double)b.ntotal / (double)b.nlist * np : 0;
+    const size_t smem = align_up((size_t)4 * d * 4, 16) + 16 * sizeof(TopK);
+    h->prof.launch("ivf_scan", 3.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
+        hipLaunchKernelGGL(k_scan, dim3((unsigned)((nq + 3) / 4)), dim3(256), smem, st, q, h->assign.as<int64_t>(), np,
+                           h->list_off(), h->ids(), h->vecs(), nq, d, k, D, I, h->P.as<int64_t>(), h->flag.as<int>());
+    });
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace rvcmi
+
+extern "C" {
+
+int rvcmi_ivf_create_from_file(const char* path, int device, rvcmi_ivf** out) {
+    return guarded([&] {
+        if (!path || !out) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        *out = read_faiss(path, device);
+    });
+}
+int rvcmi_ivf_write_file(const rvcmi_ivf* h, const char* path) {
+    return guarded([&] {
+        if (!h || !path) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        write_faiss(h, path);
+    });
+}
+int rvcmi_ivf_create(int d, int64_t n, int64_t nlist, int nprobe, const float* centroids, const int64_t* list_offsets,
+                     const int64_t* ids, const float* vecs, int device, rvcmi_ivf** out) {
+    return guarded([&] {
+        if (!centroids || !list_offsets || !out || (n && (!ids || !vecs))) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        auto blob = build_blob(d, n, nlist, nprobe, centroids, list_offsets, ids, vecs);
+        *out = from_host_blob(blob, device);
+    });
+}
+int rvcmi_ivf_destroy(rvcmi_ivf* h) {
+    return guarded([&] { delete h; });
+}
+int rvcmi_ivf_d(const rvcmi_ivf* h) { return h ? h->hdr.d : RVCMI_ERR_INVALID; }
+int64_t rvcmi_ivf_ntotal(const rvcmi_ivf* h) { return h ? h->hdr.ntotal : RVCMI_ERR_INVALID; }
+int64_t rvcmi_ivf_nlist(const rvcmi_ivf* h) { return h ? h->hdr.nlist : RVCMI_ERR_INVALID; }
+int rvcmi_ivf_nprobe(const rvcmi_ivf* h) { return h ? h->hdr.nprobe : RVCMI_ERR_INVALID; }
+int rvcmi_ivf_set_nprobe(rvcmi_ivf* h, int nprobe) {
+    return guarded([&] {
+        if (!h || nprobe < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "bad nprobe");
+        h->hdr.nprobe = nprobe;
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipMemcpy(h->blob, &h->hdr, sizeof(BlobHeader), hipMemcpyHostToDevice));
+    });
+}
+int rvcmi_ivf_reserve(rvcmi_ivf* h, int64_t max_nq) {
+    return guarded([&] {
+        if (!h || max_nq < 0) RVCMI_FAIL(RVCMI_ERR_INVALID, "bad argument");
+        reserve(h, max_nq);
+    });
+}
+int rvcmi_ivf_search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, int64_t* I, void* stream) {
+    return guarded([&] { search(h, nq, q, k, D, I, (hipStream_t)stream); });
+}
+int rvcmi_ivf_search_blend(rvcmi_ivf* h, int64_t nq, float* feats, float index_rate, int k, int skip_if_short, void* stream) {
+    return guarded([&] {
+        if (!h || (nq && !feats)) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        if (nq == 0) return;
+        hipStream_t st = (hipStream_t)stream;
+        reserve(h, nq);
+        search(h, nq, feats, k, h->Dtmp.as<float>(), h->Itmp.as<int64_t>(), st);
+        const int d = h->hdr.d;
+        // torch evaluates `npy * index_rate + (1 - index_rate) * feats` with the python scalars cast to fp32
+        const float rate = index_rate, omr = (float)(1.0 - (double)index_rate);
+        h->prof.launch("ivf_blend", 2.0 * nq * k * d, (double)nq * d * 4 * (2 + k), st, [&] {
+            hipLaunchKernelGGL(k_blend, dim3((unsigned)nq), dim3(256), 0, st, feats, h->Dtmp.as<float>(), h->P.as<int64_t>(),
+                               h->vecs(), d, k, h->hdr.pos_last, rate, omr, h->flag.as<int>(), skip_if_short);
+        });
+        HIP_CHECK(hipGetLastError());
+    });
+}
+int rvcmi_ivf_reconstruct_n(const rvcmi_ivf* h, int64_t i0, int64_t n, float* out_host) {
+    return guarded([&] {
+        if (!h || !out_host) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        const BlobHeader& b = h->hdr;
+        if (i0 < 0 || n < 0 || i0 + n > b.ntotal) RVCMI_FAIL(RVCMI_ERR_INVALID, "range [%lld,%lld) outside ntotal %lld",
+                                                                 (long long)i0, (long long)(i0 + n), (long long)b.ntotal);
+        if (!n) return;
+        HIP_CHECK(hipSetDevice(h->device));
+        std::vector<int64_t> ids(b.ntotal);
+        std::vector<float> vecs((size_t)b.ntotal * b.d);
+        HIP_CHECK(hipMemcpy(ids.data(), h->blob + b.off_ids, ids.size() * 8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(vecs.data(), h->blob + b.off_vecs, vecs.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t p = 0; p < b.ntotal; ++p) {
+            const int64_t id = ids[p];
+            if (id >= i0 && id < i0 + n) memcpy(out_host + (size_t)(id - i0) * b.d, vecs.data() + (size_t)p * b.d, (size_t)b.d * 4);
+        }
+    });
+}
+int rvcmi_ivf_blob(const rvcmi_ivf* h, void** dev_ptr, size_t* bytes) {
+    return guarded([&] {
+        if (!h || !dev_ptr || !bytes) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        *dev_ptr = h->blob;
+        *bytes = h->hdr.total_bytes;
+    });
+}
+int rvcmi_ivf_create_from_blob(void* dev_ptr, size_t bytes, int device, int take_ownership, rvcmi_ivf** out) {
+    return guarded([&] {
+        if (!dev_ptr || !out || bytes < sizeof(BlobHeader)) RVCMI_FAIL(RVCMI_ERR_INVALID, "bad blob");
+        HIP_CHECK(hipSetDevice(device));
+        std::unique_ptr<rvcmi_ivf> h(new rvcmi_ivf());
+        h->device = device;
+        HIP_CHECK(hipMemcpy(&h->hdr, dev_ptr, sizeof(BlobHeader), hipMemcpyDeviceToHost));
+        if (h->hdr.magic != kMagic || h->hdr.version != 1 || h->hdr.total_bytes != bytes)
+            RVCMI_FAIL(RVCMI_ERR_INVALID, "not an rvcmi IVF blob (magic/version/size mismatch)");
+        validate(h->hdr.d, h->hdr.ntotal, h->hdr.nlist, h->hdr.nprobe);
+        h->blob = (char*)dev_ptr;
+        h->owns_blob = take_ownership != 0;
+        *out = h.release();
+    });
+}
+int rvcmi_ivf_profile_enable(rvcmi_ivf* h, int enable) {
+    return guarded([&] {
+        if (!h) RVCMI_FAIL(RVCMI_ERR_INVALID, "null handle");
+        h->prof.enabled = enable != 0;
+    });
+}
+int rvcmi_ivf_profile_read(rvcmi_ivf* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset) {
+    return guarded([&] {
+        if (!h) RVCMI_FAIL(RVCMI_ERR_INVALID, "null handle");
+        h->prof.read(stats, capacity, n, reset);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,704 @@
+// Host side of the generator: weight preparation (stands in for rvc/synthesizer.py:10-28 for
+// `net_g.dec`), workspace, and the launch sequence of NSFGenerator.forward (rvc/layers/nsf.py:145-191)
+// / Generator.forward (rvc/layers/generators.py:70-98).
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <memory>
+#include <string>
+#include <unordered_map>
+
+#include "common.hpp"
+#include "nsf_kernels.hpp"
+
+namespace rvcmi {
+
+thread_local std::string g_last_error;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+// ---- host float -> operand conversions (round-to-nearest-even, like the device casts) -----------
+static inline uint16_t f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline uint16_t f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+
+struct Geom {
+    int MI, NJ, WCO, TT;
+};
+// Block/wave tiling per output-channel count (see k_conv_mfma): waves split output channels first
+// (each wave streams its OWN weight slice), time second.
+static Geom conv_geom(int cout) {
+    Geom g;
+    g.NJ = 4;
+    if (cout >= 256) { g.MI = 2; g.WCO = 4; }
+    else if (cout >= 128) { g.MI = 2; g.WCO = 2; }
+    else if (cout >= 64) { g.MI = 2; g.WCO = 1; }
+    else { g.MI = 1; g.WCO = 1; }
+    g.TT = (4 / g.WCO) * g.NJ * 32;
+    return g;
+}
+
+// One convolution (or one polyphase transposed convolution = `nphase` small convolutions).
+struct ConvLayer {
+    int cin = 0, cout = 0;
+    int nphase = 1;
+    int dstep = 1;
+    int ntaps[16] = {0};   // real taps per phase
+    int in_off[16] = {0};  // input row of (q, tap 0) relative to q, per phase
+    int ntaps_p = 0;       // padded tap count used by the MFMA kernel (uniform over phases)
+    long f32_off[16] = {0};
+    long pack_off[16] = {0};
+    long ct_stride = 0;    // packed elements per 32-channel output tile
+    DevBuf w_f32, w_pack, bias;
+    double flops_per_pos = 0;  // 2*cin*cout*sum(real taps) per output position q (all phases)
+};
+
+using WFn = std::function<float(int co, int ci, int phase, int tap)>;
+
+static void build_conv(ConvLayer& L, int cin, int cout, int nphase, const int* ntaps, const int* in_off, int dstep,
+                       const WFn& W, const float* bias, int operand) {
+    L.cin = cin;
+    L.cout = cout;
+    L.nphase = nphase;
+    L.dstep = dstep;
+    int jmax = 0, jsum = 0;
+    for (int p = 0; p < nphase; ++p) {
+        L.ntaps[p] = ntaps[p];
+        L.in_off[p] = in_off[p];
+        jmax = std::max(jmax, ntaps[p]);
+        jsum += ntaps[p];
+    }
+    L.flops_per_pos = 2.0 * cin * cout * jsum;
+    if (bias) {
+        L.bias.alloc(sizeof(float) * cout);
+        HIP_CHECK(hipMemcpy(L.bias.p, bias, sizeof(float) * cout, hipMemcpyHostToDevice));
+    }
+    if (operand == RVCMI_OPERAND_F32) {
+        std::vector<float> w((size_t)jsum * cin * cout);
+        long off = 0;
+        for (int p = 0; p < nphase; ++p) {
+            L.f32_off[p] = off;
+            for (int j = 0; j < ntaps[p]; ++j)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int co = 0; co < cout; ++co) w[off + ((size_t)j * cin + ci) * cout + co] = W(co, ci, p, j);
+            off += (long)ntaps[p] * cin * cout;
+        }
+        L.w_f32.alloc(w.size() * sizeof(float));
+        HIP_CHECK(hipMemcpy(L.w_f32.p, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+        L.ntaps_p = jmax;
+        return;
+    }
+    if (cin % 16) RVCMI_FAIL(RVCMI_ERR_INVALID, "MFMA path needs C_in %% 16 == 0 (got %d)", cin);
+    const int CC = cin / 16;
+    const int tpg = CC >= KGROUP ? 1 : KGROUP / CC;
+    if (CC >= KGROUP ? (CC % KGROUP) : (KGROUP % CC)) RVCMI_FAIL(RVCMI_ERR_INVALID, "unsupported C_in %d", cin);
+    L.ntaps_p = (jmax + tpg - 1) / tpg * tpg;
+    const int KSP = L.ntaps_p * CC;
+    const int ctiles = (cout + 31) / 32;
+    L.ct_stride = (long)KSP * 512;
+    std::vector<uint16_t> pk((size_t)nphase * ctiles * L.ct_stride, 0);
+    for (int p = 0; p < nphase; ++p) {
+        L.pack_off[p] = (long)p * ctiles * L.ct_stride;
+        for (int ct = 0; ct < ctiles; ++ct)
+            for (int tap = 0; tap < ntaps[p]; ++tap)
+                for (int cc = 0; cc < CC; ++cc) {
+                    uint16_t* dst = pk.data() + L.pack_off[p] + (size_t)ct * L.ct_stride + (size_t)(tap * CC + cc) * 512;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = ct * 32 + (lane & 31);
+                        if (co >= cout) continue;
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = cc * 16 + 8 * (lane >> 5) + e;
+                            const float v = W(co, ci, p, tap);
+                            dst[lane * 8 + e] = operand == RVCMI_OPERAND_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+                        }
+                    }
+                }
+    }
+    L.w_pack.alloc(pk.size() * 2);
+    HIP_CHECK(hipMemcpy(L.w_pack.p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+}
+
+struct Stage {
+    int cin, cout, u, k, pad;
+    ConvLayer up;
+    // noise conv (nsf.py:103-115)
+    int nk = 0, ns = 1, npad = 0;
+    DevBuf noise_w, noise_b;
+    // resblocks[j].pair[m] = {conv1, conv2}
+    std::vector<std::vector<std::pair<ConvLayer, ConvLayer>>> rb;
+};
+
+}  // namespace rvcmi
+
+using namespace rvcmi;
+
+struct rvcmi_nsf {
+    rvcmi_nsf_config cfg;
+    int device = 0;
+    int max_B = 0, max_T = 0;
+    int upp = 1;
+    int C0 = 0;
+    ConvLayer pre;
+    DevBuf cond_w, cond_b;
+    float lin_w = 1.f, lin_b = 0.f;
+    std::vector<Stage> stages;
+    DevBuf post_w;
+    int c_last = 0;
+    // workspace
+    size_t S = 0;  // elements per activation buffer
+    DevBuf XS[2], X0, Xa, Xb, H, har, har2, x2, phase, condv, dbg;
+    size_t ws_bytes = 0;
+    Profiler prof;
+};
+
+namespace rvcmi {
+
+struct WeightMap {
+    std::unordered_map<std::string, const rvcmi_tensor*> m;
+    const rvcmi_tensor& get(const std::string& name, std::initializer_list<int64_t> shape) const {
+        auto it = m.find(name);
+        if (it == m.end()) RVCMI_FAIL(RVCMI_ERR_MISSING, "missing weight tensor '%s'", name.c_str());
+        const rvcmi_tensor& t = *it->second;
+        if ((size_t)t.ndim != shape.size()) RVCMI_FAIL(RVCMI_ERR_INVALID, "weight '%s': ndim %d", name.c_str(), t.ndim);
+        int i = 0;
+        for (int64_t s : shape) {
+            if (t.shape[i] != s)
+                RVCMI_FAIL(RVCMI_ERR_INVALID, "weight '%s': dim %d is %lld, expected %lld", name.c_str(), i,
+                           (long long)t.shape[i], (long long)s);
+            ++i;
+        }
+        return t;
+    }
+};
+
+static void upload(DevBuf& d, const std::vector<float>& v) {
+    d.alloc(v.size() * sizeof(float));
+    HIP_CHECK(hipMemcpy(d.p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+}
+
+static void set_lds_limits();
+
+static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights, int n_weights, int device, int max_B,
+                       int max_T, rvcmi_nsf** out) {
+    if (!cfg || !out || (!weights && n_weights)) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+    if (cfg->n_ups < 1 || cfg->n_ups > RVCMI_MAX_UPS || cfg->n_resblock_kernels < 1 ||
+        cfg->n_resblock_kernels > RVCMI_MAX_RB)
+        RVCMI_FAIL(RVCMI_ERR_INVALID, "bad stage counts");
+    if (cfg->operand < 0 || cfg->operand > 2) RVCMI_FAIL(RVCMI_ERR_INVALID, "bad operand type %d", cfg->operand);
+    if (max_B < 1 || max_T < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "max_B/max_T must be positive");
+    HIP_CHECK(hipSetDevice(device));
+    set_lds_limits();
+
+    std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
+    h->cfg = *cfg;
+    h->device = device;
+    h->max_B = max_B;
+    h->max_T = max_T;
+    const int op = cfg->operand;
+    WeightMap wm;
+    for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
+
+    const int C0 = cfg->upsample_initial_channel, inter = cfg->inter_channels;
+    h->C0 = C0;
+    {  // conv_pre: Conv1d(inter, C0, 7, padding=3)   nsf.py:84-86
+        const rvcmi_tensor& w = wm.get("conv_pre.weight", {C0, inter, 7});
+        const rvcmi_tensor& b = wm.get("conv_pre.bias", {C0});
+        const float* wd = w.data;
+        int nt = 7, off = -3;
+        build_conv(h->pre, inter, C0, 1, &nt, &off, 1,
+                   [=](int co, int ci, int, int tap) { return wd[((size_t)co * inter + ci) * 7 + tap]; }, b.data, op);
+    }
+    if (cfg->gin_channels) {  // cond: Conv1d(gin, C0, 1)   nsf.py:129-130
+        const rvcmi_tensor& w = wm.get("cond.weight", {C0, cfg->gin_channels, 1});
+        const rvcmi_tensor& b = wm.get("cond.bias", {C0});
+        upload(h->cond_w, std::vector<float>(w.data, w.data + (size_t)C0 * cfg->gin_channels));
+        upload(h->cond_b, std::vector<float>(b.data, b.data + C0));
+    }
+    if (cfg->use_f0) {  // m_source.l_linear: Linear(1,1)   nsf.py:51
+        h->lin_w = wm.get("m_source.l_linear.weight", {1, 1}).data[0];
+        h->lin_b = wm.get("m_source.l_linear.bias", {1}).data[0];
+    }
+    int upp = 1;
+    for (int i = 0; i < cfg->n_ups; ++i) upp *= cfg->upsample_rates[i];
+    h->upp = upp;
+
+    h->stages.resize(cfg->n_ups);
+    size_t S = (size_t)max_T * C0;
+    long L = max_T;
+    for (int i = 0; i < cfg->n_ups; ++i) {
+        Stage& s = h->stages[i];
+        s.cin = C0 >> i;
+        s.cout = C0 >> (i + 1);
+        s.u = cfg->upsample_rates[i];
+        s.k = cfg->upsample_kernel_sizes[i];
+        s.pad = (s.k - s.u) / 2;
+        if (s.u > 16) RVCMI_FAIL(RVCMI_ERR_INVALID, "upsample rate %d > 16 unsupported", s.u);
+        if (s.cout < 4 || (s.cout & 3)) RVCMI_FAIL(RVCMI_ERR_INVALID, "stage %d has %d channels", i, s.cout);
+        // The reference requires len(ups) == len(noise_convs): (L-1)*u - 2*pad + k == u*L  <=>  k - 2*pad == u
+        if (s.k - 2 * s.pad != s.u) RVCMI_FAIL(RVCMI_ERR_INVALID, "stage %d: k-u must be even (k=%d,u=%d)", i, s.k, s.u);
+        L *= s.u;
+        S = std::max(S, (size_t)L * s.cout);
+        {  // ups[i]: ConvTranspose1d(cin, cout, k, u, padding=(k-u)//2)   nsf.py:92-102
+            // out[q*u + r] = sum_j x[q + off_r - j] * W[:, :, cm_r + j*u],  c = r + pad, off_r = c / u, cm_r = c % u
+            const rvcmi_tensor& w = wm.get("ups." + std::to_string(i) + ".weight", {s.cin, s.cout, s.k});
+            const rvcmi_tensor& b = wm.get("ups." + std::to_string(i) + ".bias", {s.cout});
+            int nt[16], off[16], cm[16];
+            for (int r = 0; r < s.u; ++r) {
+                const int c = r + s.pad;
+                off[r] = c / s.u;
+                cm[r] = c % s.u;
+                nt[r] = (s.k - cm[r] + s.u - 1) / s.u;
+            }
+            const float* wd = w.data;
+            const int cout = s.cout, k = s.k, u = s.u;
+            std::vector<int> cmv(cm, cm + s.u);
+            build_conv(s.up, s.cin, s.cout, s.u, nt, off, -1,
+                       [=](int co, int ci, int p, int tap) { return wd[((size_t)ci * cout + co) * k + cmv[p] + tap * u]; },
+                       b.data, op);
+        }
+        if (cfg->use_f0) {  // noise_convs[i]   nsf.py:103-115
+            int sf = 1;
+            for (int j = i + 1; j < cfg->n_ups; ++j) sf *= cfg->upsample_rates[j];
+            const bool last = i + 1 == cfg->n_ups;
+            s.nk = last ? 1 : 2 * sf;
+            s.ns = last ? 1 : sf;
+            s.npad = last ? 0 : sf / 2;
+            const rvcmi_tensor& w = wm.get("noise_convs." + std::to_string(i) + ".weight", {s.cout, 1, s.nk});
+            const rvcmi_tensor& b = wm.get("noise_convs." + std::to_string(i) + ".bias", {s.cout});
+            std::vector<float> wt((size_t)s.nk * s.cout);
+            for (int co = 0; co < s.cout; ++co)
+                for (int j = 0; j < s.nk; ++j) wt[(size_t)j * s.cout + co] = w.data[(size_t)co * s.nk + j];
+            upload(s.noise_w, wt);
+            upload(s.noise_b, std::vector<float>(b.data, b.data + s.cout));
+        }
+        s.rb.resize(cfg->n_resblock_kernels);
+        for (int j = 0; j < cfg->n_resblock_kernels; ++j) {  // ResBlock1   residuals.py:19-58
+            const int n = i * cfg->n_resblock_kernels + j;
+            const int k = cfg->resblock_kernel_sizes[j];
+            const int nd = cfg->n_dilations[j];
+            if (nd < 1 || nd > RVCMI_MAX_DIL || !(k & 1)) RVCMI_FAIL(RVCMI_ERR_INVALID, "bad resblock %d", j);
+            s.rb[j].resize(nd);
+            for (int m = 0; m < nd; ++m) {
+                const int d = cfg->resblock_dilation_sizes[j][m];
+                const std::string base = "resblocks." + std::to_string(n);
+                const int C = s.cout;
+                for (int which = 0; which < 2; ++which) {
+                    const std::string nm = base + (which ? ".convs2." : ".convs1.") + std::to_string(m);
+                    const rvcmi_tensor& w = wm.get(nm + ".weight", {C, C, k});
+                    const rvcmi_tensor& b = wm.get(nm + ".bias", {C});
+                    const int dil = which ? 1 : d;
+                    int nt = k, off = -((k * dil - dil) / 2);  // get_padding, rvc/layers/utils.py:14
+                    const float* wd = w.data;
+                    ConvLayer& L2 = which ? s.rb[j][m].second : s.rb[j][m].first;
+                    build_conv(L2, C, C, 1, &nt, &off, dil,
+                               [=](int co, int ci, int, int tap) { return wd[((size_t)co * C + ci) * k + tap]; }, b.data, op);
+                }
+            }
+        }
+    }
+    h->c_last = C0 >> cfg->n_ups;
+    {  // conv_post: Conv1d(ch, 1, 7, padding=3, bias=False)   nsf.py:126
+        const rvcmi_tensor& w = wm.get("conv_post.weight", {1, h->c_last, 7});
+        std::vector<float> wt((size_t)7 * h->c_last);
+        for (int c = 0; c < h->c_last; ++c)
+            for (int j = 0; j < 7; ++j) wt[(size_t)j * h->c_last + c] = w.data[(size_t)c * 7 + j];
+        upload(h->post_w, wt);
+    }
+    if (h->c_last & 3) RVCMI_FAIL(RVCMI_ERR_INVALID, "last stage channel count %d", h->c_last);
+
+    // workspace
+    h->S = S * (size_t)max_B;
+    const size_t fb = h->S * sizeof(float);
+    h->XS[0].alloc(fb);
+    h->XS[1].alloc(fb);
+    h->X0.alloc(fb);
+    h->Xa.alloc(fb);
+    h->Xb.alloc(fb);
+    h->H.alloc(fb);
+    const size_t hb = (size_t)max_B * max_T * upp * sizeof(float);
+    h->har.alloc(hb);
+    h->har2.alloc(hb);
+    h->x2.alloc((size_t)max_B * inter * max_T * sizeof(float));
+    h->phase.alloc((size_t)max_B * max_T * sizeof(float));
+    h->condv.alloc((size_t)max_B * C0 * sizeof(float));
+    HIP_CHECK(hipMemset(h->condv.p, 0, h->condv.bytes));
+    h->ws_bytes = 6 * fb + 2 * hb + h->x2.bytes + h->phase.bytes + h->condv.bytes;
+    *out = h.release();
+}
+
+// ---- launches -----------------------------------------------------------------------------------
+
+template <typename OpT, int CIN, int MI, int NJ, int WCO>
+static void launch_inst(const ConvArgs& a, int B, hipStream_t st) {
+    using TL = Tile<CIN>;
+    constexpr int TT = (4 / WCO) * NJ * 32;
+    const int co_blocks = (a.cout + 32 * MI * WCO - 1) / (32 * MI * WCO);
+    dim3 grid((a.Lq + TT - 1) / TT, co_blocks * a.nphase, B);
+    const size_t smem = (size_t)a.tile_rows * TL::STRIDE;
+    if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "LDS tile too large: %zu bytes (cin %d)", smem, CIN);
+    hipLaunchKernelGGL((k_conv_mfma<OpT, CIN, MI, NJ, WCO>), grid, dim3(256), smem, st, a);
+}
+
+template <typename OpT, int CIN, int MI, int NJ, int WCO>
+static void set_lds_inst() {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_mfma<OpT, CIN, MI, NJ, WCO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+}
+
+#define RVCMI_FOR_EACH_CIN(X, OpT, MI, NJ, WCO) \
+    X(OpT, 16, MI, NJ, WCO)                     \
+    X(OpT, 32, MI, NJ, WCO)                     \
+    X(OpT, 64, MI, NJ, WCO)                     \
+    X(OpT, 128, MI, NJ, WCO)                    \
+    X(OpT, 192, MI, NJ, WCO)                    \
+    X(OpT, 256, MI, NJ, WCO)                    \
+    X(OpT, 512, MI, NJ, WCO)
+
+template <typename OpT, int MI, int NJ, int WCO>
+static void launch_by_cin(const ConvArgs& a, int B, hipStream_t st) {
+    switch (a.cin) {
+#define X(OpT_, CIN_, MI_, NJ_, WCO_) \
+    case CIN_:                        \
+        return launch_inst<OpT_, CIN_, MI_, NJ_, WCO_>(a, B, st);
+        RVCMI_FOR_EACH_CIN(X, OpT, MI, NJ, WCO)
+#undef X
+        default:
+            RVCMI_FAIL(RVCMI_ERR_INVALID, "unsupported C_in %d for the MFMA path", a.cin);
+    }
+}
+
+template <typename OpT>
+static void launch_conv_mfma(const ConvArgs& a, int B, hipStream_t st) {
+    const Geom g = conv_geom(a.cout);
+    if (g.MI == 2 && g.WCO == 4) return launch_by_cin<OpT, 2, 4, 4>(a, B, st);
+    if (g.MI == 2 && g.WCO == 2) return launch_by_cin<OpT, 2, 4, 2>(a, B, st);
+    if (g.MI == 2 && g.WCO == 1) return launch_by_cin<OpT, 2, 4, 1>(a, B, st);
+    return launch_by_cin<OpT, 1, 4, 1>(a, B, st);
+}
+
+template <typename OpT>
+static void set_lds_all() {
+#define X(OpT_, CIN_, MI_, NJ_, WCO_) set_lds_inst<OpT_, CIN_, MI_, NJ_, WCO_>();
+    RVCMI_FOR_EACH_CIN(X, OpT, 2, 4, 4)
+    RVCMI_FOR_EACH_CIN(X, OpT, 2, 4, 2)
+    RVCMI_FOR_EACH_CIN(X, OpT, 2, 4, 1)
+    RVCMI_FOR_EACH_CIN(X, OpT, 1, 4, 1)
+#undef X
+}
+static void set_lds_limits() {
+    set_lds_all<__bf16>();
+    set_lds_all<_Float16>();
+}
+
+// Fill the common part of ConvArgs for `L` and launch it in the handle's operand mode.
+static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const char* name, hipStream_t st) {
+    a.cin = L.cin;
+    a.cout = L.cout;
+    a.bias = L.bias.as<float>();
+    a.dstep = L.dstep;
+    a.nphase = L.nphase;
+    const int op = h->cfg.operand;
+    int jsum = 0;
+    for (int p = 0; p < L.nphase; ++p) {
+        a.ph_in_off[p] = L.in_off[p];
+        a.ph_ntaps[p] = L.ntaps[p];
+        a.ph_w_off[p] = op == RVCMI_OPERAND_F32 ? L.f32_off[p] : L.pack_off[p];
+        jsum += L.ntaps[p];
+    }
+    a.in_off = L.in_off[0];
+    const double flops = L.flops_per_pos * (double)a.Lq * B;
+    const size_t esz = op == RVCMI_OPERAND_F32 ? 4 : 2;
+    double bytes = (double)B * a.Lin * L.cin * (a.in_mode == IN_OP_RAW ? esz : 4) +
+                   (double)B * a.Lq * L.nphase * L.cout * (a.out_mode == OUT_ACT ? esz : 4) * (a.accumulate ? 2 : 1) +
+                   (a.res ? (double)B * a.Lq * L.nphase * L.cout * 4 : 0) + (double)jsum * L.cin * L.cout * esz;
+    if (op == RVCMI_OPERAND_F32) {
+        a.w = L.w_f32.p;
+        a.ntaps = L.ntaps[0];
+        a.roff = 0;
+        a.tile_rows = 0;
+        const size_t n = (size_t)a.Lq * a.cout;
+        dim3 grid((unsigned)((n + 255) / 256), L.nphase, B);
+        h->prof.launch(name, flops, bytes, st, [&] { hipLaunchKernelGGL(k_conv_f32, grid, dim3(256), 0, st, a); });
+    } else {
+        const Geom g = conv_geom(L.cout);
+        a.w = L.w_pack.p;
+        a.w_ct_stride = L.ct_stride;
+        a.ntaps = L.ntaps_p;
+        const int span = (L.ntaps_p - 1) * std::abs(L.dstep);
+        a.roff = L.dstep < 0 ? span : 0;
+        a.tile_rows = g.TT + span;
+        h->prof.launch(name, flops, bytes, st, [&] {
+            if (op == RVCMI_OPERAND_BF16) launch_conv_mfma<__bf16>(a, B, st);
+            else launch_conv_mfma<_Float16>(a, B, st);
+        });
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+static ConvArgs base_args() {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.slope_in = 0.1f;
+    a.div_in = 1.f;
+    a.slope_out = 0.1f;
+    a.out_mul = 1;
+    a.nphase = 1;
+    return a;
+}
+
+struct TapRequest {
+    const char* what = nullptr;
+    float* out_host = nullptr;
+    size_t capacity = 0;
+    int64_t* shape = nullptr;
+    bool done = false;
+};
+
+static void copy_tap_cl(rvcmi_nsf* h, const float* src_cl, int B, int L, int C, TapRequest* tr, hipStream_t st) {
+    const size_t n = (size_t)B * L * C;
+    if (n > tr->capacity) RVCMI_FAIL(RVCMI_ERR_NOMEM, "tap needs %zu floats, capacity %zu", n, tr->capacity);
+    if (h->dbg.bytes < n * 4) h->dbg.alloc(n * 4);
+    dim3 grid((unsigned)(((size_t)L * C + 255) / 256), B);
+    hipLaunchKernelGGL(k_cl_to_cf, grid, dim3(256), 0, st, src_cl, h->dbg.as<float>(), L, C);
+    HIP_CHECK(hipMemcpyAsync(tr->out_host, h->dbg.p, n * 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    tr->shape[0] = B;
+    tr->shape[1] = C;
+    tr->shape[2] = L;
+    tr->done = true;
+}
+
+static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float* f0, const float* g,
+                        const float* noise, int n_res, float* out, hipStream_t st, TapRequest* tr) {
+    if (!h || !x || (!out && !tr)) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+    const rvcmi_nsf_config& c = h->cfg;
+    if (c.use_f0 && !f0) RVCMI_FAIL(RVCMI_ERR_INVALID, "f0 is required for an NSF (use_f0) generator");
+    if (B < 1 || T < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "B and T must be positive");
+    const int Te = n_res >= 0 ? n_res : T;
+    if (Te < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "n_res must be positive");
+    if (B > h->max_B || T > h->max_T || Te > h->max_T)
+        RVCMI_FAIL(RVCMI_ERR_NOMEM, "shape B=%d T=%d n_res=%d exceeds handle limits (max_B=%d max_T=%d)", B, T, n_res,
+                   h->max_B, h->max_T);
+    HIP_CHECK(hipSetDevice(h->device));
+    const int upp = h->upp, inter = c.inter_channels, C0 = h->C0;
+    const int op = c.operand;
+    auto want = [&](const char* w) { return tr && strcmp(tr->what, w) == 0; };
+
+    // ---- excitation: har[B][Te*upp]                                           nsf.py:152-153
+    const float* har = nullptr;
+    if (c.use_f0) {
+        h->prof.launch("phase_scan", 0, (double)B * T * 8, st, [&] {
+            hipLaunchKernelGGL(k_phase_scan, dim3(B), dim3(64), 0, st, f0, h->phase.as<float>(), T, (float)c.sr, (float)upp);
+        });
+        const size_t total = (size_t)B * T * upp;
+        h->prof.launch("sine_source", 0, (double)total * (noise ? 8 : 4), st, [&] {
+            hipLaunchKernelGGL(k_sine_source, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, f0,
+                               h->phase.as<float>(), noise, h->har.as<float>(), T, upp, (float)c.sr, h->lin_w, h->lin_b, total);
+        });
+        har = h->har.as<float>();
+        if (n_res >= 0 && Te != T) {  // nsf.py:155-159
+            const size_t tot2 = (size_t)B * Te * upp;
+            hipLaunchKernelGGL(k_interp_linear, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, st, har,
+                               h->har2.as<float>(), T * upp, Te * upp, tot2);
+            har = h->har2.as<float>();
+        }
+        HIP_CHECK(hipGetLastError());
+        if (want("har")) {
+            const size_t n = (size_t)B * Te * upp;
+            if (n > tr->capacity) RVCMI_FAIL(RVCMI_ERR_NOMEM, "tap capacity");
+            HIP_CHECK(hipMemcpyAsync(tr->out_host, har, n * 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            tr->shape[0] = B; tr->shape[1] = 1; tr->shape[2] = (int64_t)Te * upp;
+            tr->done = true;
+            return;
+        }
+    }
+    if (n_res >= 0 && Te != T) {  // nsf.py:160-162 / generators.py:76-79
+        const size_t tot = (size_t)B * inter * Te;
+        hipLaunchKernelGGL(k_interp_linear, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x, h->x2.as<float>(), T, Te, tot);
+        x = h->x2.as<float>();
+    }
+    // ---- conv_pre + cond                                                       nsf.py:164-166
+    if (g && c.gin_channels) {
+        hipLaunchKernelGGL(k_cond, dim3((C0 + 255) / 256, B), dim3(256), 0, st, g, h->cond_w.as<float>(),
+                           h->cond_b.as<float>(), h->condv.as<float>(), c.gin_channels, C0);
+    }
+    float* cur = h->XS[0].as<float>();
+    int cur_idx = 0;
+    {
+        ConvArgs a = base_args();
+        a.in = x;
+        a.in_bstride = (long)inter * Te;
+        a.Lin = Te;
+        a.in_mode = IN_F32_CF;
+        a.Lq = Te;
+        a.out_mode = OUT_F32;
+        a.out = cur;
+        a.out_bstride = (long)Te * C0;
+        a.out_C = C0;
+        a.cb = (g && c.gin_channels) ? h->condv.as<float>() : nullptr;
+        run_conv(h, h->pre, a, B, "conv_pre", st);
+    }
+    if (want("pre")) return copy_tap_cl(h, cur, B, Te, C0, tr, st);
+
+    long L = Te;
+    int Cprev = C0;
+    float div = 1.f;
+    const size_t esz = op == RVCMI_OPERAND_F32 ? 4 : 2;
+    (void)esz;
+    for (int i = 0; i < c.n_ups; ++i) {
+        Stage& s = h->stages[i];
+        const long Lin = L;
+        L = Lin * s.u;
+        const int C = s.cout;
+        char nm[48];
+        {  // x = ups[i](leaky_relu(x, 0.1))                                    nsf.py:171-172
+            ConvArgs a = base_args();
+            a.in = cur;
+            a.in_bstride = Lin * Cprev;
+            a.Lin = (int)Lin;
+            a.in_mode = IN_F32_ACT;
+            a.div_in = div;
+            a.Lq = (int)Lin;
+            a.out_mode = OUT_F32;
+            a.out = h->X0.p;
+            a.out_bstride = L * C;
+            a.out_C = C;
+            a.out_mul = s.u;
+            snprintf(nm, sizeof(nm), "ups_c%d", s.cin);
+            run_conv(h, s.up, a, B, nm, st);
+        }
+        if (c.use_f0) {  // x = x + noise_convs[i](har)                           nsf.py:173-174
+            const size_t n = (size_t)L * C;
+            snprintf(nm, sizeof(nm), "noise_conv_c%d", C);
+            h->prof.launch(nm, 2.0 * s.nk * n * B, (double)B * n * 8, st, [&] {
+                hipLaunchKernelGGL(k_noise_add, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, h->X0.as<float>(),
+                                   har, s.noise_w.as<float>(), s.noise_b.as<float>(), (int)L, C, Te * upp, s.nk, s.ns, s.npad);
+            });
+        }
+        snprintf(nm, sizeof(nm), "up%d", i);
+        if (want(nm)) return copy_tap_cl(h, h->X0.as<float>(), B, (int)L, C, tr, st);
+        // xs = sum_j resblocks[i*nk+j](x)                                        nsf.py:175-185
+        float* xs = h->XS[cur_idx ^ 1].as<float>();
+        for (size_t j = 0; j < s.rb.size(); ++j) {
+            const float* src = h->X0.as<float>();
+            const size_t nd = s.rb[j].size();
+            for (size_t m = 0; m < nd; ++m) {  // residuals.py:73-82
+                const bool last = m + 1 == nd;
+                snprintf(nm, sizeof(nm), "rb_c%d", C);
+                {
+                    ConvArgs a = base_args();
+                    a.in = src;
+                    a.in_bstride = L * C;
+                    a.Lin = (int)L;
+                    a.in_mode = IN_F32_ACT;
+                    a.Lq = (int)L;
+                    a.out_mode = OUT_ACT;
+                    a.out = h->H.p;
+                    a.out_bstride = L * C;
+                    a.out_C = C;
+                    run_conv(h, s.rb[j][m].first, a, B, nm, st);
+                }
+                float* dst = last ? xs : (src == h->Xa.as<float>() ? h->Xb.as<float>() : h->Xa.as<float>());
+                {
+                    ConvArgs a = base_args();
+                    a.in = h->H.p;
+                    a.in_bstride = L * C;
+                    a.Lin = (int)L;
+                    a.in_mode = IN_OP_RAW;
+                    a.Lq = (int)L;
+                    a.out_mode = OUT_F32;
+                    a.out = dst;
+                    a.out_bstride = L * C;
+                    a.out_C = C;
+                    a.res = src;
+                    a.res_bstride = L * C;
+                    a.accumulate = last && j > 0;
+                    run_conv(h, s.rb[j][m].second, a, B, nm, st);
+                }
+                src = dst;
+            }
+        }
+        cur_idx ^= 1;
+        cur = xs;
+        div = (float)s.rb.size();  // x = xs / num_kernels (nsf.py:186) is applied by the consumer
+        Cprev = C;
+        snprintf(nm, sizeof(nm), "stage%d", i);
+        if (want(nm)) return copy_tap_cl(h, cur, B, (int)L, C, tr, st);  // NOTE: the un-divided sum
+    }
+    if (tr) RVCMI_FAIL(RVCMI_ERR_INVALID, "unknown tap '%s'", tr->what);
+    // ---- x = tanh(conv_post(leaky_relu(x)))                                    nsf.py:187-189
+    h->prof.launch("conv_post", 2.0 * 7 * Cprev * (double)L * B, (double)B * L * (Cprev + 1) * 4, st, [&] {
+        hipLaunchKernelGGL(k_post, dim3((unsigned)((L + 255) / 256), B), dim3(256), (size_t)7 * Cprev * 4, st, cur,
+                           h->post_w.as<float>(), out, (int)L, Cprev, div);
+    });
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace rvcmi
+
+// ---- C ABI -------------------------------------------------------------------------------------
+extern "C" {
+
+const char* rvcmi_last_error(void) { return g_last_error.c_str(); }
+int rvcmi_version(void) { return RVCMI_VERSION; }
+
+int rvcmi_nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights, int n_weights, int device, int max_B,
+                     int max_T, rvcmi_nsf** out) {
+    return guarded([&] { nsf_create(cfg, weights, n_weights, device, max_B, max_T, out); });
+}
+int rvcmi_nsf_destroy(rvcmi_nsf* h) {
+    return guarded([&] { delete h; });
+}
+int rvcmi_nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float* f0, const float* g, const float* noise,
+                      int n_res, float* out, void* stream) {
+    return guarded([&] { nsf_forward(h, B, T, x, f0, g, noise, n_res, out, (hipStream_t)stream, nullptr); });
+}
+int rvcmi_nsf_upp(const rvcmi_nsf* h) { return h ? h->upp : RVCMI_ERR_INVALID; }
+size_t rvcmi_nsf_workspace_bytes(const rvcmi_nsf* h) { return h ? h->ws_bytes : 0; }
+
+int rvcmi_nsf_debug_forward(rvcmi_nsf* h, int B, int T, const float* x, const float* f0, const float* g,
+                            const float* noise, int n_res, const char* what, float* out_host, size_t capacity_floats,
+                            int64_t shape_out[3], void* stream) {
+    return guarded([&] {
+        if (!what || !out_host || !shape_out) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        TapRequest tr;
+        tr.what = what;
+        tr.out_host = out_host;
+        tr.capacity = capacity_floats;
+        tr.shape = shape_out;
+        nsf_forward(h, B, T, x, f0, g, noise, n_res, nullptr, (hipStream_t)stream, &tr);
+        if (!tr.done) RVCMI_FAIL(RVCMI_ERR_INVALID, "tap '%s' was not produced", what);
+    });
+}
+
+int rvcmi_nsf_profile_enable(rvcmi_nsf* h, int enable) {
+    return guarded([&] {
+        if (!h) RVCMI_FAIL(RVCMI_ERR_INVALID, "null handle");
+        h->prof.enabled = enable != 0;
+    });
+}
+int rvcmi_nsf_profile_read(rvcmi_nsf* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset) {
+    return guarded([&] {
+        if (!h) RVCMI_FAIL(RVCMI_ERR_INVALID, "null handle");
+        h->prof.read(stats, capacity, n, reset);
+    });
+}
+
+}  // extern "C"

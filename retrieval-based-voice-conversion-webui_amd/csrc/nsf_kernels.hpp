@@ -1,0 +1,490 @@
+// Device code of the NSF-HiFi-GAN generator for gfx950 (CDNA4).
+//
+// Internal activation layout is CHANNELS-LAST  [B][L][C]  (fp32 residual stream; the activated
+// MFMA operand copies are OpT = bf16 / fp16).  With channels last, one MFMA B-fragment of a k-tap
+// dilated convolution is "8 consecutive input channels of ONE time row": a single 16-byte LDS
+// read, and moving to the next tap is a constant row offset -- no im2col is ever materialised.
+//
+// Reference semantics reproduced here (file:line in /root/reference):
+//   sine source            rvc/layers/generators.py:148-194
+//   tanh(Linear(1,1))      rvc/layers/nsf.py:57-61
+//   conv_pre + cond        rvc/layers/nsf.py:164-166
+//   ups / noise_convs      rvc/layers/nsf.py:169-174
+//   ResBlock1              rvc/layers/residuals.py:68-85
+//   stage mean, post, tanh rvc/layers/nsf.py:186-189
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rvcmi {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// ------------------------------------------------------------------------------------------------
+// Sine source (generators.py:148-194) + source module (nsf.py:57-61)
+// ------------------------------------------------------------------------------------------------
+
+// phase[b][t] = fmod(float(sum_{tau<t} w_tau), 1), w_tau = fmod(f0/sr*upp + 0.5, 1) - 0.5.
+// torch's CPU cumsum accumulates fp32 inputs in DOUBLE and rounds each prefix to fp32
+// (verified against torch 2.10); a wave-level scan in fp64 reproduces that to the last bit except
+// on exact rounding boundaries.  One wave (64 lanes) per utterance.
+__global__ void __launch_bounds__(64) k_phase_scan(const float* __restrict__ f0, float* __restrict__ phase,
+                                                   int T, float sr, float upp) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* f = f0 + (size_t)b * T;
+    float* ph = phase + (size_t)b * T;
+    const int n = T - 1;  // increments come from frames 0..T-2
+    const int per = (n + 63) / 64;
+    const int beg = lane * per;
+    const int end = min(n, beg + per);
+    double local = 0.0;
+    for (int t = beg; t < end; ++t) {
+        float rad = __fmul_rn(__fdiv_rn(f[t], sr), upp);
+        float w = __fsub_rn(fmodf(__fadd_rn(rad, 0.5f), 1.0f), 0.5f);
+        local += (double)w;
+    }
+    // inclusive wave scan of the per-lane sums
+    double incl = local;
+    for (int off = 1; off < 64; off <<= 1) {
+        double o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    double run = incl - local;  // exclusive prefix
+    if (lane == 0) ph[0] = 0.f;
+    for (int t = beg; t < end; ++t) {
+        float rad = __fmul_rn(__fdiv_rn(f[t], sr), upp);
+        float w = __fsub_rn(fmodf(__fadd_rn(rad, 0.5f), 1.0f), 0.5f);
+        run += (double)w;
+        ph[t + 1] = fmodf((float)run, 1.0f);
+    }
+}
+
+// har[b][t*upp + n-1] = tanh(lw * (0.1*sin(2*pi*(f0/sr*n + phase)) * uv + amp * noise) + lb)
+__global__ void __launch_bounds__(256) k_sine_source(const float* __restrict__ f0, const float* __restrict__ phase,
+                                                     const float* __restrict__ noise, float* __restrict__ har,
+                                                     int T, int upp, float sr, float lw, float lb, size_t total) {
+#pragma clang fp contract(off)
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    size_t frame = i / (size_t)upp;  // b*T + t
+    int n = (int)(i - frame * upp) + 1;
+    float f = f0[frame];
+    float rad = __fadd_rn(__fmul_rn(__fdiv_rn(f, sr), (float)n), phase[frame]);
+    float s = __fmul_rn(sinf(__fmul_rn(6.2831855f, rad)), 0.1f);
+    float uv = f > 0.f ? 1.f : 0.f;
+    float amp = f > 0.f ? 0.003f : __fdiv_rn(0.1f, 3.0f);
+    float nz = noise ? noise[i] : 0.f;
+    float v = __fadd_rn(__fmul_rn(s, uv), __fmul_rn(amp, nz));
+    har[i] = tanhf(__fadd_rn(__fmul_rn(v, lw), lb));
+}
+
+// F.interpolate(mode="linear", align_corners=False) along the last axis of [rows][Lin] -> [rows][Lout]
+// (nsf.py:155-162, generators.py:76-79).
+__global__ void __launch_bounds__(256) k_interp_linear(const float* __restrict__ in, float* __restrict__ out,
+                                                       int Lin, int Lout, size_t total) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    size_t row = i / (size_t)Lout;
+    int o = (int)(i - row * Lout);
+    float scale = (float)Lin / (float)Lout;
+    float src = scale * ((float)o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    int i0 = (int)src;
+    if (i0 > Lin - 1) i0 = Lin - 1;
+    int i1 = i0 + (i0 < Lin - 1 ? 1 : 0);
+    float l1 = src - (float)i0;
+    float l0 = 1.f - l1;
+    const float* r = in + row * (size_t)Lin;
+    out[i] = l0 * r[i0] + l1 * r[i1];
+}
+
+// cond(g): a 1x1 conv over a length-1 sequence = one GEMV per utterance (nsf.py:165-166).
+__global__ void __launch_bounds__(256) k_cond(const float* __restrict__ g, const float* __restrict__ Wc,
+                                              const float* __restrict__ bc, float* __restrict__ out, int gin, int C0) {
+    int b = blockIdx.y;
+    int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= C0) return;
+    float acc = 0.f;
+    for (int i = 0; i < gin; ++i) acc = fmaf(Wc[(size_t)co * gin + i], g[(size_t)b * gin + i], acc);
+    out[(size_t)b * C0 + co] = acc + bc[co];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact-fp32 VALU kernels (RVCMI_OPERAND_F32): correctness-first reference-grade path on the GPU.
+// ------------------------------------------------------------------------------------------------
+
+enum InMode : int {
+    IN_F32_ACT = 0,   // fp32 channels-last, apply v = lrelu(v / div, slope) on load
+    IN_OP_RAW = 1,    // already-activated operand copy (OpT in MFMA mode, fp32 in F32 mode)
+    IN_F32_CF = 2     // fp32 channel-first [B][C][L] raw (conv_pre input, the reference layout)
+};
+enum OutMode : int {
+    OUT_ACT = 0,      // out = lrelu(acc + bias, slope_out) stored as operand type
+    OUT_F32 = 1       // out (+)= acc + bias (+ res) (+ cb[b][co]) stored fp32
+};
+
+struct ConvArgs {
+    // input
+    const void* in;
+    long in_bstride;   // elements per batch item
+    int Lin;           // valid input rows
+    int cin;
+    int in_mode;
+    float slope_in, div_in;
+    // weights
+    const void* w;     // F32: [taps][cin][cout] fp32.  MFMA: packed fragments (see pack_conv_weights)
+    long w_ct_stride;  // MFMA: elements per 32-channel output tile
+    const float* bias; // [cout] or nullptr
+    int cout;
+    // geometry: output position q, tap j reads input row  q + in_off + j*dstep
+    int ntaps;         // real taps (F32) / padded taps (MFMA)
+    int in_off, dstep;
+    int roff;          // MFMA: LDS tile row of (q = q0, tap 0) ; tile starts at input row q0+in_off-roff
+    int tile_rows;     // MFMA: rows staged in LDS
+    int Lq;            // output positions
+    // output
+    int out_mode;
+    void* out;
+    long out_bstride;
+    int out_C;         // channels per output row
+    int out_mul, out_add;  // output row = q*out_mul + out_add  (polyphase transposed conv)
+    float slope_out;
+    const float* res;  // fp32 residual [B][Lq][out_C] or nullptr
+    long res_bstride;
+    int accumulate;    // out += ...
+    const float* cb;   // per-(batch, channel) additive term [B][cout] or nullptr
+    // polyphase (transposed conv): blockIdx.y selects the phase; per-phase geometry
+    int nphase;
+    int ph_in_off[16];
+    int ph_ntaps[16];   // F32 only
+    long ph_w_off[16];  // element offset into w
+};
+
+// One thread per (q, co); co fastest so that weight reads and stores coalesce.
+__global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
+    const int b = blockIdx.z;
+    const int ph = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)a.Lq * a.cout) return;
+    const int q = (int)(i / a.cout);
+    const int co = (int)(i - (size_t)q * a.cout);
+    const int in_off = a.nphase > 1 ? a.ph_in_off[ph] : a.in_off;
+    const int ntaps = a.nphase > 1 ? a.ph_ntaps[ph] : a.ntaps;
+    const float* W = (const float*)a.w + (a.nphase > 1 ? a.ph_w_off[ph] : 0);
+    const float* in = (const float*)a.in + (size_t)b * a.in_bstride;
+    float acc = a.bias ? a.bias[co] : 0.f;
+    for (int j = 0; j < ntaps; ++j) {
+        const int r = q + in_off + j * a.dstep;
+        if (r < 0 || r >= a.Lin) continue;
+        const float* wj = W + (size_t)j * a.cin * a.cout + co;
+        if (a.in_mode == IN_F32_CF) {
+            for (int ci = 0; ci < a.cin; ++ci) acc = fmaf(in[(size_t)ci * a.Lin + r], wj[(size_t)ci * a.cout], acc);
+        } else if (a.in_mode == IN_F32_ACT) {
+            const float* row = in + (size_t)r * a.cin;
+            for (int ci = 0; ci < a.cin; ++ci) {
+                float v = row[ci];
+                if (a.div_in != 1.f) v = v / a.div_in;
+                acc = fmaf(lrelu(v, a.slope_in), wj[(size_t)ci * a.cout], acc);
+            }
+        } else {
+            const float* row = in + (size_t)r * a.cin;
+            for (int ci = 0; ci < a.cin; ++ci) acc = fmaf(row[ci], wj[(size_t)ci * a.cout], acc);
+        }
+    }
+    const size_t orow = (size_t)q * a.out_mul + (a.nphase > 1 ? ph : a.out_add);
+    if (a.out_mode == OUT_ACT) {
+        ((float*)a.out)[(size_t)b * a.out_bstride + orow * a.out_C + co] = lrelu(acc, a.slope_out);
+    } else {
+        if (a.cb) acc = acc + a.cb[(size_t)b * a.cout + co];
+        if (a.res) acc = acc + a.res[(size_t)b * a.res_bstride + orow * a.out_C + co];
+        float* o = (float*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co;
+        *o = a.accumulate ? (*o + acc) : acc;
+    }
+}
+
+// x[b][t][co] += bn[co] + sum_j har[b][t*s - pad + j] * Wn[j][co]      (nsf.py:173-174)
+__global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x, const float* __restrict__ har,
+                                                   const float* __restrict__ Wn /*[k][C]*/, const float* __restrict__ bn,
+                                                   int L, int C, int Lh, int k, int s, int pad) {
+    const int b = blockIdx.z;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)L * C) return;
+    const int t = (int)(i / C);
+    const int co = (int)(i - (size_t)t * C);
+    const float* h = har + (size_t)b * Lh;
+    float acc = bn[co];
+    const int base = t * s - pad;
+    for (int j = 0; j < k; ++j) {
+        int r = base + j;
+        if (r >= 0 && r < Lh) acc = fmaf(h[r], Wn[(size_t)j * C + co], acc);
+    }
+    x[((size_t)b * L + t) * C + co] += acc;
+}
+
+// out[b][t] = tanh(sum_{j,ci} lrelu(x[t-3+j][ci]/div, 0.01) * Wp[j][ci])    (nsf.py:187-189)
+// One thread per output sample, the [7][C] filter in LDS.  HBM-bound: reads the last stage once.
+__global__ void __launch_bounds__(256) k_post(const float* __restrict__ x, const float* __restrict__ Wp /*[7][C]*/,
+                                              float* __restrict__ out, int L, int C, float div) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* w = (float*)smem_raw;
+    for (int i = threadIdx.x; i < 7 * C; i += 256) w[i] = Wp[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= L) return;
+    const float* xb = x + (size_t)b * L * C;
+    float acc = 0.f;
+    for (int j = 0; j < 7; ++j) {
+        int r = t - 3 + j;
+        if (r < 0 || r >= L) continue;
+        const float4* row = (const float4*)(xb + (size_t)r * C);
+        const float* wj = w + j * C;
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            float4 v = row[c4];
+            float e0 = v.x, e1 = v.y, e2 = v.z, e3 = v.w;
+            if (div != 1.f) { e0 = e0 / div; e1 = e1 / div; e2 = e2 / div; e3 = e3 / div; }
+            acc = fmaf(lrelu(e0, 0.01f), wj[c4 * 4 + 0], acc);
+            acc = fmaf(lrelu(e1, 0.01f), wj[c4 * 4 + 1], acc);
+            acc = fmaf(lrelu(e2, 0.01f), wj[c4 * 4 + 2], acc);
+            acc = fmaf(lrelu(e3, 0.01f), wj[c4 * 4 + 3], acc);
+        }
+    }
+    out[(size_t)b * L + t] = tanhf(acc);
+}
+
+// channels-last fp32 [B][L][C] -> channel-first [B][C][L] (debug taps only)
+__global__ void __launch_bounds__(256) k_cl_to_cf(const float* __restrict__ in, float* __restrict__ out, int L, int C) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)L * C) return;
+    const int c = (int)(i / L);
+    const int t = (int)(i - (size_t)c * L);
+    out[(size_t)b * L * C + i] = in[((size_t)b * L + t) * C + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA convolution (RVCMI_OPERAND_BF16 / _F16)
+// ------------------------------------------------------------------------------------------------
+//
+// GEMM view of a k-tap conv: D[co][t] = sum_{tap,ci} W[co][tap,ci] * X[t + off(tap)][ci]
+//   M = output channels, N = time, K = taps*C_in, instruction v_mfma_f32_32x32x16_{bf16,f16}.
+//   A (weights)      lane l holds W[co = l&31][k = 8*(l>>5) .. +8]  -> pre-packed in that exact
+//                    order on the host, streamed global->VGPR (each wave owns its own co slice,
+//                    so LDS staging would buy nothing), double-buffered one k-group ahead.
+//   B (activations)  lane l holds X[t = l&31][ci = 8*(l>>5) .. +8]  -> ONE ds_read_b128 from the
+//                    channels-last LDS tile; rows padded by 16 B so the 16 lanes of a read group
+//                    hit 16 distinct 16-byte bank slots.
+//   D                lane l holds t = l&31, co = (r&3) + 8*(r>>2) + 4*(l>>5)  -> 4 consecutive
+//                    channels per register quad = one float4 (or 8-byte OpT) store per quad.
+// The activation tile is staged ONCE per block and reused by every tap and every output channel,
+// so the K loop has no barrier at all.
+
+template <typename OpT>
+struct Op;
+template <>
+struct Op<__bf16> {
+    using frag = bf16x8;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Op<_Float16> {
+    using frag = f16x8;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+constexpr int KGROUP = 4;  // k-steps (of 16) per software-pipeline group
+
+template <int CIN>
+struct Tile {
+    static constexpr int CC = CIN / 16;              // k-steps per tap
+    static constexpr int STRIDE = CIN * 2 + 16;      // bytes per LDS row (16-B pad: conflict-free b128 reads)
+    static constexpr int TAPS_PER_GROUP = (CC >= KGROUP) ? 1 : KGROUP / CC;
+    static_assert(CIN % 16 == 0, "C_in must be a multiple of 16");
+    static_assert((CC >= KGROUP) ? (CC % KGROUP == 0) : (KGROUP % CC == 0), "k-group must tile a tap");
+};
+
+// Stage `rows` input rows starting at global row g0 into the LDS tile (zero outside [0, Lin)).
+template <typename OpT, int CIN>
+__device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b, int g0, int rows) {
+    using frag = typename Op<OpT>::frag;
+    constexpr int STRIDE = Tile<CIN>::STRIDE;
+    constexpr int C8 = CIN / 8;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < rows * C8; idx += 256) {
+        const int r = idx / C8;
+        const int c8 = idx - r * C8;
+        const int gr = g0 + r;
+        frag v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (OpT)0.f;
+        if (gr >= 0 && gr < a.Lin) {
+            if (a.in_mode == IN_OP_RAW) {
+                v = *(const frag*)((const OpT*)a.in + (size_t)b * a.in_bstride + (size_t)gr * CIN + c8 * 8);
+            } else if (a.in_mode == IN_F32_ACT) {
+                const float4* p = (const float4*)((const float*)a.in + (size_t)b * a.in_bstride + (size_t)gr * CIN + c8 * 8);
+                float4 lo = p[0], hi = p[1];
+                float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = f[e];
+                    if (a.div_in != 1.f) x = x / a.div_in;
+                    v[e] = (OpT)lrelu(x, a.slope_in);
+                }
+            } else {  // IN_F32_CF
+                const float* p = (const float*)a.in + (size_t)b * a.in_bstride + (size_t)(c8 * 8) * a.Lin + gr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (OpT)p[(size_t)e * a.Lin];
+            }
+        }
+        *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
+    }
+}
+
+// The K loop.  acc[mi][jt] += sum over (padded) taps and channel chunks.
+//   lds_lane : smem + (wave_t0 + (lane&31)) * STRIDE + (lane>>5)*16
+//   wlane    : packed weights of this wave's first co tile + lane*8
+template <typename OpT, int CIN, int MI, int NJ>
+__device__ __forceinline__ void conv_core(f32x16 (&acc)[MI][NJ], const char* lds_lane, const OpT* wlane,
+                                          long ct_stride, int ntaps_p, int roff, int dstep) {
+    using frag = typename Op<OpT>::frag;
+    using TL = Tile<CIN>;
+    constexpr int CC = TL::CC;
+    constexpr int STRIDE = TL::STRIDE;
+    const int NG = ntaps_p * CC / KGROUP;
+
+    frag A0[KGROUP][MI], A1[KGROUP][MI];
+    auto loadA = [&](frag(&A)[KGROUP][MI], int grp) {
+#pragma unroll
+        for (int g = 0; g < KGROUP; ++g)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                A[g][mi] = *(const frag*)(wlane + (size_t)mi * ct_stride + (size_t)(grp * KGROUP + g) * 512);
+    };
+    auto compute = [&](frag(&A)[KGROUP][MI], int grp) {
+        int tap0, cc0;
+        if constexpr (CC >= KGROUP) {
+            tap0 = (grp * KGROUP) / CC;
+            cc0 = (grp * KGROUP) % CC;
+        } else {
+            tap0 = grp * TL::TAPS_PER_GROUP;
+            cc0 = 0;
+        }
+#pragma unroll
+        for (int g = 0; g < KGROUP; ++g) {
+            int tap, cc;
+            if constexpr (CC >= KGROUP) {
+                tap = tap0;
+                cc = cc0 + g;
+            } else {
+                tap = tap0 + g / CC;
+                cc = g % CC;
+            }
+            const char* bp = lds_lane + (roff + tap * dstep) * STRIDE + cc * 32;
+            frag B[NJ];
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) B[jt] = *(const frag*)(bp + jt * 32 * STRIDE);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) acc[mi][jt] = Op<OpT>::mfma(A[g][mi], B[jt], acc[mi][jt]);
+        }
+    };
+
+    loadA(A0, 0);
+    for (int grp = 0; grp < NG; grp += 2) {
+        if (grp + 1 < NG) loadA(A1, grp + 1);
+        compute(A0, grp);
+        if (grp + 1 < NG) {
+            if (grp + 2 < NG) loadA(A0, grp + 2);
+            compute(A1, grp + 1);
+        }
+    }
+}
+
+// Generic single-conv kernel: stage tile -> conv_core -> epilogue.  Grid: x = time tile,
+// y = (co block) * nphase + phase, z = batch.  Block = 4 waves laid out WCO (co) x WT (time).
+template <typename OpT, int CIN, int MI, int NJ, int WCO>
+__global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
+    using TL = Tile<CIN>;
+    constexpr int WT = 4 / WCO;
+    constexpr int TT = WT * NJ * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int b = blockIdx.z;
+    const int ph = a.nphase > 1 ? (int)(blockIdx.y % a.nphase) : 0;
+    const int cob = a.nphase > 1 ? (int)(blockIdx.y / a.nphase) : (int)blockIdx.y;
+    const int q0 = blockIdx.x * TT;
+    const int in_off = a.nphase > 1 ? a.ph_in_off[ph] : a.in_off;
+    const OpT* wbase = (const OpT*)a.w + (a.nphase > 1 ? a.ph_w_off[ph] : 0);
+
+    stage_tile<OpT, CIN>(smem, a, b, q0 + in_off - a.roff, a.tile_rows);
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wco = wave % WCO;
+    const int wt = wave / WCO;
+    const int ct0 = (cob * WCO + wco) * MI;  // first 32-channel output tile of this wave
+    const int tw0 = wt * NJ * 32;            // first time row of this wave inside the block tile
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][jt][r] = 0.f;
+
+    const char* lds_lane = smem + (size_t)(tw0 + (lane & 31)) * TL::STRIDE + (lane >> 5) * 16;
+    const OpT* wlane = wbase + (size_t)ct0 * a.w_ct_stride + lane * 8;
+    conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.w_ct_stride, a.ntaps, a.roff, a.dstep);
+
+    // ---- epilogue -------------------------------------------------------------------------
+    const int out_add = a.nphase > 1 ? ph : a.out_add;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int q = q0 + tw0 + jt * 32 + (lane & 31);
+            if (q >= a.Lq) continue;
+            const size_t orow = (size_t)q * a.out_mul + out_add;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cobase + 8 * g;
+                if (co >= a.cout) continue;  // cout is a multiple of 4 whenever it is < the padded tile
+                f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
+                if (a.bias) {
+                    const f32x4 bv = *(const f32x4*)(a.bias + co);
+                    v += bv;
+                }
+                if (a.out_mode == OUT_ACT) {
+                    using o4 = __attribute__((ext_vector_type(4))) OpT;
+                    o4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (OpT)lrelu(v[e], a.slope_out);
+                    *(o4*)((OpT*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co) = o;
+                } else {
+                    if (a.cb) v += *(const f32x4*)(a.cb + (size_t)b * a.cout + co);
+                    if (a.res) v += *(const f32x4*)(a.res + (size_t)b * a.res_bstride + orow * a.out_C + co);
+                    f32x4* o = (f32x4*)((float*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co);
+                    if (a.accumulate) v += *o;
+                    *o = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace rvcmi

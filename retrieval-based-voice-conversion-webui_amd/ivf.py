@@ -1,0 +1,185 @@
+"""The faiss index object as the reference uses it, backed by the HIP IVF-Flat kernels.
+
+Mirrors exactly the surface the reference touches:
+
+    index = faiss.read_index(path)                 -> read_index(path)            pipeline.py:214
+    big_npy = index.reconstruct_n(0, index.ntotal) -> index.reconstruct_n(0, n)   pipeline.py:215
+    score, ix = index.search(npy, k=8)             -> index.search(npy, k=8)      pipeline.py:126
+    faiss.extract_index_ivf(index).nprobe = 1      -> index.nprobe = 1            web.py:551-552
+    faiss.write_index(index, path)                 -> write_index(index, path)    web.py:571
+
+plus the device-resident fast path ``search_blend`` that fuses pipeline.py:126-138 and removes the
+two D2H + two H2D hops around retrieval.  numpy in -> numpy out (drop-in); torch.cuda in -> torch.cuda out.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+
+class IVFFlatHIP:
+    def __init__(self, handle: C.c_void_p, device: torch.device, keepalive=None):
+        self._h = handle
+        self.device = device
+        self._keepalive = keepalive  # e.g. the torch tensor that owns a broadcast blob
+
+    # -- construction ----------------------------------------------------------------------------
+    @classmethod
+    def from_arrays(cls, centroids: np.ndarray, list_offsets: np.ndarray, ids: np.ndarray, vecs: np.ndarray,
+                    nprobe: int = 1, device="cuda:0") -> "IVFFlatHIP":
+        """What ``index.train(); index.add()`` leave behind (web.py:553-563): centroids [nlist,d],
+        list_offsets [nlist+1], and ids [n] / vecs [n,d] in list-major order."""
+        dev = _cuda(device)
+        cent = np.ascontiguousarray(centroids, dtype=np.float32)
+        off = np.ascontiguousarray(list_offsets, dtype=np.int64)
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        vecs = np.ascontiguousarray(vecs, dtype=np.float32)
+        nlist, d = cent.shape
+        n = ids.shape[0]
+        if off.shape != (nlist + 1,) or vecs.shape != (n, d):
+            raise ValueError("inconsistent IVF arrays")
+        h = C.c_void_p(None)
+        _lib.check(_lib.lib().rvcmi_ivf_create(d, n, nlist, int(nprobe), cent.ctypes.data_as(C.c_void_p),
+                                               off.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                                               vecs.ctypes.data_as(C.c_void_p), _idx(dev), C.byref(h)))
+        return cls(h, dev)
+
+    @classmethod
+    def from_blob(cls, blob: torch.Tensor) -> "IVFFlatHIP":
+        """Adopt a device blob (uint8 CUDA tensor), e.g. one received by an RCCL broadcast."""
+        if blob.dtype != torch.uint8 or blob.device.type != "cuda" or not blob.is_contiguous():
+            raise ValueError("blob must be a contiguous uint8 CUDA tensor")
+        h = C.c_void_p(None)
+        _lib.check(_lib.lib().rvcmi_ivf_create_from_blob(C.c_void_p(blob.data_ptr()), blob.numel(), _idx(blob.device), 0,
+                                                         C.byref(h)))
+        return cls(h, blob.device, keepalive=blob)
+
+    def blob(self) -> torch.Tensor:
+        """A uint8 CUDA tensor holding a COPY of the whole index (header+centroids+lists)."""
+        p, n = C.c_void_p(None), C.c_size_t(0)
+        _lib.check(_lib.lib().rvcmi_ivf_blob(self._h, C.byref(p), C.byref(n)))
+        out = torch.empty(n.value, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream().synchronize()
+            rc = _hip_memcpy_d2d(out.data_ptr(), p.value, n.value)
+        if rc:
+            raise _lib.RvcmiError("hipMemcpy failed (%d)" % rc)
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().rvcmi_ivf_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- faiss attribute surface -------------------------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        return int(_lib.lib().rvcmi_ivf_ntotal(self._h))
+
+    @property
+    def d(self) -> int:
+        return int(_lib.lib().rvcmi_ivf_d(self._h))
+
+    @property
+    def nlist(self) -> int:
+        return int(_lib.lib().rvcmi_ivf_nlist(self._h))
+
+    @property
+    def nprobe(self) -> int:
+        return int(_lib.lib().rvcmi_ivf_nprobe(self._h))
+
+    @nprobe.setter
+    def nprobe(self, v: int) -> None:
+        _lib.check(_lib.lib().rvcmi_ivf_set_nprobe(self._h, int(v)))
+
+    def reserve(self, max_nq: int) -> "IVFFlatHIP":
+        _lib.check(_lib.lib().rvcmi_ivf_reserve(self._h, int(max_nq)))
+        return self
+
+    def reconstruct_n(self, i0: int = 0, n: int = None) -> np.ndarray:
+        n = self.ntotal - i0 if n is None else int(n)
+        out = np.empty((n, self.d), dtype=np.float32)
+        _lib.check(_lib.lib().rvcmi_ivf_reconstruct_n(self._h, int(i0), n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def search(self, x: ArrayLike, k: int = 8) -> Tuple[ArrayLike, ArrayLike]:
+        """``index.search(x, k)`` -> (D squared-L2 ascending, I int64, -1/FLT_MAX padded)."""
+        is_np = isinstance(x, np.ndarray)
+        if is_np:
+            if x.dtype != np.float32:
+                raise TypeError("queries must be float32 (faiss raises on anything else)")
+            xt = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        else:
+            xt = x.to(self.device, torch.float32).contiguous()
+        if xt.dim() != 2 or xt.shape[1] != self.d:
+            raise ValueError("queries must be [nq, %d], got %s" % (self.d, tuple(xt.shape)))  # faiss: assert d == self.d
+        nq = xt.shape[0]
+        D = torch.empty(nq, k, dtype=torch.float32, device=self.device)
+        I = torch.empty(nq, k, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().rvcmi_ivf_search(self._h, nq, C.c_void_p(xt.data_ptr()), int(k), C.c_void_p(D.data_ptr()),
+                                                   C.c_void_p(I.data_ptr()), C.c_void_p(st)))
+        if is_np:
+            return D.cpu().numpy(), I.cpu().numpy()
+        return D, I
+
+    def search_blend(self, feats: torch.Tensor, index_rate: float, k: int = 8, skip_if_short: bool = False) -> torch.Tensor:
+        """pipeline.py:126-138 fused on the device; ``feats`` [nq,d] fp32 CUDA is updated IN PLACE and returned.
+        ``skip_if_short`` reproduces the realtime guard ``if (ix >= 0).all()`` of rtrvc.py:173."""
+        if feats.device.type != "cuda" or feats.dtype != torch.float32 or not feats.is_contiguous():
+            raise ValueError("feats must be a contiguous float32 CUDA tensor")
+        if feats.dim() != 2 or feats.shape[1] != self.d:
+            raise ValueError("feats must be [nq, %d]" % self.d)
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().rvcmi_ivf_search_blend(self._h, feats.shape[0], C.c_void_p(feats.data_ptr()),
+                                                         float(index_rate), int(k), 1 if skip_if_short else 0, C.c_void_p(st)))
+        return feats
+
+    def profile(self, enable: bool) -> None:
+        _lib.check(_lib.lib().rvcmi_ivf_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self, reset: bool = True) -> List[dict]:
+        return _lib.read_stats(_lib.lib().rvcmi_ivf_profile_read, self._h, reset)
+
+
+def read_index(path: str, device="cuda:0") -> IVFFlatHIP:
+    """``faiss.read_index(path)`` for IVF-Flat/L2 files (IwFl)."""
+    dev = _cuda(device)
+    h = C.c_void_p(None)
+    _lib.check(_lib.lib().rvcmi_ivf_create_from_file(str(path).encode(), _idx(dev), C.byref(h)))
+    return IVFFlatHIP(h, dev)
+
+
+def write_index(index: IVFFlatHIP, path: str) -> None:
+    """``faiss.write_index(index, path)``."""
+    _lib.check(_lib.lib().rvcmi_ivf_write_file(index._h, str(path).encode()))
+
+
+def _cuda(device) -> torch.device:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.RvcmiError("the HIP IVF index needs a GPU device (got %s); there is no CPU fallback" % device)
+    return dev
+
+
+def _idx(dev: torch.device) -> int:
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+def _hip_memcpy_d2d(dst: int, src: int, n: int) -> int:
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    return hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), n, 3)  # hipMemcpyDeviceToDevice

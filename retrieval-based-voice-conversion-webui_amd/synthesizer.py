@@ -1,0 +1,59 @@
+"""``rvc.synthesizer`` surface (rvc/synthesizer.py:10-35) with the generator swapped for the HIP one.
+
+    get_synthesizer(cpt, device)      -> (net_g, cpt)     rvc/synthesizer.py:10
+    load_synthesizer(pth_path, device) -> (net_g, cpt)    rvc/synthesizer.py:31
+
+Everything except ``net_g.dec`` (TextEncoder, flow, emb_g -- SURVEY.md 8f "next" rows) stays the
+reference's own PyTorch-ROCm modules: this module calls the reference loader, which must therefore be
+importable (it is when this package is dropped into an RVC checkout), then replaces ``net_g.dec``.
+"""
+from __future__ import annotations
+
+import torch
+
+from .nsf import GeneratorHIP, NSFGeneratorHIP
+
+
+def accelerate_synthesizer(net_g: torch.nn.Module, device=None, operand: str = "bf16", max_B: int = 1, max_T: int = 256):
+    """Swap ``net_g.dec`` (already weight-norm-folded, rvc/synthesizer.py:27) for the HIP generator.
+    ``net_g.infer`` (rvc/layers/synthesizers.py:160-203) keeps working unchanged: it type-switches on
+    ``isinstance(self.dec, NSFGenerator)`` / ``Generator`` so the replacement classes are registered as
+    virtual subclasses of those when they are importable."""
+    dec = net_g.dec
+    if device is None:
+        device = next(net_g.parameters()).device
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("accelerate_synthesizer needs the synthesizer on a GPU (got %s)" % device)
+    use_f0 = hasattr(dec, "m_source")
+    cls = NSFGeneratorHIP if use_f0 else GeneratorHIP
+    new = cls.from_reference(dec, device=device, operand=operand, max_B=max_B, max_T=max_T)
+    net_g.dec = _as_reference_subclass(new, dec)
+    return net_g
+
+
+def _as_reference_subclass(new, old):
+    """``SynthesizerTrnMsNSFsid.infer`` dispatches with isinstance(self.dec, NSFGenerator) (synthesizers.py:190-199).
+    Give the replacement a dynamic subclass that also inherits the reference class so that dispatch still
+    routes to it; no reference code is copied, only its type identity is reused."""
+    ref_cls = type(old)
+    name = type(new).__name__
+    try:
+        dyn = type(name, (type(new), ref_cls), {"__init__": lambda self, *a, **k: None})
+        new.__class__ = dyn
+    except TypeError:
+        pass
+    return new
+
+
+def get_synthesizer(cpt, device=torch.device("cpu"), operand: str = "bf16"):
+    from rvc.synthesizer import get_synthesizer as _ref_get  # the reference's own loader
+
+    net_g, cpt = _ref_get(cpt, device)
+    if torch.device(device).type == "cuda":
+        accelerate_synthesizer(net_g, device, operand)
+    return net_g, cpt
+
+
+def load_synthesizer(pth_path, device=torch.device("cpu"), operand: str = "bf16"):
+    return get_synthesizer(torch.load(pth_path, map_location=torch.device("cpu"), weights_only=True), device, operand)
