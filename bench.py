@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Headline benchmark: real-time factor of the RVC hot path (IVF retrieval + NSF-HiFi-GAN decode)
+on 10 s clips, v2 / 48 kHz, synthetic data, one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of B clips per rank: 599 HuBERT-shaped queries per
+clip through search(k=8)+blend against the index, then the generator on T=1198 frames (what a 10 s
+clip costs inside the pipeline with x_pad=1).  Inputs are resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLIP_SECONDS = 10.0
+T_CLIP = 1198        # vocoder frames per 10 s clip inside the pipeline (pipeline.py:146-148, x_pad=1)
+NQ_CLIP = 599        # HuBERT frames = retrieval queries per clip
+GEN_FLOP_PER_CLIP = 1319.6e9  # SURVEY.md 8d, T=1198
+PEAK = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 1.573e14}  # MI355X dense MFMA / fp32 peaks (MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=1, help="clips per rank per step (BASELINE config 2 = 1, config 3 = 64)")
+    p.add_argument("--operand", default="fp16", choices=["fp16", "bf16", "fp32"])
+    p.add_argument("--frames", type=int, default=T_CLIP)
+    p.add_argument("--index-n", type=int, default=10000)
+    p.add_argument("--index-d", type=int, default=768)
+    p.add_argument("--index-rate", type=float, default=0.75)
+    p.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, index_rate):
+    """The CPU side timed next to the GPU: the oracle (kind 'port') on this host's cores.
+    Generator = torch-CPU fp32 restatement (same ATen/oneDNN conv kernels the reference calls);
+    retrieval = the C restatement in fp32 arithmetic with OpenMP (faiss itself is not installable).
+    Sample: ONE 10 s clip (T frames + 599 queries), 1 warm-up + best of 2."""
+    import ctypes as C
+
+    from oracle import nsf_oracle
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "libivf_oracle.so"))
+    q = np.ascontiguousarray(phone[0].numpy())
+    nq, d = q.shape
+    D = np.empty((nq, 8), np.float32)
+    I = np.empty((nq, 8), np.int64)
+    P = np.empty((nq, 8), np.int64)
+    pos_last = int(np.nonzero(idx["ids"] == idx["ntotal"] - 1)[0][0])
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def once():
+        t0 = time.perf_counter()
+        feats = q.copy()
+        lib.ivf_search(vp(feats), C.c_int64(nq), C.c_int(d), vp(idx["centroids"]), C.c_int64(idx["nlist"]), C.c_int(1),
+                       vp(idx["list_offsets"]), vp(idx["ids"]), vp(idx["vecs"]), C.c_int(8), vp(D), vp(I), vp(P), C.c_int(1))
+        lib.ivf_blend(vp(feats), C.c_int64(nq), C.c_int(d), vp(D), vp(P), C.c_int(8), vp(idx["vecs"]), C.c_int64(pos_last),
+                      C.c_float(index_rate), C.c_float(1.0 - index_rate))
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            nsf_oracle.generator_forward(cfg, w, z[:1], f0[:1], g[:1], noise[:1])
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1
+
+    once()
+    runs = [once(), once()]
+    t_ivf = min(r[0] for r in runs)
+    t_gen = min(r[1] for r in runs)
+    return {"value": CLIP_SECONDS / (t_ivf + t_gen), "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": "port",
+            "sample": "1 clip: 599 queries vs %dx%d IVF (C restatement, fp32, OpenMP) %.3fs + generator T=%d (torch-CPU fp32 oracle) %.3fs; best of 2"
+                      % (idx["ntotal"], idx["d"], t_ivf, z.shape[-1], t_gen)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import rvc_amd
+    from oracle import nsf_oracle, synth
+
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    B, T = a.batch, a.frames
+    w = synth.make_dec_weights(cfg, 1234)
+    z, f0, g = synth.make_dec_inputs(cfg, B, T, seed=1234 + rank)
+    noise = nsf_oracle.reference_noise(B, T, cfg.upp, 114514 + rank)
+    phone = synth.make_phone(B, NQ_CLIP, a.index_d, seed=1234 + 100 * rank)
+
+    # ---- index: built on rank 0, ONE RCCL broadcast of the packed blob ----------
+    idx = None
+    t_bcast = 0.0
+    if rank == 0:
+        idx = synth.make_ivf(a.index_n, a.index_d, seed=4321, kmeans_iters=1)
+        index = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=dev)
+    else:
+        index = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        index = rvc_amd.dist.broadcast_index(index, src=0, device=dev)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+    index.reserve(B * NQ_CLIP)
+
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=dev, operand=a.operand, max_B=B, max_T=T)
+    zd, f0d, gd, nd = z.to(dev), f0.to(dev), g.to(dev), noise.to(dev)
+    phone_d = phone.to(dev).reshape(B * NQ_CLIP, a.index_d).contiguous()
+    feats = torch.empty_like(phone_d)
+    out_holder = {}
+
+    def step():
+        feats.copy_(phone_d)
+        index.search_blend(feats, a.index_rate, 8)
+        out_holder["o"] = gen(zd, f0d, gd, noise=nd)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    graph = None
+    if a.graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa
+            print("[bench] graph capture failed (%s); timing eager launches" % e, file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+
+    for _ in range(a.warmup):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out_holder["o"]).all(), "non-finite generator output"
+
+    # ---- roofline leg: the same step, eager, every kernel bracketed by HIP events --------------
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        gen.profile(True)
+        index.profile(True)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        gs, ivs = gen.profile_read(), index.profile_read()
+        gen.profile(False)
+        index.profile(False)
+        dom = max(gs, key=lambda s: s["ms"])
+        peak = PEAK[a.operand]
+        ach = dom["flops"] / (dom["ms"] * 1e-3)
+        tot_ms = sum(s["ms"] for s in gs) / 3.0
+        gen_ach = GEN_FLOP_PER_CLIP * B * (T / T_CLIP) / (tot_ms * 1e-3)
+        roof = {"bound": "mfma", "kernel": dom["name"], "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None,
+                "avg_launch_us": 1e3 * dom["ms"] / dom["launches"], "launches_per_step": dom["launches"] // 3,
+                "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
+                "generator_all_kernels": {"ms_per_step": tot_ms, "achieved": gen_ach / 1e12, "frac": gen_ach / peak},
+                "kernels_ms_per_step": {s["name"]: round(s["ms"] / 3.0, 4) for s in gs + ivs}}
+        scan = [s for s in ivs if s["name"] == "ivf_scan"]
+        if scan and scan[0]["ms"] > 0:
+            roof["ivf_scan_hbm"] = {"achieved": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                    "frac": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 8e12}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, a.index_rate)
+
+    if rank == 0:
+        clips = B * world * a.steps
+        value = clips * CLIP_SECONDS * (T / T_CLIP) / dt
+        line = {
+            "metric": "real-time factor (audio-sec/wall-sec), 48 kHz v2, 10 s clips, retrieval + NSF-HiFi-GAN decode",
+            "value": value, "unit": "x real-time (audio-sec/wall-sec), whole job",
+            "per_gpu": value / world,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.operand + " MFMA operands, fp32 accumulate/residual; fp64 IVF distances" if a.operand != "fp32" else "fp32",
+            "data": "synthetic (seeded weights, features, f0, noise, index; no checkpoints offline)",
+            "config": {"workload": "BASELINE configs[%d]: v2/48k, %d x 10 s clip(s) per GPU, T=%d frames, 599 queries/clip, "
+                                   "IVF %dx%d nlist=%d nprobe=1 k=8 index_rate=%.2f" % (
+                                       1 if B == 1 else 2, B, T, a.index_n, a.index_d, index.nlist, a.index_rate),
+                       "clips_per_gpu_per_step": B, "hipgraph": graph is not None,
+                       "index_broadcast_s": t_bcast if world > 1 else None},
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
