@@ -41,7 +41,7 @@ __host__ __device__ static inline uint64_t align_up(uint64_t v, uint64_t a) { re
 // kernels
 // ---------------------------------------------------------------------------------------------
 
-constexpr int QT = 8;  // queries per coarse block
+constexpr int QT = 4;  // queries per coarse block
 
 // Coarse quantiser, nprobe == 1: for QT queries (LDS, broadcast reads) every lane owns one centroid
 // at a time and accumulates QT fp64 distances for it -- no cross-lane reduction in the hot loop.
@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(256) k_coarse1(const float* __restrict__ q, co
         double acc[QT];
 #pragma unroll
         for (int k = 0; k < QT; ++k) acc[k] = 0.0;
+#pragma unroll 4
         for (int e = 0; e < d4; ++e) {
             const float4 v = row[e];
 #pragma unroll
@@ -177,60 +178,70 @@ __device__ __forceinline__ void topk_insert(TopK& t, double dv, int64_t idv, int
     }
 }
 
-// List scan: one wave per query.  The wave is split into 4 groups of 16 lanes; group g takes rows
-// g, g+4, ... of the probed list(s); inside a group lane s reads float4 chunks s, s+16, ... of the row
-// (16 lanes x 16 B = 256 contiguous bytes per load) and the 16 partial fp64 sums are combined with four
-// xor-shuffles.  Every lane of a group carries the group's sorted top-k; lane 0 merges the 4 groups.
+// List scan: one 256-thread block per query = 16 groups of 16 lanes.  Group g takes rows g, g+16, ... of the
+// probed list(s); inside a group lane s reads float4 chunks s, s+16, ... of the row (16 lanes x 16 B = 256
+// contiguous bytes per load, 4 loads in flight per lane) and the 16 partial fp64 sums are combined with four
+// xor-shuffles (wavefront-level reduction).  Every lane of a group carries the group's sorted top-8 in
+// registers; thread 0 merges the 16 group lists.  ~40 rows per list (web.py:544) => 2-3 rows per group, so the
+// whole list is in flight at once instead of being walked serially.
+constexpr int SCAN_GROUPS = 16;
 __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const int64_t* __restrict__ assign, int nprobe,
                                               const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
                                               const float* __restrict__ vecs, int64_t nq, int d, int k,
                                               float* __restrict__ D, int64_t* __restrict__ I, int64_t* __restrict__ P,
                                               int* __restrict__ any_short) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
-    float* qs = (float*)smem_raw + (size_t)wave * d;
-    TopK* merge = (TopK*)(smem_raw + align_up((size_t)4 * d * 4, 16)) + wave * 4;
-    const bool active = qi < nq;
-    if (active)
-        for (int e = lane; e < d; e += 64) qs[e] = q[qi * d + e];
+    const int64_t qi = blockIdx.x;
+    float* qs = (float*)smem_raw;
+    TopK* merge = (TopK*)(smem_raw + align_up((size_t)d * 4, 16));
+    for (int e = threadIdx.x; e < d; e += 256) qs[e] = q[qi * d + e];
     __syncthreads();
     TopK t;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) { t.d[s] = INFINITY; t.id[s] = INT64_MAX; t.pos[s] = -1; }
-    const int grp = lane >> 4, sub = lane & 15;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
     const int d4 = d >> 2;
-    if (active) {
-        for (int p = 0; p < nprobe; ++p) {
-            const int64_t l = assign[qi * nprobe + p];
-            if (l < 0) continue;
-            const int64_t beg = list_off[l], end = list_off[l + 1];
-            for (int64_t r = beg + grp; r < end; r += 4) {
-                const float4* row = (const float4*)(vecs + r * d);
-                double acc = 0.0;
-                for (int c = sub; c < d4; c += 16) {
-                    const float4 v = row[c];
-                    const float4 qq = *(const float4*)(qs + c * 4);
-                    double t0 = (double)qq.x - (double)v.x, t1 = (double)qq.y - (double)v.y;
-                    double t2 = (double)qq.z - (double)v.z, t3 = (double)qq.w - (double)v.w;
-                    acc = fma(t0, t0, acc);
-                    acc = fma(t1, t1, acc);
-                    acc = fma(t2, t2, acc);
-                    acc = fma(t3, t3, acc);
+    for (int p = 0; p < nprobe; ++p) {
+        const int64_t l = assign[qi * nprobe + p];
+        if (l < 0) continue;
+        const int64_t beg = list_off[l], end = list_off[l + 1];
+        for (int64_t r = beg + grp; r < end; r += SCAN_GROUPS) {
+            const float4* row = (const float4*)(vecs + r * d);
+            double acc = 0.0;
+            for (int c0 = sub; c0 < d4; c0 += 64) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 16 * u;
+                    v[u] = c < d4 ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-                topk_insert(t, acc, ids[r], r);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 16 * u;
+                    if (c < d4) {
+                        const float4 qq = *(const float4*)(qs + c * 4);
+                        double t0 = (double)qq.x - (double)v[u].x, t1 = (double)qq.y - (double)v[u].y;
+                        double t2 = (double)qq.z - (double)v[u].z, t3 = (double)qq.w - (double)v[u].w;
+                        acc = fma(t0, t0, acc);
+                        acc = fma(t1, t1, acc);
+                        acc = fma(t2, t2, acc);
+                        acc = fma(t3, t3, acc);
+                    }
+                }
             }
+            for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            topk_insert(t, acc, ids[r], r);
         }
-        if (sub == 0) merge[grp] = t;
     }
+    if (sub == 0) merge[grp] = t;
     __syncthreads();
-    if (active && lane == 0) {
-        int idx[4] = {0, 0, 0, 0};
+    if (threadIdx.x == 0) {
+        int idx[SCAN_GROUPS];
+        for (int g = 0; g < SCAN_GROUPS; ++g) idx[g] = 0;
         bool short_list = false;
         for (int s = 0; s < k; ++s) {
             int bg = -1;
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < SCAN_GROUPS; ++g) {
                 if (idx[g] >= KMAX) continue;
                 const double dv = merge[g].d[idx[g]];
                 const int64_t iv = merge[g].id[idx[g]];
@@ -564,9 +575,9 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
         });
     }
     const double rows = b.nlist ? (double)b.ntotal / (double)b.nlist * np : 0;
-    const size_t smem = align_up((size_t)4 * d * 4, 16) + 16 * sizeof(TopK);
+    const size_t smem = align_up((size_t)d * 4, 16) + SCAN_GROUPS * sizeof(TopK);
     h->prof.launch("ivf_scan", 3.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
-        hipLaunchKernelGGL(k_scan, dim3((unsigned)((nq + 3) / 4)), dim3(256), smem, st, q, h->assign.as<int64_t>(), np,
+        hipLaunchKernelGGL(k_scan, dim3((unsigned)nq), dim3(256), smem, st, q, h->assign.as<int64_t>(), np,
                            h->list_off(), h->ids(), h->vecs(), nq, d, k, D, I, h->P.as<int64_t>(), h->flag.as<int>());
     });
     HIP_CHECK(hipGetLastError());

@@ -162,7 +162,9 @@ struct rvcmi_nsf {
     int c_last = 0;
     // workspace
     size_t S = 0;  // elements per activation buffer
-    DevBuf XS[2], X0, Xa, Xb, H, har, har2, x2, phase, condv, dbg;
+    // P: conv_pre output.  X0: ups(+noise) output = input of the stage's resblocks.  Ya[j]/Yb[j]: ping-pong
+    // fp32 streams of resblock j (its final output is one of them; the consumer sums the nk of them).
+    DevBuf P, X0, Ya[RVCMI_MAX_RB], Yb[RVCMI_MAX_RB], H, har, har2, x2, phase, condv, dbg;
     size_t ws_bytes = 0;
     Profiler prof;
 };
@@ -193,6 +195,7 @@ static void upload(DevBuf& d, const std::vector<float>& v) {
 }
 
 static void set_lds_limits();
+constexpr int RB_KG = 4;  // k-steps per weight-prefetch group inside the fused resblock kernel
 
 static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights, int n_weights, int device, int max_B,
                        int max_T, rvcmi_nsf** out) {
@@ -323,14 +326,16 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     if (h->c_last & 3) RVCMI_FAIL(RVCMI_ERR_INVALID, "last stage channel count %d", h->c_last);
 
     // workspace
+    if (cfg->n_resblock_kernels > 3) RVCMI_FAIL(RVCMI_ERR_INVALID, "more than 3 resblock kernels per stage is unsupported");
     h->S = S * (size_t)max_B;
     const size_t fb = h->S * sizeof(float);
-    h->XS[0].alloc(fb);
-    h->XS[1].alloc(fb);
+    h->P.alloc((size_t)max_B * max_T * C0 * sizeof(float));
     h->X0.alloc(fb);
-    h->Xa.alloc(fb);
-    h->Xb.alloc(fb);
-    h->H.alloc(fb);
+    for (int j = 0; j < cfg->n_resblock_kernels; ++j) {
+        h->Ya[j].alloc(fb);
+        h->Yb[j].alloc(fb);
+    }
+    if (op == RVCMI_OPERAND_F32) h->H.alloc(fb);
     const size_t hb = (size_t)max_B * max_T * upp * sizeof(float);
     h->har.alloc(hb);
     h->har2.alloc(hb);
@@ -338,7 +343,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     h->phase.alloc((size_t)max_B * max_T * sizeof(float));
     h->condv.alloc((size_t)max_B * C0 * sizeof(float));
     HIP_CHECK(hipMemset(h->condv.p, 0, h->condv.bytes));
-    h->ws_bytes = 6 * fb + 2 * hb + h->x2.bytes + h->phase.bytes + h->condv.bytes;
+    h->ws_bytes = (size_t)(1 + 2 * cfg->n_resblock_kernels + (op == RVCMI_OPERAND_F32 ? 1 : 0)) * fb + h->P.bytes + 2 * hb + h->x2.bytes + h->phase.bytes + h->condv.bytes;
     *out = h.release();
 }
 
@@ -401,9 +406,44 @@ static void set_lds_all() {
     RVCMI_FOR_EACH_CIN(X, OpT, 1, 4, 1)
 #undef X
 }
+template <typename OpT>
+static void set_lds_rb();
 static void set_lds_limits() {
     set_lds_all<__bf16>();
     set_lds_all<_Float16>();
+    set_lds_rb<__bf16>();
+    set_lds_rb<_Float16>();
+}
+
+
+template <typename OpT, int C, int MI, int NW, int KG>
+static void launch_rb_inst(const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
+    const size_t smem = (size_t)rows * Tile<C>::STRIDE;
+    if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "resblock LDS tile too large (%zu B)", smem);
+    hipLaunchKernelGGL((k_rb_pair<OpT, C, MI, NW, KG>), dim3(tiles, nj, B), dim3(64 * NW), smem, st, ra);
+}
+template <typename OpT>
+static void launch_rb_pair_t(int C, const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
+    switch (C) {
+        case 256: return launch_rb_inst<OpT, 256, 2, 4, RB_KG>(ra, tiles, nj, B, rows, st);
+        case 128: return launch_rb_inst<OpT, 128, 2, 2, RB_KG>(ra, tiles, nj, B, rows, st);
+        case 64: return launch_rb_inst<OpT, 64, 2, 1, RB_KG>(ra, tiles, nj, B, rows, st);
+        case 32: return launch_rb_inst<OpT, 32, 1, 1, RB_KG>(ra, tiles, nj, B, rows, st);
+        case 16: return launch_rb_inst<OpT, 16, 1, 1, RB_KG>(ra, tiles, nj, B, rows, st);
+        default: RVCMI_FAIL(RVCMI_ERR_INVALID, "unsupported resblock channel count %d", C);
+    }
+}
+static void launch_rb_pair(int op, int C, const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
+    if (op == RVCMI_OPERAND_BF16) launch_rb_pair_t<__bf16>(C, ra, tiles, nj, B, rows, st);
+    else launch_rb_pair_t<_Float16>(C, ra, tiles, nj, B, rows, st);
+}
+template <typename OpT>
+static void set_lds_rb() {
+#define RB_ATTR(C_, MI_, NW_)                                                                                   \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_pair<OpT, C_, MI_, NW_, RB_KG>),           \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RB_ATTR(256, 2, 4) RB_ATTR(128, 2, 2) RB_ATTR(64, 2, 1) RB_ATTR(32, 1, 1) RB_ATTR(16, 1, 1)
+#undef RB_ATTR
 }
 
 // Fill the common part of ConvArgs for `L` and launch it in the handle's operand mode.
@@ -539,8 +579,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
         hipLaunchKernelGGL(k_cond, dim3((C0 + 255) / 256, B), dim3(256), 0, st, g, h->cond_w.as<float>(),
                            h->cond_b.as<float>(), h->condv.as<float>(), c.gin_channels, C0);
     }
-    float* cur = h->XS[0].as<float>();
-    int cur_idx = 0;
+    float* P = h->P.as<float>();
     {
         ConvArgs a = base_args();
         a.in = x;
@@ -549,28 +588,31 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
         a.in_mode = IN_F32_CF;
         a.Lq = Te;
         a.out_mode = OUT_F32;
-        a.out = cur;
+        a.out = P;
         a.out_bstride = (long)Te * C0;
         a.out_C = C0;
         a.cb = (g && c.gin_channels) ? h->condv.as<float>() : nullptr;
         run_conv(h, h->pre, a, B, "conv_pre", st);
     }
-    if (want("pre")) return copy_tap_cl(h, cur, B, Te, C0, tr, st);
+    if (want("pre")) return copy_tap_cl(h, P, B, Te, C0, tr, st);
 
+    // The running activation is ((y[0] + y[1]) + y[2]) / div  (nsf.py:177-186); stage 0 reads P alone.
+    const float* y[3] = {P, nullptr, nullptr};
+    float div = 1.f;
     long L = Te;
     int Cprev = C0;
-    float div = 1.f;
-    const size_t esz = op == RVCMI_OPERAND_F32 ? 4 : 2;
-    (void)esz;
     for (int i = 0; i < c.n_ups; ++i) {
         Stage& s = h->stages[i];
         const long Lin = L;
         L = Lin * s.u;
         const int C = s.cout;
+        const int nk = (int)s.rb.size();
         char nm[48];
         {  // x = ups[i](leaky_relu(x, 0.1))                                    nsf.py:171-172
             ConvArgs a = base_args();
-            a.in = cur;
+            a.in = y[0];
+            a.in_b = y[1];
+            a.in_c = y[2];
             a.in_bstride = Lin * Cprev;
             a.Lin = (int)Lin;
             a.in_mode = IN_F32_ACT;
@@ -594,17 +636,19 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
         }
         snprintf(nm, sizeof(nm), "up%d", i);
         if (want(nm)) return copy_tap_cl(h, h->X0.as<float>(), B, (int)L, C, tr, st);
-        // xs = sum_j resblocks[i*nk+j](x)                                        nsf.py:175-185
-        float* xs = h->XS[cur_idx ^ 1].as<float>();
-        for (size_t j = 0; j < s.rb.size(); ++j) {
-            const float* src = h->X0.as<float>();
-            const size_t nd = s.rb[j].size();
-            for (size_t m = 0; m < nd; ++m) {  // residuals.py:73-82
-                const bool last = m + 1 == nd;
-                snprintf(nm, sizeof(nm), "rb_c%d", C);
-                {
+
+        // resblocks[i*nk + j](x), j < nk                                         nsf.py:175-185
+        size_t maxnd = 0;
+        for (int j = 0; j < nk; ++j) maxnd = std::max(maxnd, s.rb[j].size());
+        const float* src[RVCMI_MAX_RB];
+        for (int j = 0; j < nk; ++j) src[j] = h->X0.as<float>();
+        if (op == RVCMI_OPERAND_F32) {
+            snprintf(nm, sizeof(nm), "rb_c%d", C);
+            for (int j = 0; j < nk; ++j)
+                for (size_t m = 0; m < s.rb[j].size(); ++m) {  // residuals.py:73-82
+                    float* dst = (m & 1) ? h->Yb[j].as<float>() : h->Ya[j].as<float>();
                     ConvArgs a = base_args();
-                    a.in = src;
+                    a.in = src[j];
                     a.in_bstride = L * C;
                     a.Lin = (int)L;
                     a.in_mode = IN_F32_ACT;
@@ -614,10 +658,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     a.out_bstride = L * C;
                     a.out_C = C;
                     run_conv(h, s.rb[j][m].first, a, B, nm, st);
-                }
-                float* dst = last ? xs : (src == h->Xa.as<float>() ? h->Xb.as<float>() : h->Xa.as<float>());
-                {
-                    ConvArgs a = base_args();
+                    a = base_args();
                     a.in = h->H.p;
                     a.in_bstride = L * C;
                     a.Lin = (int)L;
@@ -627,25 +668,75 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     a.out = dst;
                     a.out_bstride = L * C;
                     a.out_C = C;
-                    a.res = src;
+                    a.res = src[j];
                     a.res_bstride = L * C;
-                    a.accumulate = last && j > 0;
                     run_conv(h, s.rb[j][m].second, a, B, nm, st);
+                    src[j] = dst;
                 }
-                src = dst;
+        } else {
+            snprintf(nm, sizeof(nm), "rb_pair_c%d", C);
+            for (size_t m = 0; m < maxnd; ++m) {
+                RbPairArgs ra;
+                memset(&ra, 0, sizeof(ra));
+                ra.L = (int)L;
+                ra.bstride = L * C;
+                int nj = 0, max_tiles = 0, max_rows = 0;
+                double flops = 0, bytes = 0;
+                // heaviest kernel size first so that the long blocks are dispatched first
+                int order[RVCMI_MAX_RB];
+                for (int j = 0; j < nk; ++j) order[j] = j;
+                std::sort(order, order + nk, [&](int a1, int b1) {
+                    return s.rb[a1][0].first.ntaps[0] > s.rb[b1][0].first.ntaps[0];
+                });
+                float* dsts[RVCMI_MAX_RB] = {nullptr};
+                for (int oj = 0; oj < nk; ++oj) {
+                    const int j = order[oj];
+                    if (m >= s.rb[j].size()) continue;
+                    const ConvLayer& c1 = s.rb[j][m].first;
+                    const ConvLayer& c2 = s.rb[j][m].second;
+                    RbJob& J = ra.job[nj++];
+                    float* dst = (m & 1) ? h->Yb[j].as<float>() : h->Ya[j].as<float>();
+                    dsts[j] = dst;
+                    J.src = src[j];
+                    J.dst = dst;
+                    J.w1 = c1.w_pack.p;
+                    J.w2 = c2.w_pack.p;
+                    J.b1 = c1.bias.as<float>();
+                    J.b2 = c2.bias.as<float>();
+                    J.ct1 = c1.ct_stride;
+                    J.ct2 = c2.ct_stride;
+                    J.k = c1.ntaps[0];
+                    J.k_p = c1.ntaps_p;
+                    J.dil = c1.dstep;
+                    J.tt2 = RB_ROWS - (J.k - 1);
+                    J.ntiles = (int)((L + J.tt2 - 1) / J.tt2);
+                    max_tiles = std::max(max_tiles, J.ntiles);
+                    max_rows = std::max(max_rows, RB_ROWS + (J.k_p - 1) * J.dil);
+                    flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
+                    bytes += (double)B * L * C * 8 + 2.0 * J.k * C * C * 2;
+                }
+                h->prof.launch(nm, flops, bytes, st, [&] { launch_rb_pair(op, C, ra, max_tiles, nj, B, max_rows, st); });
+                for (int j = 0; j < nk; ++j)
+                    if (dsts[j]) src[j] = dsts[j];
             }
+            HIP_CHECK(hipGetLastError());
         }
-        cur_idx ^= 1;
-        cur = xs;
-        div = (float)s.rb.size();  // x = xs / num_kernels (nsf.py:186) is applied by the consumer
+        for (int j = 0; j < 3; ++j) y[j] = j < nk ? src[j] : nullptr;
+        div = (float)nk;  // x = xs / num_kernels (nsf.py:186) is applied by the consumer
         Cprev = C;
         snprintf(nm, sizeof(nm), "stage%d", i);
-        if (want(nm)) return copy_tap_cl(h, cur, B, (int)L, C, tr, st);  // NOTE: the un-divided sum
+        if (want(nm)) {  // the un-divided sum
+            const size_t n = (size_t)B * L * C;
+            hipLaunchKernelGGL(k_sum3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y[0], y[1], y[2], h->X0.as<float>(), n);
+            return copy_tap_cl(h, h->X0.as<float>(), B, (int)L, C, tr, st);
+        }
     }
     if (tr) RVCMI_FAIL(RVCMI_ERR_INVALID, "unknown tap '%s'", tr->what);
     // ---- x = tanh(conv_post(leaky_relu(x)))                                    nsf.py:187-189
-    h->prof.launch("conv_post", 2.0 * 7 * Cprev * (double)L * B, (double)B * L * (Cprev + 1) * 4, st, [&] {
-        hipLaunchKernelGGL(k_post, dim3((unsigned)((L + 255) / 256), B), dim3(256), (size_t)7 * Cprev * 4, st, cur,
+    const int nkk = c.n_resblock_kernels;
+    h->prof.launch("conv_post", 2.0 * 7 * Cprev * (double)L * B, (double)B * L * (Cprev * nkk + 1) * 4, st, [&] {
+        const size_t smem = (size_t)(7 * Cprev + (POST_TT + 6) * (Cprev + 1)) * 4;
+        hipLaunchKernelGGL(k_post, dim3((unsigned)((L + POST_TT - 1) / POST_TT), B), dim3(256), smem, st, y[0], y[1], y[2],
                            h->post_w.as<float>(), out, (int)L, Cprev, div);
     });
     HIP_CHECK(hipGetLastError());

@@ -133,6 +133,8 @@ enum OutMode : int {
 struct ConvArgs {
     // input
     const void* in;
+    const float* in_b;  // optional 2nd / 3rd fp32 addends: v = ((in + in_b) + in_c) / div_in   (nsf.py:177-186)
+    const float* in_c;
     long in_bstride;   // elements per batch item
     int Lin;           // valid input rows
     int cin;
@@ -188,8 +190,12 @@ __global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
             for (int ci = 0; ci < a.cin; ++ci) acc = fmaf(in[(size_t)ci * a.Lin + r], wj[(size_t)ci * a.cout], acc);
         } else if (a.in_mode == IN_F32_ACT) {
             const float* row = in + (size_t)r * a.cin;
+            const float* rowb = a.in_b ? a.in_b + (size_t)b * a.in_bstride + (size_t)r * a.cin : nullptr;
+            const float* rowc = a.in_c ? a.in_c + (size_t)b * a.in_bstride + (size_t)r * a.cin : nullptr;
             for (int ci = 0; ci < a.cin; ++ci) {
                 float v = row[ci];
+                if (rowb) v = v + rowb[ci];
+                if (rowc) v = v + rowc[ci];
                 if (a.div_in != 1.f) v = v / a.div_in;
                 acc = fmaf(lrelu(v, a.slope_in), wj[(size_t)ci * a.cout], acc);
             }
@@ -228,35 +234,53 @@ __global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x, const 
     x[((size_t)b * L + t) * C + co] += acc;
 }
 
-// out[b][t] = tanh(sum_{j,ci} lrelu(x[t-3+j][ci]/div, 0.01) * Wp[j][ci])    (nsf.py:187-189)
-// One thread per output sample, the [7][C] filter in LDS.  HBM-bound: reads the last stage once.
-__global__ void __launch_bounds__(256) k_post(const float* __restrict__ x, const float* __restrict__ Wp /*[7][C]*/,
+// out[b][t] = tanh(sum_{j,ci} lrelu(x[t-3+j][ci], 0.01) * Wp[j][ci]),  x = ((xa + xb) + xc) / div   (nsf.py:186-189)
+// HBM-bound: the last stage is read exactly once with coalesced float4 loads into an LDS tile whose
+// row stride C+1 makes the per-thread row walk conflict-free.
+constexpr int POST_TT = 256;
+__global__ void __launch_bounds__(256) k_post(const float* __restrict__ xa, const float* __restrict__ xb,
+                                              const float* __restrict__ xc, const float* __restrict__ Wp /*[7][C]*/,
                                               float* __restrict__ out, int L, int C, float div) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* w = (float*)smem_raw;
-    for (int i = threadIdx.x; i < 7 * C; i += 256) w[i] = Wp[i];
-    __syncthreads();
+    float* w = (float*)smem_raw;          // [7][C]
+    float* tile = w + 7 * C;              // [POST_TT + 6][C + 1]
     const int b = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t0 = blockIdx.x * POST_TT;
+    const int S = C + 1;
+    for (int i = threadIdx.x; i < 7 * C; i += 256) w[i] = Wp[i];
+    const int C4 = C >> 2;
+    const size_t boff = (size_t)b * L * C;
+    for (int idx = threadIdx.x; idx < (POST_TT + 6) * C4; idx += 256) {
+        const int r = idx / C4, c4 = idx - r * C4;
+        const int t = t0 - 3 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < L) {
+            v = *(const float4*)(xa + boff + (size_t)t * C + c4 * 4);
+            if (xb) { const float4 o = *(const float4*)(xb + boff + (size_t)t * C + c4 * 4); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (xc) { const float4 o = *(const float4*)(xc + boff + (size_t)t * C + c4 * 4); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            if (div != 1.f) { v.x = v.x / div; v.y = v.y / div; v.z = v.z / div; v.w = v.w / div; }
+            v.x = lrelu(v.x, 0.01f); v.y = lrelu(v.y, 0.01f); v.z = lrelu(v.z, 0.01f); v.w = lrelu(v.w, 0.01f);
+        }
+        float* d = tile + r * S + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
     if (t >= L) return;
-    const float* xb = x + (size_t)b * L * C;
     float acc = 0.f;
     for (int j = 0; j < 7; ++j) {
-        int r = t - 3 + j;
-        if (r < 0 || r >= L) continue;
-        const float4* row = (const float4*)(xb + (size_t)r * C);
+        const float* row = tile + (threadIdx.x + j) * S;
         const float* wj = w + j * C;
-        for (int c4 = 0; c4 < C / 4; ++c4) {
-            float4 v = row[c4];
-            float e0 = v.x, e1 = v.y, e2 = v.z, e3 = v.w;
-            if (div != 1.f) { e0 = e0 / div; e1 = e1 / div; e2 = e2 / div; e3 = e3 / div; }
-            acc = fmaf(lrelu(e0, 0.01f), wj[c4 * 4 + 0], acc);
-            acc = fmaf(lrelu(e1, 0.01f), wj[c4 * 4 + 1], acc);
-            acc = fmaf(lrelu(e2, 0.01f), wj[c4 * 4 + 2], acc);
-            acc = fmaf(lrelu(e3, 0.01f), wj[c4 * 4 + 3], acc);
-        }
+        for (int c = 0; c < C; ++c) acc = fmaf(row[c], wj[c], acc);
     }
     out[(size_t)b * L + t] = tanhf(acc);
+}
+
+// y = (a + b) + c   (debug tap of the stage sum only)
+__global__ void __launch_bounds__(256) k_sum3(const float* __restrict__ a, const float* __restrict__ b,
+                                              const float* __restrict__ c, float* __restrict__ y, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = (a[i] + (b ? b[i] : 0.f)) + (c ? c[i] : 0.f);
 }
 
 // channels-last fp32 [B][L][C] -> channel-first [B][C][L] (debug taps only)
@@ -303,7 +327,17 @@ struct Op<_Float16> {
     }
 };
 
-constexpr int KGROUP = 4;  // k-steps (of 16) per software-pipeline group
+constexpr int KGROUP = 4;  // k-steps (of 16) per software-pipeline group (also the weight-packing pad unit)
+
+// float -> operand, round-to-nearest-even; fp16 saturates instead of overflowing to inf.
+template <typename OpT>
+__device__ __forceinline__ OpT to_op(float v) {
+    return (OpT)v;
+}
+template <>
+__device__ __forceinline__ _Float16 to_op<_Float16>(float v) {
+    return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+}
 
 template <int CIN>
 struct Tile {
@@ -335,16 +369,26 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
                 const float4* p = (const float4*)((const float*)a.in + (size_t)b * a.in_bstride + (size_t)gr * CIN + c8 * 8);
                 float4 lo = p[0], hi = p[1];
                 float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (a.in_b) {
+                    const float4* pb = (const float4*)(a.in_b + (size_t)b * a.in_bstride + (size_t)gr * CIN + c8 * 8);
+                    float4 l2 = pb[0], h2 = pb[1];
+                    f[0] += l2.x; f[1] += l2.y; f[2] += l2.z; f[3] += l2.w; f[4] += h2.x; f[5] += h2.y; f[6] += h2.z; f[7] += h2.w;
+                }
+                if (a.in_c) {
+                    const float4* pc = (const float4*)(a.in_c + (size_t)b * a.in_bstride + (size_t)gr * CIN + c8 * 8);
+                    float4 l2 = pc[0], h2 = pc[1];
+                    f[0] += l2.x; f[1] += l2.y; f[2] += l2.z; f[3] += l2.w; f[4] += h2.x; f[5] += h2.y; f[6] += h2.z; f[7] += h2.w;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float x = f[e];
                     if (a.div_in != 1.f) x = x / a.div_in;
-                    v[e] = (OpT)lrelu(x, a.slope_in);
+                    v[e] = to_op<OpT>(lrelu(x, a.slope_in));
                 }
             } else {  // IN_F32_CF
                 const float* p = (const float*)a.in + (size_t)b * a.in_bstride + (size_t)(c8 * 8) * a.Lin + gr;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (OpT)p[(size_t)e * a.Lin];
+                for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(p[(size_t)e * a.Lin]);
             }
         }
         *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
@@ -354,13 +398,15 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
 // The K loop.  acc[mi][jt] += sum over (padded) taps and channel chunks.
 //   lds_lane : smem + (wave_t0 + (lane&31)) * STRIDE + (lane>>5)*16
 //   wlane    : packed weights of this wave's first co tile + lane*8
-template <typename OpT, int CIN, int MI, int NJ>
+template <typename OpT, int CIN, int MI, int NJ, int KGROUP = ::rvcmi::KGROUP>
 __device__ __forceinline__ void conv_core(f32x16 (&acc)[MI][NJ], const char* lds_lane, const OpT* wlane,
                                           long ct_stride, int ntaps_p, int roff, int dstep) {
     using frag = typename Op<OpT>::frag;
     using TL = Tile<CIN>;
     constexpr int CC = TL::CC;
     constexpr int STRIDE = TL::STRIDE;
+    constexpr int TAPS_PER_GROUP = (CC >= KGROUP) ? 1 : KGROUP / CC;
+    static_assert((CC >= KGROUP) ? (CC % KGROUP == 0) : (KGROUP % CC == 0), "k-group must tile a tap");
     const int NG = ntaps_p * CC / KGROUP;
 
     frag A0[KGROUP][MI], A1[KGROUP][MI];
@@ -377,7 +423,7 @@ __device__ __forceinline__ void conv_core(f32x16 (&acc)[MI][NJ], const char* lds
             tap0 = (grp * KGROUP) / CC;
             cc0 = (grp * KGROUP) % CC;
         } else {
-            tap0 = grp * TL::TAPS_PER_GROUP;
+            tap0 = grp * TAPS_PER_GROUP;
             cc0 = 0;
         }
 #pragma unroll
@@ -473,7 +519,7 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
                     using o4 = __attribute__((ext_vector_type(4))) OpT;
                     o4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (OpT)lrelu(v[e], a.slope_out);
+                    for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(lrelu(v[e], a.slope_out));
                     *(o4*)((OpT*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co) = o;
                 } else {
                     if (a.cb) v += *(const f32x4*)(a.cb + (size_t)b * a.cout + co);
@@ -482,6 +528,174 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
                     if (a.accumulate) v += *o;
                     *o = v;
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused ResBlock1 pair (residuals.py:73-82):   x <- conv2(lrelu(conv1_dil(lrelu(x)) + b1)) + b2 + x
+// ------------------------------------------------------------------------------------------------
+//
+// One launch covers pair level m of ALL resblocks of a stage (grid.y = resblock j; they read the same
+// or sibling fp32 streams and are independent).  Per block, for one utterance and one time tile:
+//   1. stage lrelu(x) as OpT into an LDS tile X of 128 + (k-1)*dil rows           (HBM read #1)
+//   2. conv1 (dilated) on MFMA -> 128 rows of h; barrier
+//   3. h -> lrelu -> OpT written back INTO THE SAME LDS region (X is dead; rows outside [0,L) are
+//      written as zeros because conv2 zero-pads ITS input)                        barrier
+//   4. conv2 (dil 1) on MFMA over the h tile -> 128-(k-1) valid output rows
+//   5. epilogue: + b2 + residual x (fp32, HBM read #2) -> fp32 store              (HBM write)
+// The intermediate never leaves the CU, and the only barriers are around step 3.  A block is
+// C/64 waves (each wave owns a 64-channel output slice and streams its own weights), so 2-8 blocks
+// share a CU and one block's staging/epilogue overlaps another block's MFMA work.
+
+struct RbJob {
+    const float* src;   // x  [B][L][C] fp32
+    float* dst;         // x' [B][L][C] fp32
+    const void* w1;     // packed conv1 weights
+    const void* w2;
+    const float* b1;
+    const float* b2;
+    long ct1, ct2;      // packed elements per 32-channel output tile
+    int k_p;            // padded tap count (same for conv1 and conv2)
+    int k;              // real kernel size
+    int dil;            // conv1 dilation
+    int tt2;            // valid outputs per tile = 128 - (k-1)
+    int ntiles;
+};
+struct RbPairArgs {
+    RbJob job[4];
+    int L;
+    long bstride;
+};
+
+constexpr int RB_ROWS = 128;  // conv1 output rows per tile = 4 MFMA column tiles per wave
+
+template <typename OpT, int C, int MI, int NW, int KG>
+__global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
+    using TL = Tile<C>;
+    using frag = typename Op<OpT>::frag;
+    constexpr int STRIDE = TL::STRIDE;
+    constexpr int C8 = C / 8;
+    constexpr int NT = 64 * NW;
+    constexpr int NJ = RB_ROWS / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const RbJob& J = a.job[blockIdx.y];
+    if ((int)blockIdx.x >= J.ntiles) return;
+    const int b = blockIdx.z;
+    const int p2 = (J.k - 1) / 2;
+    const int p1 = J.dil * (J.k - 1) / 2;
+    const int t0 = blockIdx.x * J.tt2;          // first output time of this tile
+    const int h0 = t0 - p2;                     // global time of h row 0
+    const int x0 = h0 - p1;                     // global time of X row 0
+    const int xrows = RB_ROWS + (J.k_p - 1) * J.dil;
+    const float* src = J.src + (size_t)b * a.bstride;
+
+    // ---- 1. stage lrelu(x) -> OpT tile, 4 independent 32-byte loads in flight per thread ----------
+    const int total = xrows * C8;
+    for (int base = threadIdx.x; base < total; base += 4 * NT) {
+        float4 lo[4], hi[4];
+        int rr[4], cc8[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * NT;
+            rr[u] = idx / C8;
+            cc8[u] = idx - rr[u] * C8;
+            const int gr = x0 + rr[u];
+            ok[u] = idx < total && gr >= 0 && gr < a.L;
+            if (ok[u]) {
+                const float4* p = (const float4*)(src + (size_t)gr * C + cc8[u] * 8);
+                lo[u] = p[0];
+                hi[u] = p[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (base + u * NT >= total) continue;
+            frag v;
+            if (ok[u]) {
+                const float f[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(lrelu(f[e], 0.1f));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (OpT)0.f;
+            }
+            *(frag*)(smem + (size_t)rr[u] * STRIDE + cc8[u] * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int ct0 = wave * MI;
+    const char* lds_lane = smem + (size_t)(lane & 31) * STRIDE + (lane >> 5) * 16;
+
+    f32x16 acc[MI][NJ];
+    auto zero = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][jt][r] = 0.f;
+    };
+
+    // ---- 2. conv1 -----------------------------------------------------------------------------------
+    zero();
+    conv_core<OpT, C, MI, NJ, KG>(acc, lds_lane, (const OpT*)J.w1 + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p, 0, J.dil);
+    __syncthreads();  // every wave has finished reading X
+
+    // ---- 3. h = lrelu(conv1 + b1) -> OpT, in place over X (zero outside the utterance) --------------
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int hrow = jt * 32 + (lane & 31);
+            const int th = h0 + hrow;
+            const bool inside = th >= 0 && th < a.L;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cobase + 8 * g;
+                using o4 = __attribute__((ext_vector_type(4))) OpT;
+                o4 o;
+                if (co < C) {
+                    const f32x4 bv = *(const f32x4*)(J.b1 + co);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = inside ? to_op<OpT>(lrelu(acc[mi][jt][4 * g + e] + bv[e], 0.1f)) : (OpT)0.f;
+                    *(o4*)(smem + (size_t)hrow * STRIDE + co * 2) = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. conv2 -----------------------------------------------------------------------------------
+    zero();
+    conv_core<OpT, C, MI, NJ, KG>(acc, lds_lane, (const OpT*)J.w2 + (size_t)ct0 * J.ct2 + lane * 8, J.ct2, J.k_p, 0, 1);
+
+    // ---- 5. epilogue: x' = conv2 + b2 + x ------------------------------------------------------------
+    float* dst = J.dst + (size_t)b * a.bstride;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int o = jt * 32 + (lane & 31);
+            const int t = t0 + o;
+            if (o >= J.tt2 || t >= a.L) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cobase + 8 * g;
+                if (co >= C) continue;
+                f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
+                v += *(const f32x4*)(J.b2 + co);
+                v += *(const f32x4*)(src + (size_t)t * C + co);
+                *(f32x4*)(dst + (size_t)t * C + co) = v;
             }
         }
     }
