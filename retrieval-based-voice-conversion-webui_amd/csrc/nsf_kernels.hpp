@@ -592,38 +592,38 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
     const int xrows = RB_ROWS + (J.k_p - 1) * J.dil;
     const float* src = J.src + (size_t)b * a.bstride;
 
-    // ---- 1. stage lrelu(x) -> OpT tile, 4 independent 32-byte loads in flight per thread ----------
+    // ---- 1. stage lrelu(x) -> OpT tile.  SB independent 32-byte loads in flight per thread: the
+    //         accumulators are not live yet, so the whole register file is available as a landing zone.
+    constexpr int SB = 8;
     const int total = xrows * C8;
-    for (int base = threadIdx.x; base < total; base += 4 * NT) {
-        float4 lo[4], hi[4];
-        int rr[4], cc8[4];
-        bool ok[4];
+    for (int base = threadIdx.x; base < total; base += SB * NT) {
+        float4 lo[SB], hi[SB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SB; ++u) {
             const int idx = base + u * NT;
-            rr[u] = idx / C8;
-            cc8[u] = idx - rr[u] * C8;
-            const int gr = x0 + rr[u];
-            ok[u] = idx < total && gr >= 0 && gr < a.L;
-            if (ok[u]) {
-                const float4* p = (const float4*)(src + (size_t)gr * C + cc8[u] * 8);
+            const int r = idx / C8;
+            const int c8 = idx - r * C8;
+            const int gr = x0 + r;
+            if (idx < total && gr >= 0 && gr < a.L) {
+                const float4* p = (const float4*)(src + (size_t)gr * C + c8 * 8);
                 lo[u] = p[0];
                 hi[u] = p[1];
+            } else {
+                lo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                hi[u] = lo[u];
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (base + u * NT >= total) continue;
+        for (int u = 0; u < SB; ++u) {
+            const int idx = base + u * NT;
+            if (idx >= total) continue;
+            const int r = idx / C8;
+            const int c8 = idx - r * C8;
+            const float f[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
             frag v;
-            if (ok[u]) {
-                const float f[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(lrelu(f[e], 0.1f));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (OpT)0.f;
-            }
-            *(frag*)(smem + (size_t)rr[u] * STRIDE + cc8[u] * 16) = v;
+            for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(lrelu(f[e], 0.1f));
+            *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
         }
     }
     __syncthreads();
