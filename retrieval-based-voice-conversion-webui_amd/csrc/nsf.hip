@@ -408,11 +408,15 @@ static void set_lds_all() {
 }
 template <typename OpT>
 static void set_lds_rb();
+template <typename OpT>
+static void set_lds_ups();
 static void set_lds_limits() {
     set_lds_all<__bf16>();
     set_lds_all<_Float16>();
     set_lds_rb<__bf16>();
     set_lds_rb<_Float16>();
+    set_lds_ups<__bf16>();
+    set_lds_ups<_Float16>();
 }
 
 
@@ -444,6 +448,42 @@ static void set_lds_rb() {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RB_ATTR(256, 2, 4) RB_ATTR(128, 2, 2) RB_ATTR(64, 2, 1) RB_ATTR(32, 1, 1) RB_ATTR(16, 1, 1)
 #undef RB_ATTR
+}
+
+template <typename OpT, int CIN, int MI, int WV>
+static void launch_ups_inst(const UpsArgs& a, int B, hipStream_t st) {
+    constexpr int TQ = 32 * 4 * (4 / WV);
+    const size_t smem = (size_t)a.tile_rows * Tile<CIN>::STRIDE;
+    if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "upsampler LDS tile too large (%zu B)", smem);
+    const int per_block = WV * a.vpw;
+    dim3 grid((a.Lin + TQ - 1) / TQ, (a.nvt + per_block - 1) / per_block, B);
+    hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV>), grid, dim3(256), smem, st, a);
+}
+#define RVCMI_UPS_CASES(X, OpT) \
+    X(OpT, 512, 2) X(OpT, 256, 2) X(OpT, 128, 2) X(OpT, 64, 1) X(OpT, 32, 1)
+template <typename OpT>
+static void launch_ups_t(const UpsArgs& a, int wv, int B, hipStream_t st) {
+#define X(OpT_, CIN_, MI_)                                                        \
+    if (a.cin == CIN_) {                                                          \
+        if (wv == 4) return launch_ups_inst<OpT_, CIN_, MI_, 4>(a, B, st);        \
+        if (wv == 2) return launch_ups_inst<OpT_, CIN_, MI_, 2>(a, B, st);        \
+        return launch_ups_inst<OpT_, CIN_, MI_, 1>(a, B, st);                     \
+    }
+    RVCMI_UPS_CASES(X, OpT)
+#undef X
+    RVCMI_FAIL(RVCMI_ERR_INVALID, "unsupported upsampler C_in %d", a.cin);
+}
+template <typename OpT>
+static void set_lds_ups() {
+#define X(OpT_, CIN_, MI_)                                                                                              \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ups<OpT_, CIN_, MI_, 4>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                             \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ups<OpT_, CIN_, MI_, 2>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                             \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ups<OpT_, CIN_, MI_, 1>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RVCMI_UPS_CASES(X, OpT)
+#undef X
 }
 
 // Fill the common part of ConvArgs for `L` and launch it in the handle's operand mode.
@@ -608,31 +648,87 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
         const int C = s.cout;
         const int nk = (int)s.rb.size();
         char nm[48];
-        {  // x = ups[i](leaky_relu(x, 0.1))                                    nsf.py:171-172
-            ConvArgs a = base_args();
-            a.in = y[0];
-            a.in_b = y[1];
-            a.in_c = y[2];
-            a.in_bstride = Lin * Cprev;
-            a.Lin = (int)Lin;
-            a.in_mode = IN_F32_ACT;
-            a.div_in = div;
-            a.Lq = (int)Lin;
-            a.out_mode = OUT_F32;
-            a.out = h->X0.p;
-            a.out_bstride = L * C;
-            a.out_C = C;
-            a.out_mul = s.u;
+        if (op == RVCMI_OPERAND_F32) {
+            {  // x = ups[i](leaky_relu(x, 0.1))                                nsf.py:171-172
+                ConvArgs a = base_args();
+                a.in = y[0];
+                a.in_b = y[1];
+                a.in_c = y[2];
+                a.in_bstride = Lin * Cprev;
+                a.Lin = (int)Lin;
+                a.in_mode = IN_F32_ACT;
+                a.div_in = div;
+                a.Lq = (int)Lin;
+                a.out_mode = OUT_F32;
+                a.out = h->X0.p;
+                a.out_bstride = L * C;
+                a.out_C = C;
+                a.out_mul = s.u;
+                snprintf(nm, sizeof(nm), "ups_c%d", s.cin);
+                run_conv(h, s.up, a, B, nm, st);
+            }
+            if (c.use_f0) {  // x = x + noise_convs[i](har)                       nsf.py:173-174
+                const size_t n = (size_t)L * C;
+                snprintf(nm, sizeof(nm), "noise_conv_c%d", C);
+                h->prof.launch(nm, 2.0 * s.nk * n * B, (double)B * n * 8, st, [&] {
+                    hipLaunchKernelGGL(k_noise_add, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, h->X0.as<float>(),
+                                       har, s.noise_w.as<float>(), s.noise_b.as<float>(), (int)L, C, Te * upp, s.nk, s.ns, s.npad);
+                });
+            }
+        } else {  // ups + bias + noise conv in one MFMA kernel, X0 written once      nsf.py:171-174
+            const ConvLayer& U = s.up;
+            UpsArgs ua;
+            memset(&ua, 0, sizeof(ua));
+            ua.in_a = y[0];
+            ua.in_b = y[1];
+            ua.in_c = y[2];
+            ua.div = div;
+            ua.Lin = (int)Lin;
+            ua.cin = s.cin;
+            ua.in_bstride = Lin * Cprev;
+            ua.w = U.w_pack.p;
+            ua.ct_stride = U.ct_stride;
+            int lo = 1 << 30, hi = -(1 << 30);
+            for (int r = 0; r < s.u; ++r) {
+                ua.ph_w_off[r] = U.pack_off[r];
+                ua.ph_in_off[r] = U.in_off[r];
+                lo = std::min(lo, U.in_off[r] - (U.ntaps_p - 1));
+                hi = std::max(hi, U.in_off[r]);
+            }
+            ua.ntaps_p = U.ntaps_p;
+            ua.u = s.u;
+            ua.cout = C;
+            ua.lo = lo;
+            ua.bias = U.bias.as<float>();
+            ua.out = h->X0.as<float>();
+            ua.out_bstride = L * C;
+            if (c.use_f0) {
+                ua.har = har;
+                ua.Lh = Te * upp;
+                ua.Wn = s.noise_w.as<float>();
+                ua.bn = s.noise_b.as<float>();
+                ua.nk = s.nk;
+                ua.ns = s.ns;
+                ua.npad = s.npad;
+            }
+            const int MIu = C >= 64 ? 2 : 1;
+            ua.cog = (C + 32 * MIu - 1) / (32 * MIu);
+            ua.nvt = s.u * ua.cog;
+            const int wv = ua.nvt >= 4 ? 4 : (ua.nvt >= 2 ? 2 : 1);
+            const int TQ = 128 * (4 / wv);
+            ua.tile_rows = TQ + (hi - lo);
+            const long qtiles = (Lin + TQ - 1) / TQ;
+            int vpw = (ua.nvt + wv - 1) / wv;  // everything in one block ...
+            while (vpw > 1 && qtiles * B * ((ua.nvt + wv * vpw - 1) / (wv * vpw)) < 512) --vpw;  // ... unless the grid would starve
+            ua.vpw = vpw;
             snprintf(nm, sizeof(nm), "ups_c%d", s.cin);
-            run_conv(h, s.up, a, B, nm, st);
-        }
-        if (c.use_f0) {  // x = x + noise_convs[i](har)                           nsf.py:173-174
-            const size_t n = (size_t)L * C;
-            snprintf(nm, sizeof(nm), "noise_conv_c%d", C);
-            h->prof.launch(nm, 2.0 * s.nk * n * B, (double)B * n * 8, st, [&] {
-                hipLaunchKernelGGL(k_noise_add, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, h->X0.as<float>(),
-                                   har, s.noise_w.as<float>(), s.noise_b.as<float>(), (int)L, C, Te * upp, s.nk, s.ns, s.npad);
+            const double flops = U.flops_per_pos * (double)Lin * B + 2.0 * s.nk * (double)L * C * B;
+            const double bytes = (double)B * Lin * Cprev * 4 * (y[1] ? (y[2] ? 3 : 2) : 1) + (double)B * L * C * 4;
+            h->prof.launch(nm, flops, bytes, st, [&] {
+                if (op == RVCMI_OPERAND_BF16) launch_ups_t<__bf16>(ua, wv, B, st);
+                else launch_ups_t<_Float16>(ua, wv, B, st);
             });
+            HIP_CHECK(hipGetLastError());
         }
         snprintf(nm, sizeof(nm), "up%d", i);
         if (want(nm)) return copy_tap_cl(h, h->X0.as<float>(), B, (int)L, C, tr, st);

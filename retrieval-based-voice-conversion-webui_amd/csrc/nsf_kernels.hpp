@@ -701,4 +701,170 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Polyphase transposed convolution + noise conv (nsf.py:171-174):
+//   X0[q*u + r] = b + sum_j lrelu(x)[q + off_r - j] * Wt[:, :, cm_r + j*u]  +  noise_conv(har)[q*u + r]
+// ------------------------------------------------------------------------------------------------
+//
+// x = ((in_a + in_b) + in_c) / div is the mean of the previous stage's resblocks (nsf.py:186).  The
+// activated input tile is staged ONCE per block and shared by every phase r and output-channel group
+// ("virtual tile") the block's waves walk through; the epilogue adds the bias and the strided 1->C
+// noise convolution (VALU, k = 2*s taps of the har excitation) so X0 is written exactly once.
+struct UpsArgs {
+    const float* in_a;
+    const float* in_b;
+    const float* in_c;
+    float div;
+    int Lin, cin;
+    long in_bstride;
+    const void* w;
+    long ct_stride;
+    long ph_w_off[16];
+    int ph_in_off[16];
+    int ntaps_p, u, cout;
+    int lo;          // lowest input-row offset any (phase, tap) touches relative to q
+    int tile_rows;
+    const float* bias;
+    float* out;
+    long out_bstride;
+    const float* har;  // [B][Lh] or nullptr (no-f0 generator)
+    int Lh;
+    const float* Wn;   // [nk][cout]
+    const float* bn;
+    int nk, ns, npad;
+    int nvt, cog, vpw;
+};
+
+template <typename OpT, int CIN, int MI, int WV>
+__global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
+    using TL = Tile<CIN>;
+    using frag = typename Op<OpT>::frag;
+    constexpr int STRIDE = TL::STRIDE;
+    constexpr int C8 = CIN / 8;
+    constexpr int NJ = 4;
+    constexpr int WT = 4 / WV;
+    constexpr int TQ = 32 * NJ * WT;
+    constexpr int SB = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * TQ;
+    const int g0 = q0 + a.lo;
+    const size_t boff = (size_t)b * a.in_bstride;
+
+    const int total = a.tile_rows * C8;
+    for (int base = threadIdx.x; base < total; base += SB * 256) {
+        float f[SB][8];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int idx = base + u * 256;
+            const int r = idx / C8;
+            const int c8 = idx - r * C8;
+            const int gr = g0 + r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[u][e] = 0.f;
+            if (idx < total && gr >= 0 && gr < a.Lin) {
+                const size_t o = boff + (size_t)gr * CIN + c8 * 8;
+                const float4 l0 = *(const float4*)(a.in_a + o), h0 = *(const float4*)(a.in_a + o + 4);
+                f[u][0] = l0.x; f[u][1] = l0.y; f[u][2] = l0.z; f[u][3] = l0.w; f[u][4] = h0.x; f[u][5] = h0.y; f[u][6] = h0.z; f[u][7] = h0.w;
+                if (a.in_b) {
+                    const float4 l1 = *(const float4*)(a.in_b + o), h1 = *(const float4*)(a.in_b + o + 4);
+                    f[u][0] += l1.x; f[u][1] += l1.y; f[u][2] += l1.z; f[u][3] += l1.w; f[u][4] += h1.x; f[u][5] += h1.y; f[u][6] += h1.z; f[u][7] += h1.w;
+                }
+                if (a.in_c) {
+                    const float4 l2 = *(const float4*)(a.in_c + o), h2 = *(const float4*)(a.in_c + o + 4);
+                    f[u][0] += l2.x; f[u][1] += l2.y; f[u][2] += l2.z; f[u][3] += l2.w; f[u][4] += h2.x; f[u][5] += h2.y; f[u][6] += h2.z; f[u][7] += h2.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int idx = base + u * 256;
+            if (idx >= total) continue;
+            const int r = idx / C8;
+            const int c8 = idx - r * C8;
+            frag v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = f[u][e];
+                if (a.div != 1.f) x = x / a.div;
+                v[e] = to_op<OpT>(lrelu(x, 0.1f));
+            }
+            *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = wave % WV, wt = wave / WV;
+    const int tw0 = wt * NJ * 32;
+    const char* lds_lane = smem + (size_t)(tw0 + (lane & 31)) * STRIDE + (lane >> 5) * 16;
+    const float* har = a.har ? a.har + (size_t)b * a.Lh : nullptr;
+    float* out = a.out + (size_t)b * a.out_bstride;
+
+    for (int i = 0; i < a.vpw; ++i) {
+        const int vt = ((int)blockIdx.y * WV + wv) * a.vpw + i;
+        if (vt >= a.nvt) break;
+        const int r = vt / a.cog;
+        const int ct0 = (vt - r * a.cog) * MI;
+        f32x16 acc[MI][NJ];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
+        const OpT* wlane = (const OpT*)a.w + a.ph_w_off[r] + (size_t)ct0 * a.ct_stride + lane * 8;
+        conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.ct_stride, a.ntaps_p, a.ph_in_off[r] - a.lo, -1);
+
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int q = q0 + tw0 + jt * 32 + (lane & 31);
+            if (q >= a.Lin) continue;
+            const int t = q * a.u + r;
+            // noise conv for this output row: nv[mi][g] (4 channels each) += har[t*s - pad + j] * Wn[j][co]
+            f32x4 nv[MI][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) nv[mi][g] = {0.f, 0.f, 0.f, 0.f};
+            if (har) {
+                const int hb = t * a.ns - a.npad;
+                for (int j = 0; j < a.nk; ++j) {
+                    const int hi = hb + j;
+                    const float hv = (hi >= 0 && hi < a.Lh) ? har[hi] : 0.f;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = cobase + 8 * g;
+                            if (co < a.cout) {
+                                const f32x4 wv4 = *(const f32x4*)(a.Wn + (size_t)j * a.cout + co);
+                                nv[mi][g] += wv4 * hv;
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = cobase + 8 * g;
+                    if (co >= a.cout) continue;
+                    f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
+                    v += *(const f32x4*)(a.bias + co);
+                    if (har) {  // x + (noise_conv + its bias): same association as nsf.py:173-174
+                        const f32x4 nb = nv[mi][g] + *(const f32x4*)(a.bn + co);
+                        v += nb;
+                    }
+                    *(f32x4*)(out + (size_t)t * a.cout + co) = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace rvcmi
