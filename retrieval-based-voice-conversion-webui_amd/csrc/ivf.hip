@@ -30,7 +30,8 @@ struct BlobHeader {  // first 128 bytes of the device blob; everything the kerne
     int64_t pos_last;  // list-major position of the row whose id == ntotal-1 (numpy's big_npy[-1])
     uint64_t off_centroids, off_list_offsets, off_ids, off_vecs;
     uint64_t total_bytes;
-    uint64_t reserved[5];
+    uint64_t off_centroids_t;  // [d/4][nlist] float4: the coarse pass reads it lane-per-centroid, coalesced
+    uint64_t reserved[4];
 };
 static_assert(sizeof(BlobHeader) == 128, "blob header must be 128 bytes");
 static const uint64_t kMagic = 0x465649494d435652ull;  // "RVCMIIVF" little-endian
@@ -46,7 +47,7 @@ constexpr int QT = 4;  // queries per coarse block
 // Coarse quantiser, nprobe == 1: for QT queries (LDS, broadcast reads) every lane owns one centroid
 // at a time and accumulates QT fp64 distances for it -- no cross-lane reduction in the hot loop.
 // Each lane keeps its running best; one wave-level (dist, id) argmin per query at the end.
-__global__ void __launch_bounds__(256) k_coarse1(const float* __restrict__ q, const float* __restrict__ cent,
+__global__ void __launch_bounds__(256) k_coarse1(const float* __restrict__ q, const float4* __restrict__ cent_t,
                                                  int64_t nq, int64_t nlist, int d, int64_t* __restrict__ assign) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* qs = (float*)smem_raw;                               // [QT][d]
@@ -65,13 +66,13 @@ __global__ void __launch_bounds__(256) k_coarse1(const float* __restrict__ q, co
     for (int k = 0; k < QT; ++k) { best[k] = INFINITY; besti[k] = INT64_MAX; }
     const int d4 = d >> 2;
     for (int64_t c = threadIdx.x; c < nlist; c += 256) {
-        const float4* row = (const float4*)(cent + c * d);
+        const float4* row = cent_t + c;  // element e of centroid c lives at cent_t[e*nlist + c]
         double acc[QT];
 #pragma unroll
         for (int k = 0; k < QT; ++k) acc[k] = 0.0;
-#pragma unroll 4
+#pragma unroll 8
         for (int e = 0; e < d4; ++e) {
-            const float4 v = row[e];
+            const float4 v = row[(size_t)e * nlist];
 #pragma unroll
             for (int k = 0; k < QT; ++k) {
                 const float4 qq = *(const float4*)(qs + k * d + e * 4);
@@ -235,32 +236,32 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
     }
     if (sub == 0) merge[grp] = t;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int idx[SCAN_GROUPS];
-        for (int g = 0; g < SCAN_GROUPS; ++g) idx[g] = 0;
-        bool short_list = false;
-        for (int s = 0; s < k; ++s) {
-            int bg = -1;
-            for (int g = 0; g < SCAN_GROUPS; ++g) {
-                if (idx[g] >= KMAX) continue;
-                const double dv = merge[g].d[idx[g]];
-                const int64_t iv = merge[g].id[idx[g]];
-                if (iv == INT64_MAX) continue;
-                if (bg < 0 || before(dv, iv, merge[bg].d[idx[bg]], merge[bg].id[idx[bg]])) bg = g;
-            }
-            if (bg < 0) {  // fewer than k candidates: faiss pads with -1 / FLT_MAX
-                D[qi * k + s] = FLT_MAX;
-                I[qi * k + s] = -1;
-                P[qi * k + s] = -1;
-                short_list = true;
+    // 16 sorted lists x 8 = 128 candidates; thread i ranks candidate i against all others (broadcast LDS reads)
+    // under the strict order (distance, id, slot) and, if it lands in the first k, writes that output slot.
+    if (threadIdx.x < SCAN_GROUPS * KMAX) {
+        const int me = threadIdx.x;
+        const int mg = me / KMAX, ms = me % KMAX;
+        const double md = merge[mg].d[ms];
+        const int64_t mid = merge[mg].id[ms];
+        int rank = 0;
+        for (int o = 0; o < SCAN_GROUPS * KMAX; ++o) {
+            const double od = merge[o / KMAX].d[o % KMAX];
+            const int64_t oid = merge[o / KMAX].id[o % KMAX];
+            const bool ob = od < md || (od == md && (oid < mid || (oid == mid && o < me)));
+            rank += ob ? 1 : 0;
+        }
+        if (rank < k) {
+            if (mid == INT64_MAX) {  // fewer than k candidates: faiss pads with -1 / FLT_MAX
+                D[qi * k + rank] = FLT_MAX;
+                I[qi * k + rank] = -1;
+                P[qi * k + rank] = -1;
+                atomicOr(any_short, 1);
             } else {
-                D[qi * k + s] = (float)merge[bg].d[idx[bg]];
-                I[qi * k + s] = merge[bg].id[idx[bg]];
-                P[qi * k + s] = merge[bg].pos[idx[bg]];
-                idx[bg]++;
+                D[qi * k + rank] = (float)md;
+                I[qi * k + rank] = mid;
+                P[qi * k + rank] = merge[mg].pos[ms];
             }
         }
-        if (short_list) atomicOr(any_short, 1);
     }
 }
 
@@ -318,6 +319,7 @@ struct rvcmi_ivf {
     DevBuf assign, P, Dtmp, Itmp, flag, cdist;
     Profiler prof;
     const float* centroids() const { return (const float*)(blob + hdr.off_centroids); }
+    const float4* centroids_t() const { return (const float4*)(blob + hdr.off_centroids_t); }
     const int64_t* list_off() const { return (const int64_t*)(blob + hdr.off_list_offsets); }
     const int64_t* ids() const { return (const int64_t*)(blob + hdr.off_ids); }
     const float* vecs() const { return (const float*)(blob + hdr.off_vecs); }
@@ -361,11 +363,19 @@ static std::vector<char> build_blob(int d, int64_t n, int64_t nlist, int nprobe,
     off = align_up(off + (uint64_t)std::max<int64_t>(n, 1) * 8, 256);
     h.off_vecs = off;
     off = align_up(off + (uint64_t)std::max<int64_t>(n, 1) * d * 4, 256);
+    h.off_centroids_t = off;
+    off = align_up(off + (uint64_t)nlist * d * 4, 256);
     h.total_bytes = off;
     std::vector<char> blob(off, 0);
     memcpy(blob.data(), &h, sizeof(h));
     memcpy(blob.data() + h.off_centroids, centroids, (size_t)nlist * d * 4);
     memcpy(blob.data() + h.off_list_offsets, list_offsets, (size_t)(nlist + 1) * 8);
+    {
+        float* ct = (float*)(blob.data() + h.off_centroids_t);
+        const int d4 = d / 4;
+        for (int64_t c = 0; c < nlist; ++c)
+            for (int e = 0; e < d4; ++e) memcpy(ct + ((size_t)e * nlist + c) * 4, centroids + c * d + e * 4, 16);
+    }
     if (n) {
         memcpy(blob.data() + h.off_ids, ids, (size_t)n * 8);
         memcpy(blob.data() + h.off_vecs, vecs, (size_t)n * d * 4);
@@ -562,7 +572,7 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
     if (np == 1) {
         const size_t smem = align_up((size_t)QT * d * 4, 16) + 4 * QT * 16;
         h->prof.launch("ivf_coarse", cflops, (double)nq * d * 4 + (double)b.nlist * d * 4, st, [&] {
-            hipLaunchKernelGGL(k_coarse1, dim3((unsigned)((nq + QT - 1) / QT)), dim3(256), smem, st, q, h->centroids(), nq,
+            hipLaunchKernelGGL(k_coarse1, dim3((unsigned)((nq + QT - 1) / QT)), dim3(256), smem, st, q, h->centroids_t(), nq,
                                b.nlist, d, h->assign.as<int64_t>());
         });
     } else {
