@@ -410,6 +410,8 @@ template <typename OpT>
 static void set_lds_rb();
 template <typename OpT>
 static void set_lds_ups();
+template <typename OpT>
+static void set_lds_rbf();
 static void set_lds_limits() {
     set_lds_all<__bf16>();
     set_lds_all<_Float16>();
@@ -417,6 +419,8 @@ static void set_lds_limits() {
     set_lds_rb<_Float16>();
     set_lds_ups<__bf16>();
     set_lds_ups<_Float16>();
+    set_lds_rbf<__bf16>();
+    set_lds_rbf<_Float16>();
 }
 
 
@@ -486,6 +490,39 @@ static void set_lds_ups() {
 #undef X
 }
 
+// ---- fully fused resblock (C <= 64) ----------------------------------------------------------------
+template <int C> struct RbFullGeom;
+// C=64 uses 3 column tiles per wave (R = 384): x(96) + h(96) accumulators + operands stay under 512 registers without spills
+// (NJ = 4 spilled ~100 registers to scratch)
+template <> struct RbFullGeom<64> { static constexpr int MI = 2, NJ = 3, KG = 4; };
+template <> struct RbFullGeom<32> { static constexpr int MI = 1, NJ = 6, KG = 4; };
+template <> struct RbFullGeom<16> { static constexpr int MI = 1, NJ = 6, KG = 4; };
+static int rbf_rows(int C) { return C == 64 ? 384 : 768; }
+template <typename OpT, int C>
+static void launch_rbf_inst(const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
+    using G = RbFullGeom<C>;
+    constexpr int R = 4 * 32 * G::NJ;
+    const size_t smem = (size_t)(R + 2 * RBF_G + R + 2 * RBF_G2) * Tile<C>::STRIDE;
+    hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
+}
+template <typename OpT>
+static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
+    switch (C) {
+        case 64: return launch_rbf_inst<OpT, 64>(ra, tiles, nj, B, st);
+        case 32: return launch_rbf_inst<OpT, 32>(ra, tiles, nj, B, st);
+        case 16: return launch_rbf_inst<OpT, 16>(ra, tiles, nj, B, st);
+        default: RVCMI_FAIL(RVCMI_ERR_INVALID, "fused resblock: unsupported channel count %d", C);
+    }
+}
+template <typename OpT>
+static void set_lds_rbf() {
+#define RBF_ATTR(C_)                                                                                                        \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, C_, RbFullGeom<C_>::MI, RbFullGeom<C_>::NJ, RbFullGeom<C_>::KG>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RBF_ATTR(64) RBF_ATTR(32) RBF_ATTR(16)
+#undef RBF_ATTR
+}
+
 // Fill the common part of ConvArgs for `L` and launch it in the handle's operand mode.
 static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const char* name, hipStream_t st) {
     a.cin = L.cin;
@@ -529,6 +566,12 @@ static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const 
         });
     }
     HIP_CHECK(hipGetLastError());
+}
+
+// RVCMI_DBG: timing-ablation bit mask forwarded to the kernels (results are WRONG when non-zero; bench/dev only).
+static int dbg_flags() {
+    const char* e = getenv("RVCMI_DBG");
+    return e ? atoi(e) : 0;
 }
 
 static ConvArgs base_args() {
@@ -679,6 +722,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             const ConvLayer& U = s.up;
             UpsArgs ua;
             memset(&ua, 0, sizeof(ua));
+            ua.dbg = dbg_flags();
             ua.in_a = y[0];
             ua.in_b = y[1];
             ua.in_c = y[2];
@@ -769,6 +813,57 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     run_conv(h, s.rb[j][m].second, a, B, nm, st);
                     src[j] = dst;
                 }
+        } else if (C <= 64 && maxnd <= 3 && !getenv("RVCMI_NO_RBFULL")) {
+            // whole resblocks fused (x resident in registers): ONE launch for the stage   residuals.py:68-85
+            snprintf(nm, sizeof(nm), "rb_full_c%d", C);
+            RbFullArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.L = (int)L;
+            ra.bstride = L * C;
+            ra.dbg = dbg_flags();
+            const int R = rbf_rows(C);
+            int order[RVCMI_MAX_RB];
+            for (int j = 0; j < nk; ++j) order[j] = j;
+            std::sort(order, order + nk, [&](int a1, int b1) { return s.rb[a1][0].first.ntaps[0] > s.rb[b1][0].first.ntaps[0]; });
+            int max_tiles = 0;
+            double flops = 0, bytes = 0;
+            for (int oj = 0; oj < nk; ++oj) {
+                const int j = order[oj];
+                RbFullJob& J = ra.job[oj];
+                J.src = h->X0.as<float>();
+                J.dst = h->Ya[j].as<float>();
+                J.nd = (int)s.rb[j].size();
+                J.k = s.rb[j][0].first.ntaps[0];
+                J.k_p = s.rb[j][0].first.ntaps_p;
+                J.ct1 = s.rb[j][0].first.ct_stride;
+                J.ct2 = s.rb[j][0].second.ct_stride;
+                int dsum = 0;
+                for (int m = 0; m < J.nd; ++m) {
+                    const ConvLayer& c1 = s.rb[j][m].first;
+                    const ConvLayer& c2 = s.rb[j][m].second;
+                    J.w1[m] = c1.w_pack.p;
+                    J.w2[m] = c2.w_pack.p;
+                    J.b1[m] = c1.bias.as<float>();
+                    J.b2[m] = c2.bias.as<float>();
+                    J.dil[m] = c1.dstep;
+                    dsum += c1.dstep;
+                    flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
+                    bytes += 2.0 * J.k * C * C * 2;
+                    if (c1.dstep * (J.k - 1) / 2 + c1.dstep > RBF_G) RVCMI_FAIL(RVCMI_ERR_INVALID, "dilation too large for the fused resblock");
+                }
+                J.HL = (J.k - 1) / 2 * (dsum + J.nd);
+                J.tvalid = R - 2 * J.HL;
+                if (J.tvalid < R / 4) RVCMI_FAIL(RVCMI_ERR_INVALID, "resblock halo too large for the fused kernel");
+                J.ntiles = (int)((L + J.tvalid - 1) / J.tvalid);
+                max_tiles = std::max(max_tiles, J.ntiles);
+                bytes += (double)B * L * C * 8;
+                src[j] = J.dst;
+            }
+            h->prof.launch(nm, flops, bytes, st, [&] {
+                if (op == RVCMI_OPERAND_BF16) launch_rbf_t<__bf16>(C, ra, max_tiles, nk, B, st);
+                else launch_rbf_t<_Float16>(C, ra, max_tiles, nk, B, st);
+            });
+            HIP_CHECK(hipGetLastError());
         } else {
             snprintf(nm, sizeof(nm), "rb_pair_c%d", C);
             for (size_t m = 0; m < maxnd; ++m) {
@@ -776,6 +871,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 memset(&ra, 0, sizeof(ra));
                 ra.L = (int)L;
                 ra.bstride = L * C;
+                ra.dbg = dbg_flags();
                 int nj = 0, max_tiles = 0, max_rows = 0;
                 double flops = 0, bytes = 0;
                 // heaviest kernel size first so that the long blocks are dispatched first

@@ -567,6 +567,7 @@ struct RbPairArgs {
     RbJob job[4];
     int L;
     long bstride;
+    int dbg;  // timing ablations only (RVCMI_DBG): 1 skip staging loads, 2 skip conv1, 4 skip conv2, 8 skip residual read, 16 skip store
 };
 
 constexpr int RB_ROWS = 128;  // conv1 output rows per tile = 4 MFMA column tiles per wave
@@ -604,11 +605,12 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
             const int r = idx / C8;
             const int c8 = idx - r * C8;
             const int gr = x0 + r;
-            if (idx < total && gr >= 0 && gr < a.L) {
-                const float4* p = (const float4*)(src + (size_t)gr * C + c8 * 8);
-                lo[u] = p[0];
-                hi[u] = p[1];
-            } else {
+            const bool ok = gr >= 0 && gr < a.L;
+            const int grc = min(max(gr, 0), a.L - 1);  // clamped address: unconditional loads, no branch per load
+            const float4* p = (const float4*)(src + (size_t)grc * C + c8 * 8);
+            lo[u] = p[0];
+            hi[u] = p[1];
+            if (!ok) {
                 lo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 hi[u] = lo[u];
             }
@@ -645,7 +647,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
 
     // ---- 2. conv1 -----------------------------------------------------------------------------------
     zero();
-    conv_core<OpT, C, MI, NJ, KG>(acc, lds_lane, (const OpT*)J.w1 + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p, 0, J.dil);
+    if (!(a.dbg & 2))
+        conv_core<OpT, C, MI, NJ, KG>(acc, lds_lane, (const OpT*)J.w1 + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p, 0, J.dil);
     __syncthreads();  // every wave has finished reading X
 
     // ---- 3. h = lrelu(conv1 + b1) -> OpT, in place over X (zero outside the utterance) --------------
@@ -662,7 +665,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
                 const int co = cobase + 8 * g;
                 using o4 = __attribute__((ext_vector_type(4))) OpT;
                 o4 o;
-                if (co < C) {
+                if ((C % 32 == 0) || co < C) {
                     const f32x4 bv = *(const f32x4*)(J.b1 + co);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -676,7 +679,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
 
     // ---- 4. conv2 -----------------------------------------------------------------------------------
     zero();
-    conv_core<OpT, C, MI, NJ, KG>(acc, lds_lane, (const OpT*)J.w2 + (size_t)ct0 * J.ct2 + lane * 8, J.ct2, J.k_p, 0, 1);
+    if (!(a.dbg & 4))
+        conv_core<OpT, C, MI, NJ, KG>(acc, lds_lane, (const OpT*)J.w2 + (size_t)ct0 * J.ct2 + lane * 8, J.ct2, J.k_p, 0, 1);
 
     // ---- 5. epilogue: x' = conv2 + b2 + x ------------------------------------------------------------
     float* dst = J.dst + (size_t)b * a.bstride;
@@ -691,11 +695,11 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = cobase + 8 * g;
-                if (co >= C) continue;
+                if ((C % 32 != 0) && co >= C) continue;
                 f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
                 v += *(const f32x4*)(J.b2 + co);
-                v += *(const f32x4*)(src + (size_t)t * C + co);
-                *(f32x4*)(dst + (size_t)t * C + co) = v;
+                if (!(a.dbg & 8)) v += *(const f32x4*)(src + (size_t)t * C + co);
+                if (!(a.dbg & 16)) *(f32x4*)(dst + (size_t)t * C + co) = v;
             }
         }
     }
@@ -733,6 +737,7 @@ struct UpsArgs {
     const float* bn;
     int nk, ns, npad;
     int nvt, cog, vpw;
+    int dbg;  // timing ablations only: 1 skip staging loads, 2 skip MFMA, 4 skip noise conv, 16 skip store
 };
 
 template <typename OpT, int CIN, int MI, int WV>
@@ -760,10 +765,10 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
             const int r = idx / C8;
             const int c8 = idx - r * C8;
             const int gr = g0 + r;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[u][e] = 0.f;
-            if (idx < total && gr >= 0 && gr < a.Lin) {
-                const size_t o = boff + (size_t)gr * CIN + c8 * 8;
+            const bool ok = gr >= 0 && gr < a.Lin;
+            const int grc = min(max(gr, 0), a.Lin - 1);  // clamped address: unconditional loads
+            {
+                const size_t o = boff + (size_t)grc * CIN + c8 * 8;
                 const float4 l0 = *(const float4*)(a.in_a + o), h0 = *(const float4*)(a.in_a + o + 4);
                 f[u][0] = l0.x; f[u][1] = l0.y; f[u][2] = l0.z; f[u][3] = l0.w; f[u][4] = h0.x; f[u][5] = h0.y; f[u][6] = h0.z; f[u][7] = h0.w;
                 if (a.in_b) {
@@ -774,6 +779,10 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
                     const float4 l2 = *(const float4*)(a.in_c + o), h2 = *(const float4*)(a.in_c + o + 4);
                     f[u][0] += l2.x; f[u][1] += l2.y; f[u][2] += l2.z; f[u][3] += l2.w; f[u][4] += h2.x; f[u][5] += h2.y; f[u][6] += h2.z; f[u][7] += h2.w;
                 }
+            }
+            if (!ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[u][e] = 0.f;
             }
         }
 #pragma unroll
@@ -815,7 +824,7 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
         const OpT* wlane = (const OpT*)a.w + a.ph_w_off[r] + (size_t)ct0 * a.ct_stride + lane * 8;
-        conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.ct_stride, a.ntaps_p, a.ph_in_off[r] - a.lo, -1);
+        if (!(a.dbg & 2)) conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.ct_stride, a.ntaps_p, a.ph_in_off[r] - a.lo, -1);
 
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
@@ -828,7 +837,7 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) nv[mi][g] = {0.f, 0.f, 0.f, 0.f};
-            if (har) {
+            if (har && !(a.dbg & 4)) {
                 const int hb = t * a.ns - a.npad;
                 for (int j = 0; j < a.nk; ++j) {
                     const int hi = hb + j;
@@ -860,11 +869,220 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
                         const f32x4 nb = nv[mi][g] + *(const f32x4*)(a.bn + co);
                         v += nb;
                     }
-                    *(f32x4*)(out + (size_t)t * a.cout + co) = v;
+                    if (!(a.dbg & 16)) *(f32x4*)(out + (size_t)t * a.cout + co) = v;
                 }
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fully fused ResBlock1 (residuals.py:68-85) for C <= 64: all (conv1, conv2) pairs in ONE kernel
+// ------------------------------------------------------------------------------------------------
+//
+// The fp32 residual stream x never leaves the register file: each of the block's 4 waves owns a slab
+// of R/4 time rows x ALL channels as MFMA accumulators (conv2 accumulates straight onto x, which IS the
+// residual add).  LDS holds only the two activated OpT operand tiles (X = lrelu(x), H = lrelu(conv1)),
+// through which the waves exchange their halo rows.  The tile is computed "overlap-save": the block
+// loads R rows, every pair runs on all R rows, edge garbage creeps inwards by (p1+p2) rows per pair and
+// only the central R - 2*HL rows are stored (HL = sum of the pair halos).  Per resblock: one HBM read of
+// x, one HBM write -- instead of one of each per PAIR -- and 2 barriers per pair.
+struct RbFullJob {
+    const float* src;
+    float* dst;
+    const void* w1[3];
+    const void* w2[3];
+    const float* b1[3];
+    const float* b2[3];
+    long ct1, ct2;
+    int k, k_p;
+    int dil[3];
+    int nd;
+    int HL;       // total one-sided halo of the resblock
+    int tvalid;   // R - 2*HL
+    int ntiles;
+};
+struct RbFullArgs {
+    RbFullJob job[3];
+    int L;
+    long bstride;
+    int dbg;
+};
+
+constexpr int RBF_G = 32;   // zero guard rows around X (>= max dilated half-width + one padded tap)
+constexpr int RBF_G2 = 8;   // zero guard rows around H
+
+template <typename OpT, int C, int MI, int NJ, int KG>
+__global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
+    using TL = Tile<C>;
+    constexpr int STRIDE = TL::STRIDE;
+    constexpr int SLAB = 32 * NJ;
+    constexpr int R = 4 * SLAB;
+    constexpr int XROWS = R + 2 * RBF_G;
+    constexpr int HROWS = R + 2 * RBF_G2;
+    constexpr int CP = 32 * MI;  // padded channel count (C == 16 runs as one 32-channel tile)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* X = smem;
+    char* H = smem + (size_t)XROWS * STRIDE;
+
+    const RbFullJob& J = a.job[blockIdx.y];
+    if ((int)blockIdx.x >= J.ntiles) return;
+    const int b = blockIdx.z;
+    const int tg0 = blockIdx.x * J.tvalid - J.HL;  // global time of tile row 0
+    const float* src = J.src + (size_t)b * a.bstride;
+    float* dst = J.dst + (size_t)b * a.bstride;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slab = wave * SLAB;
+    using o4 = __attribute__((ext_vector_type(4))) OpT;
+
+    // zero the guard rows once (nobody writes them afterwards)
+    {
+        constexpr int W = STRIDE / 16;  // 16-byte words per row
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < 2 * RBF_G * W; i += 256) {
+            const int r = i / W, c = i - r * W;
+            const int row = r < RBF_G ? r : RBF_G + R + (r - RBF_G);
+            *(uint4*)(X + (size_t)row * STRIDE + c * 16) = z;
+        }
+        for (int i = threadIdx.x; i < 2 * RBF_G2 * W; i += 256) {
+            const int r = i / W, c = i - r * W;
+            const int row = r < RBF_G2 ? r : RBF_G2 + R + (r - RBF_G2);
+            *(uint4*)(H + (size_t)row * STRIDE + c * 16) = z;
+        }
+    }
+
+    // ---- load x straight into the accumulator layout; publish lrelu(x) as the first operand tile ----
+    f32x16 xacc[MI][NJ];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int row = slab + jt * 32 + (lane & 31);
+            const int tg = tg0 + row;
+            const bool in = tg >= 0 && tg < a.L;
+            const int tgc = min(max(tg, 0), a.L - 1);  // clamped: the load is unconditional (no branch per load)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
+                const int coc = (C % 32 == 0) ? co : min(co, C - 4);
+                const f32x4 v = *(const f32x4*)(src + (size_t)tgc * C + coc);
+                const bool ok = in && ((C % 32 == 0) || co < C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] = ok ? v[e] : 0.f;
+            }
+        }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int row = slab + jt * 32 + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
+                if ((C % 32 == 0) || co < C) {
+                    o4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(lrelu(xacc[mi][jt][4 * g + e], 0.1f));
+                    *(o4*)(X + (size_t)(RBF_G + row) * STRIDE + co * 2) = o;
+                }
+            }
+        }
+    __syncthreads();
+
+    const char* xl = X + (size_t)(slab + (lane & 31)) * STRIDE + (lane >> 5) * 16;
+    const char* hl = H + (size_t)(slab + (lane & 31)) * STRIDE + (lane >> 5) * 16;
+    const int p2 = (J.k - 1) / 2;
+
+    for (int m = 0; m < J.nd; ++m) {
+        const int p1 = J.dil[m] * (J.k - 1) / 2;
+        // ---- conv1 (dilated) -> h -------------------------------------------------------------------
+        f32x16 hacc[MI][NJ];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) hacc[mi][jt][e] = 0.f;
+        if (!(a.dbg & 2))
+            conv_core<OpT, C, MI, NJ, KG>(hacc, xl, (const OpT*)J.w1[m] + lane * 8, J.ct1, J.k_p, RBF_G - p1, J.dil[m]);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                const int row = slab + jt * 32 + (lane & 31);
+                const int tg = tg0 + row;
+                const bool in = tg >= 0 && tg < a.L;  // conv2 zero-pads ITS input at the utterance edges
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
+                    if ((C % 32 == 0) || co < C) {
+                        const f32x4 bv = *(const f32x4*)(J.b1[m] + co);
+                        o4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = in ? to_op<OpT>(lrelu(hacc[mi][jt][4 * g + e] + bv[e], 0.1f)) : (OpT)0.f;
+                        *(o4*)(H + (size_t)(RBF_G2 + row) * STRIDE + co * 2) = o;
+                    }
+                }
+            }
+        __syncthreads();  // h complete; every wave is also done reading X
+        // ---- conv2 accumulates onto x: x <- x + conv2(h) + b2 -----------------------------------------
+        if (!(a.dbg & 4))
+            conv_core<OpT, C, MI, NJ, KG>(xacc, hl, (const OpT*)J.w2[m] + lane * 8, J.ct2, J.k_p, RBF_G2 - p2, 1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
+                if ((C % 32 == 0) || co < C) {
+                    const f32x4 bv = *(const f32x4*)(J.b2[m] + co);
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] += bv[e];
+                }
+            }
+        if (m + 1 < J.nd) {  // publish lrelu(x') for the next pair
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) {
+                    const int row = slab + jt * 32 + (lane & 31);
+                    const int tg = tg0 + row;
+                    const bool in = tg >= 0 && tg < a.L;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
+                        if ((C % 32 == 0) || co < C) {
+                            o4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = in ? to_op<OpT>(lrelu(xacc[mi][jt][4 * g + e], 0.1f)) : (OpT)0.f;
+                            *(o4*)(X + (size_t)(RBF_G + row) * STRIDE + co * 2) = o;
+                        }
+                    }
+                }
+            __syncthreads();
+        }
+    }
+
+    // ---- store the valid centre of the tile ---------------------------------------------------------
+    if (a.dbg & 16) return;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int row = slab + jt * 32 + (lane & 31);
+            const int tg = tg0 + row;
+            if (row < J.HL || row >= R - J.HL || tg >= a.L) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
+                if ((C % 32 != 0) && co >= C) continue;
+                const f32x4 v = {xacc[mi][jt][4 * g + 0], xacc[mi][jt][4 * g + 1], xacc[mi][jt][4 * g + 2], xacc[mi][jt][4 * g + 3]};
+                *(f32x4*)(dst + (size_t)tg * C + co) = v;
+            }
+        }
+    (void)CP;
 }
 
 }  // namespace rvcmi
