@@ -1,0 +1,142 @@
+"""TEST INFRASTRUCTURE ONLY -- pins the oracle to the REFERENCE ITSELF and writes tests/golden/*.npz.
+
+Runs only where /root/reference is mounted (the build container); the GPU box and the tests read the
+committed fixtures, never the reference.  For every case below the reference's own modules
+(``rvc.layers.nsf.NSFGenerator``, ``rvc.layers.generators.Generator``, and for one case the whole
+``SynthesizerTrnMsNSFsid.infer``) are executed on torch-CPU fp32 with seeded synthetic weights, the
+oracle restatement (oracle/nsf_oracle.py) is checked against them to <= 2e-6, and inputs + injected
+noise + outputs are stored.  Weights are NOT stored (63 MB): tests regenerate them from the seed with
+oracle/synth.py and verify the sha256 recorded here.
+
+    python -m oracle.make_golden            # regenerate every fixture
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("RVC_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from oracle import nsf_oracle, synth  # noqa: E402
+from oracle.nsf_oracle import CONFIGS, GenConfig  # noqa: E402
+
+
+def build_reference_dec(cfg: GenConfig, w):
+    sys.path.insert(0, REF)
+    from rvc.layers.generators import Generator
+    from rvc.layers.nsf import NSFGenerator
+
+    if cfg.use_f0:
+        net = NSFGenerator(cfg.inter_channels, "1", cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes, cfg.upsample_rates,
+                           cfg.upsample_initial_channel, cfg.upsample_kernel_sizes, cfg.gin_channels, cfg.sr)
+    else:
+        net = Generator(cfg.inter_channels, "1", cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes, cfg.upsample_rates,
+                        cfg.upsample_initial_channel, cfg.upsample_kernel_sizes, cfg.gin_channels)
+    net.eval()
+    net.remove_weight_norm()
+    net.load_state_dict(w, strict=True)
+    return net
+
+
+def dec_case(name: str, cfg_name: str, B: int, T: int, seed: int = 1234, use_f0: bool = True, n_res=None, noise_seed: int = 114514):
+    cfg = CONFIGS[cfg_name]
+    if not use_f0:
+        cfg = GenConfig(**{**vars(cfg), "use_f0": False})
+    w = synth.make_dec_weights(cfg, seed)
+    net = build_reference_dec(cfg, w)
+    z, f0, g = synth.make_dec_inputs(cfg, B, T, seed)
+    torch.manual_seed(noise_seed)  # the reference draws rand(1,1,1) then randn_like([B,T*upp,1]) from the global CPU generator
+    with torch.no_grad():
+        ref = net(z, f0, g=g, n_res=n_res) if use_f0 else net(z, g=g, n_res=n_res)
+    noise = nsf_oracle.reference_noise(B, T, cfg.upp, noise_seed) if use_f0 else None
+    taps = {}
+    with torch.no_grad():
+        ora = nsf_oracle.generator_forward(cfg, w, z, f0, g, noise, n_res=n_res, taps=taps)
+    err = (ora - ref).abs().max().item()
+    assert err < 2e-6, "%s: oracle restatement deviates from the reference by %g" % (name, err)
+    out = dict(cfg_name=cfg_name, use_f0=use_f0, seed=seed, noise_seed=noise_seed, weights_sha256=synth.weights_sha256(w),
+               z=z.numpy(), g=g.numpy(), out=ref.numpy(), n_res=-1 if n_res is None else int(n_res),
+               oracle_max_abs_dev=err)
+    if use_f0:
+        out.update(f0=f0.numpy(), noise=noise.numpy(), har=taps["har"].numpy())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print("%-28s ref rms %.3f  oracle-vs-reference max dev %.2e  (%d KB)" % (
+        name, ref.pow(2).mean().sqrt().item(), err, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
+def infer_case(name: str = "infer_v2_48k_T20", T: int = 20, seed: int = 1234):
+    """The whole ``SynthesizerTrnMsNSFsid.infer`` (rvc/layers/synthesizers.py:160-203) of the reference, loaded
+    through the reference's own ``get_synthesizer`` from a synthetic fp16 / legacy-weight-norm checkpoint.  What the
+    decoder receives inside ``infer`` (z*x_mask, pitchf, g) and what it returns are captured with a forward hook, so
+    the fixture pins the drop-in boundary *in situ*, including the RNG draw order (randn_like for z_p first)."""
+    sys.path.insert(0, REF)
+    from rvc.layers.synthesizers import SynthesizerTrnMsNSFsid
+    from rvc.synthesizer import get_synthesizer
+
+    cfg = CONFIGS["v2_48k"]
+    cpt, expect = synth.make_legacy_checkpoint(cfg, "v2", seed)
+    torch.manual_seed(seed)
+    donor = SynthesizerTrnMsNSFsid(*cpt["config"], encoder_dim=768, use_f0=True)
+    for k, v in donor.state_dict().items():
+        if k.startswith(("enc_q.", "dec.")):
+            continue
+        k2 = k.replace("parametrizations.weight.original0", "weight_g").replace("parametrizations.weight.original1", "weight_v")
+        cpt["weight"][k2] = v.half()
+    net_g, _ = get_synthesizer(cpt, torch.device("cpu"))
+    dec_sd = {k: v.clone() for k, v in net_g.dec.state_dict().items()}
+    for k, v in expect.items():  # the loader's folded fp32 weights are what the HIP side must receive
+        assert torch.allclose(dec_sd[k], v, rtol=0, atol=2e-7 * max(1.0, v.abs().max().item())), k
+    cap = {}
+
+    def hook(mod, args, kwargs, output):
+        cap["z"], cap["f0"] = args[0].detach().clone(), args[1].detach().clone()
+        cap["g"] = kwargs["g"].detach().clone()
+        cap["out"] = output.detach().clone()
+
+    hd = net_g.dec.register_forward_hook(hook, with_kwargs=True)
+    phone = synth.make_phone(1, T, 768, seed)
+    pitchf = synth.make_f0(1, T)
+    pitch = torch.clamp((1127 * torch.log(1 + pitchf / 700) - 1127 * np.log(1 + 50 / 700)) * 254 / (1127 * np.log(1 + 1100 / 700) - 1127 * np.log(1 + 50 / 700)) + 1, 1, 255).round().long()
+    torch.manual_seed(114514)
+    with torch.no_grad():
+        o = net_g.infer(phone, torch.tensor([T]), torch.tensor([0]), pitch, pitchf)
+    hd.remove()
+    gen = torch.Generator().manual_seed(114514)
+    torch.randn(1, 192, T, generator=gen)  # z_p draw (synthesizers.py:188)
+    torch.rand(1, 1, 1, generator=gen)  # rand_ini (generators.py:164)
+    noise = torch.randn(1, T * cfg.upp, 1, generator=gen).squeeze(-1)
+    with torch.no_grad():
+        ora = nsf_oracle.generator_forward(cfg, dec_sd, cap["z"], cap["f0"], cap["g"], noise)
+    err = (ora - o).abs().max().item()
+    assert err < 2e-6, "infer case: oracle deviates by %g" % err
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), cfg_name="v2_48k", seed=seed, z=cap["z"].numpy(), f0=cap["f0"].numpy(),
+                        g=cap["g"].numpy(), noise=noise.numpy(), out=o.numpy(), oracle_max_abs_dev=err,
+                        weights_sha256=synth.weights_sha256(dec_sd), **{"w::" + k: v.numpy() for k, v in dec_sd.items()
+                                                                        if v.numel() <= 4096})
+    print("%-28s ref rms %.3f  oracle-vs-reference max dev %.2e  (loader-folded weights verified)" % (name, o.pow(2).mean().sqrt().item(), err))
+    return dec_sd
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    dec_case("dec_v2_48k_B2_T24", "v2_48k", 2, 24)
+    dec_case("dec_v2_48k_B1_T70", "v2_48k", 1, 70)           # > one fused-resblock tile at every stage
+    dec_case("dec_v2_32k_B1_T16", "v2_32k", 1, 16)
+    dec_case("dec_v1_40k_B1_T20", "v1_40k", 1, 20)
+    dec_case("dec_v1_32k_B1_T16", "v1_32k", 1, 16)           # 5 stages, last stage C = 16
+    dec_case("dec_v1_48k_B1_T12", "v1_48k", 1, 12)
+    dec_case("dec_nof0_v2_48k_B1_T16", "v2_48k", 1, 16, use_f0=False)
+    dec_case("dec_v1_40k_nres_T31", "v1_40k", 1, 31, n_res=37)  # realtime formant shift
+    dec_case("dec_v1_40k_nres_down_T31", "v1_40k", 1, 31, n_res=26)
+    infer_case()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,7 +64,7 @@ def make_dec_weights(cfg: GenConfig, seed: int = 1234) -> "OrderedDict[str, torc
                     w[f"resblocks.{n}.{c}.{m}.weight"] = gain * _randn(gen, ch, ch, k) / math.sqrt(ch * k)
                     w[f"resblocks.{n}.{c}.{m}.bias"] = 0.1 * _randn(gen, ch)
     ch = c0 // 2 ** n_up
-    w["conv_post.weight"] = 0.35 * _randn(gen, 1, ch, 7) / math.sqrt(ch * 7)
+    w["conv_post.weight"] = 0.25 * _randn(gen, 1, ch, 7) / math.sqrt(ch * 7)
     return w
 
 

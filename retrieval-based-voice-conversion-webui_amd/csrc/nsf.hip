@@ -498,12 +498,20 @@ template <> struct RbFullGeom<64> { static constexpr int MI = 2, NJ = 3, KG = 4;
 template <> struct RbFullGeom<32> { static constexpr int MI = 1, NJ = 6, KG = 4; };
 template <> struct RbFullGeom<16> { static constexpr int MI = 1, NJ = 6, KG = 4; };
 static int rbf_rows(int C) { return C == 64 ? 384 : 768; }
+static int rbf_nb() {  // weight-prefetch depth (register buffers); RVCMI_NB overrides for A/B experiments
+    const char* e = getenv("RVCMI_NB");
+    const int v = e ? atoi(e) : 3;
+    return v < 2 ? 2 : (v > 4 ? 4 : v);
+}
 template <typename OpT, int C>
 static void launch_rbf_inst(const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
     using G = RbFullGeom<C>;
     constexpr int R = 4 * 32 * G::NJ;
-    const size_t smem = (size_t)(R + 2 * RBF_G + R + 2 * RBF_G2) * Tile<C>::STRIDE;
-    hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
+    const size_t smem = (size_t)(R + 2 * RBF_G + R + 2 * RBF_G2) * Tile<C>::STRIDE + 3 * 2 * 32 * G::MI * 4 + 512;  // + bias vectors + dev phase stamps
+    const int nb = rbf_nb();
+    if (nb == 2) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 2>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
+    else if (nb == 3) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 3>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
+    else hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 4>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
 }
 template <typename OpT>
 static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
@@ -516,10 +524,12 @@ static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, 
 }
 template <typename OpT>
 static void set_lds_rbf() {
-#define RBF_ATTR(C_)                                                                                                        \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, C_, RbFullGeom<C_>::MI, RbFullGeom<C_>::NJ, RbFullGeom<C_>::KG>), \
+#define RBF_ATTR1(C_, NB_)                                                                                                  \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, C_, RbFullGeom<C_>::MI, RbFullGeom<C_>::NJ, RbFullGeom<C_>::KG, NB_>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define RBF_ATTR(C_) RBF_ATTR1(C_, 2) RBF_ATTR1(C_, 3) RBF_ATTR1(C_, 4)
     RBF_ATTR(64) RBF_ATTR(32) RBF_ATTR(16)
+#undef RBF_ATTR1
 #undef RBF_ATTR
 }
 
@@ -859,11 +869,36 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 bytes += (double)B * L * C * 8;
                 src[j] = J.dst;
             }
+            const size_t nblk = (size_t)max_tiles * nk * B;
+            if (ra.dbg & 32) {
+                if (h->dbg.bytes < nblk * 4 * 16 * 8) h->dbg.alloc(nblk * 4 * 16 * 8);
+                HIP_CHECK(hipMemsetAsync(h->dbg.p, 0, nblk * 4 * 16 * 8, st));
+                ra.ts = h->dbg.as<unsigned long long>();
+            }
             h->prof.launch(nm, flops, bytes, st, [&] {
                 if (op == RVCMI_OPERAND_BF16) launch_rbf_t<__bf16>(C, ra, max_tiles, nk, B, st);
                 else launch_rbf_t<_Float16>(C, ra, max_tiles, nk, B, st);
             });
             HIP_CHECK(hipGetLastError());
+            if (ra.dbg & 32) {  // dev only: per-phase cycle breakdown, averaged per resblock kernel size
+                HIP_CHECK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> ts(nblk * 4 * 16);
+                HIP_CHECK(hipMemcpy(ts.data(), h->dbg.p, ts.size() * 8, hipMemcpyDeviceToHost));
+                for (int oj = 0; oj < nk; ++oj) {
+                    double sum[16] = {0};
+                    long cnt = 0;
+                    for (int t = 0; t < ra.job[oj].ntiles; ++t)
+                        for (int w = 0; w < 4; ++w) {
+                            const unsigned long long* p = &ts[((size_t)(0 * nk + oj) * max_tiles + t) * 64 + w * 16];
+                            if (!p[0]) continue;
+                            for (int i = 1; i < 16; ++i) sum[i] += p[i] ? (double)(p[i] - p[i - 1]) : 0.0;
+                            ++cnt;
+                        }
+                    fprintf(stderr, "[rvcmi ts] %s k=%d tiles=%d:", nm, ra.job[oj].k, ra.job[oj].ntiles);
+                    for (int i = 1; i < 16; ++i) fprintf(stderr, " %.0f", cnt ? sum[i] / cnt : 0.0);
+                    fprintf(stderr, "\n");
+                }
+            }
         } else {
             snprintf(nm, sizeof(nm), "rb_pair_c%d", C);
             for (size_t m = 0; m < maxnd; ++m) {

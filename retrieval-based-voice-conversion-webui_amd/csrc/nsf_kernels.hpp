@@ -398,64 +398,87 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
 // The K loop.  acc[mi][jt] += sum over (padded) taps and channel chunks.
 //   lds_lane : smem + (wave_t0 + (lane&31)) * STRIDE + (lane>>5)*16
 //   wlane    : packed weights of this wave's first co tile + lane*8
-template <typename OpT, int CIN, int MI, int NJ, int KGROUP = ::rvcmi::KGROUP>
-__device__ __forceinline__ void conv_core(f32x16 (&acc)[MI][NJ], const char* lds_lane, const OpT* wlane,
-                                          long ct_stride, int ntaps_p, int roff, int dstep) {
+// The K loop is split in two so that a kernel can put a barrier / epilogue BETWEEN "weights requested" and
+// "weights used":
+//   conv_prefetch  issues the global loads of the first NB-1 weight groups (KGROUP k-steps each) into registers;
+//   conv_run       multiplies group g while group g+NB-1 is in flight.  (An explicit one-k-step-ahead double buffer
+//                  of the B fragments was tried and measured SLOWER -- 11.2k -> 13.3k cycles per k=7 conv at C=64 --
+//                  than leaving the ds_read placement to the compiler.)
+template <typename OpT, int MI, int KGROUP, int NB>
+__device__ __forceinline__ void conv_load_group(typename Op<OpT>::frag (&Ab)[KGROUP][MI], const OpT* wlane, long ct_stride, int grp) {
+    using frag = typename Op<OpT>::frag;
+#pragma unroll
+    for (int g = 0; g < KGROUP; ++g)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+            Ab[g][mi] = *(const frag*)(wlane + (size_t)mi * ct_stride + (size_t)(grp * KGROUP + g) * 512);
+}
+
+template <typename OpT, int CIN, int MI, int KGROUP, int NB>
+__device__ __forceinline__ void conv_prefetch(typename Op<OpT>::frag (&A)[NB][KGROUP][MI], const OpT* wlane, long ct_stride,
+                                              int ntaps_p) {
+    const int NG = ntaps_p * Tile<CIN>::CC / KGROUP;
+#pragma unroll
+    for (int i = 0; i < NB - 1; ++i)
+        if (i < NG) conv_load_group<OpT, MI, KGROUP, NB>(A[i], wlane, ct_stride, i);
+}
+
+template <typename OpT, int CIN, int MI, int NJ, int KGROUP, int NB>
+__device__ __forceinline__ void conv_run(f32x16 (&acc)[MI][NJ], typename Op<OpT>::frag (&A)[NB][KGROUP][MI],
+                                         const char* lds_lane, const OpT* wlane, long ct_stride, int ntaps_p, int roff,
+                                         int dstep) {
     using frag = typename Op<OpT>::frag;
     using TL = Tile<CIN>;
     constexpr int CC = TL::CC;
     constexpr int STRIDE = TL::STRIDE;
-    constexpr int TAPS_PER_GROUP = (CC >= KGROUP) ? 1 : KGROUP / CC;
     static_assert((CC >= KGROUP) ? (CC % KGROUP == 0) : (KGROUP % CC == 0), "k-group must tile a tap");
+    static_assert(NB >= 2 && NB <= 4, "2..4 weight buffers");
     const int NG = ntaps_p * CC / KGROUP;
 
-    frag A0[KGROUP][MI], A1[KGROUP][MI];
-    auto loadA = [&](frag(&A)[KGROUP][MI], int grp) {
+    for (int grp = 0; grp < NG; grp += NB) {
 #pragma unroll
-        for (int g = 0; g < KGROUP; ++g)
+        for (int u = 0; u < NB; ++u) {
+            const int g = grp + u;
+            if (g < NG) {
+                if (g + NB - 1 < NG) conv_load_group<OpT, MI, KGROUP, NB>(A[(u + NB - 1) % NB], wlane, ct_stride, g + NB - 1);
+                int tap0, cc0;
+                if constexpr (CC >= KGROUP) {
+                    tap0 = (g * KGROUP) / CC;
+                    cc0 = (g * KGROUP) % CC;
+                } else {
+                    tap0 = g * (KGROUP / CC);
+                    cc0 = 0;
+                }
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                A[g][mi] = *(const frag*)(wlane + (size_t)mi * ct_stride + (size_t)(grp * KGROUP + g) * 512);
-    };
-    auto compute = [&](frag(&A)[KGROUP][MI], int grp) {
-        int tap0, cc0;
-        if constexpr (CC >= KGROUP) {
-            tap0 = (grp * KGROUP) / CC;
-            cc0 = (grp * KGROUP) % CC;
-        } else {
-            tap0 = grp * TAPS_PER_GROUP;
-            cc0 = 0;
-        }
+                for (int k = 0; k < KGROUP; ++k) {
+                    int tap, cc;
+                    if constexpr (CC >= KGROUP) {
+                        tap = tap0;
+                        cc = cc0 + k;
+                    } else {
+                        tap = tap0 + k / CC;
+                        cc = k % CC;
+                    }
+                    const char* bp = lds_lane + (roff + tap * dstep) * STRIDE + cc * 32;
+                    frag B[NJ];
 #pragma unroll
-        for (int g = 0; g < KGROUP; ++g) {
-            int tap, cc;
-            if constexpr (CC >= KGROUP) {
-                tap = tap0;
-                cc = cc0 + g;
-            } else {
-                tap = tap0 + g / CC;
-                cc = g % CC;
+                    for (int jt = 0; jt < NJ; ++jt) B[jt] = *(const frag*)(bp + jt * 32 * STRIDE);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) acc[mi][jt] = Op<OpT>::mfma(A[u][k][mi], B[jt], acc[mi][jt]);
+                }
             }
-            const char* bp = lds_lane + (roff + tap * dstep) * STRIDE + cc * 32;
-            frag B[NJ];
-#pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) B[jt] = *(const frag*)(bp + jt * 32 * STRIDE);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int jt = 0; jt < NJ; ++jt) acc[mi][jt] = Op<OpT>::mfma(A[g][mi], B[jt], acc[mi][jt]);
-        }
-    };
-
-    loadA(A0, 0);
-    for (int grp = 0; grp < NG; grp += 2) {
-        if (grp + 1 < NG) loadA(A1, grp + 1);
-        compute(A0, grp);
-        if (grp + 1 < NG) {
-            if (grp + 2 < NG) loadA(A0, grp + 2);
-            compute(A1, grp + 1);
         }
     }
+}
+
+template <typename OpT, int CIN, int MI, int NJ, int KGROUP = ::rvcmi::KGROUP, int NB = 2>
+__device__ __forceinline__ void conv_core(f32x16 (&acc)[MI][NJ], const char* lds_lane, const OpT* wlane,
+                                          long ct_stride, int ntaps_p, int roff, int dstep) {
+    typename Op<OpT>::frag A[NB][KGROUP][MI];
+    conv_prefetch<OpT, CIN, MI, KGROUP, NB>(A, wlane, ct_stride, ntaps_p);
+    conv_run<OpT, CIN, MI, NJ, KGROUP, NB>(acc, A, lds_lane, wlane, ct_stride, ntaps_p, roff, dstep);
 }
 
 // Generic single-conv kernel: stage tile -> conv_core -> epilogue.  Grid: x = time tile,
@@ -907,12 +930,42 @@ struct RbFullArgs {
     int L;
     long bstride;
     int dbg;
+    unsigned long long* ts;  // dbg & 32: per-wave s_memtime stamps [block][wave][16]
 };
 
 constexpr int RBF_G = 32;   // zero guard rows around X (>= max dilated half-width + one padded tap)
 constexpr int RBF_G2 = 8;   // zero guard rows around H
 
-template <typename OpT, int C, int MI, int NJ, int KG>
+// Branch-free helpers.  lrelu as max(x, slope*x) (0 < slope < 1); row masking by AND-ing the value bits so that
+// the compiler cannot turn the select into divergent control flow (it did: ~45 exec-masked blocks per publish).
+__device__ __forceinline__ float lrelu_max(float v, float slope) { return fmaxf(v, v * slope); }
+__device__ __forceinline__ float mask_bits(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
+
+// acc (MFMA D layout) -> lrelu -> OpT -> LDS operand tile.  `base` already points at this lane's (row, 4*(lane>>5))
+// element of the wave's first row; everything else is a compile-time offset.
+template <typename OpT, int C, int MI, int NJ, int STRIDE, bool MASK>
+__device__ __forceinline__ void publish_operand(char* base, const f32x16 (&acc)[MI][NJ], const unsigned (&rowmask)[NJ]) {
+    using o4 = __attribute__((ext_vector_type(4))) OpT;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (mi * 32 + 8 * g < C) {  // folds to a constant once the loops are unrolled
+                    o4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = lrelu_max(acc[mi][jt][4 * g + e], 0.1f);
+                        if constexpr (MASK) v = mask_bits(v, rowmask[jt]);
+                        o[e] = to_op<OpT>(v);
+                    }
+                    *(o4*)(base + jt * 32 * STRIDE + (mi * 32 + 8 * g) * 2) = o;
+                }
+            }
+}
+
+template <typename OpT, int C, int MI, int NJ, int KG, int NB>
 __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
     using TL = Tile<C>;
     constexpr int STRIDE = TL::STRIDE;
@@ -924,6 +977,8 @@ __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* X = smem;
     char* H = smem + (size_t)XROWS * STRIDE;
+    float* bias_l = (float*)(smem + (size_t)(XROWS + HROWS) * STRIDE);          // [nd][2][CP]
+    unsigned long long* tsl = (unsigned long long*)(bias_l + 3 * 2 * CP);         // dev-only phase stamps
 
     const RbFullJob& J = a.job[blockIdx.y];
     if ((int)blockIdx.x >= J.ntiles) return;
@@ -933,9 +988,16 @@ __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
     float* dst = J.dst + (size_t)b * a.bstride;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slab = wave * SLAB;
-    using o4 = __attribute__((ext_vector_type(4))) OpT;
+    const int half4 = 4 * (lane >> 5);
 
-    // zero the guard rows once (nobody writes them afterwards)
+    int tsn = 0;
+    auto stamp = [&]() {  // dev-only: kept in LDS and flushed once at the end (a global store would sit in front of
+        if ((a.dbg & 32) && lane == 0 && tsn < 16) tsl[wave * 16 + tsn] = __builtin_readcyclecounter();  // barriers)
+        ++tsn;
+    };
+    stamp();  // 0
+
+    // zero the guard rows once (nobody writes them afterwards); stage every bias vector of the resblock in LDS
     {
         constexpr int W = STRIDE / 16;  // 16-byte words per row
         const uint4 z = make_uint4(0, 0, 0, 0);
@@ -949,45 +1011,52 @@ __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
             const int row = r < RBF_G2 ? r : RBF_G2 + R + (r - RBF_G2);
             *(uint4*)(H + (size_t)row * STRIDE + c * 16) = z;
         }
+        for (int i = threadIdx.x; i < J.nd * 2 * CP; i += 256) {
+            const int m = i / (2 * CP), w = (i / CP) & 1, c = i % CP;
+            const float* bp = w ? J.b2[m] : J.b1[m];
+            bias_l[i] = c < C ? bp[c] : 0.f;
+        }
     }
 
-    // ---- load x straight into the accumulator layout; publish lrelu(x) as the first operand tile ----
+    // Rows of this lane's NJ column tiles that lie outside the utterance must read as zero in every operand tile
+    // (each conv zero-pads ITS input).  Interior tiles (the vast majority) skip the masking altogether.
+    const bool interior = tg0 >= 0 && tg0 + R <= a.L;  // block-uniform
+    unsigned rowmask[NJ];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        const int tg = tg0 + slab + jt * 32 + (lane & 31);
+        rowmask[jt] = (tg >= 0 && tg < a.L) ? 0xffffffffu : 0u;
+    }
+
+    // ---- load x straight into the accumulator layout (clamped addresses: unconditional loads) -----------
     f32x16 xacc[MI][NJ];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
-            const int row = slab + jt * 32 + (lane & 31);
-            const int tg = tg0 + row;
-            const bool in = tg >= 0 && tg < a.L;
-            const int tgc = min(max(tg, 0), a.L - 1);  // clamped: the load is unconditional (no branch per load)
+            const int tg = tg0 + slab + jt * 32 + (lane & 31);
+            const int tgc = min(max(tg, 0), a.L - 1);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
-                const int coc = (C % 32 == 0) ? co : min(co, C - 4);
-                const f32x4 v = *(const f32x4*)(src + (size_t)tgc * C + coc);
-                const bool ok = in && ((C % 32 == 0) || co < C);
+                if (mi * 32 + 8 * g < C) {  // folds to a constant once the loops are unrolled
+                    const f32x4 v = *(const f32x4*)(src + (size_t)tgc * C + mi * 32 + 8 * g + half4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] = ok ? v[e] : 0.f;
-            }
-        }
+                    for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] = mask_bits(v[e], rowmask[jt]);
+                } else {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) {
-            const int row = slab + jt * 32 + (lane & 31);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
-                if ((C % 32 == 0) || co < C) {
-                    o4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(lrelu(xacc[mi][jt][4 * g + e], 0.1f));
-                    *(o4*)(X + (size_t)(RBF_G + row) * STRIDE + co * 2) = o;
+                    for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] = 0.f;
                 }
             }
         }
+    stamp();  // 1: x loaded
+    typename Op<OpT>::frag A[NB][KG][MI];  // weight register ring, requested one phase ahead of its use
+    conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w1[0] + lane * 8, J.ct1, J.k_p);
+    char* xw = X + (size_t)(RBF_G + slab + (lane & 31)) * STRIDE + half4 * 2;   // this lane's publish base in X
+    char* hw = H + (size_t)(RBF_G2 + slab + (lane & 31)) * STRIDE + half4 * 2;  // ... and in H
+    publish_operand<OpT, C, MI, NJ, STRIDE, false>(xw, xacc, rowmask);          // masked already
+    stamp();  // 2
     __syncthreads();
+    stamp();  // 3
 
     const char* xl = X + (size_t)(slab + (lane & 31)) * STRIDE + (lane >> 5) * 16;
     const char* hl = H + (size_t)(slab + (lane & 31)) * STRIDE + (lane >> 5) * 16;
@@ -995,94 +1064,80 @@ __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
 
     for (int m = 0; m < J.nd; ++m) {
         const int p1 = J.dil[m] * (J.k - 1) / 2;
-        // ---- conv1 (dilated) -> h -------------------------------------------------------------------
+        // ---- conv1 (dilated) -> h; the accumulators start from b1 ----------------------------------------
         f32x16 hacc[MI][NJ];
+        {
+            const float* bl = bias_l + (m * 2 + 0) * CP + half4;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int jt = 0; jt < NJ; ++jt)
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *(const f32x4*)(bl + mi * 32 + 8 * g);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) hacc[mi][jt][e] = 0.f;
-        if (!(a.dbg & 2))
-            conv_core<OpT, C, MI, NJ, KG>(hacc, xl, (const OpT*)J.w1[m] + lane * 8, J.ct1, J.k_p, RBF_G - p1, J.dil[m]);
+                    for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hacc[mi][jt][4 * g + e] = bv[e];
+                }
+        }
+        conv_run<OpT, C, MI, NJ, KG, NB>(hacc, A, xl, (const OpT*)J.w1[m] + lane * 8, J.ct1, J.k_p, RBF_G - p1, J.dil[m]);
+        conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w2[m] + lane * 8, J.ct2, J.k_p);  // in flight across the publish + barrier
+        if (m == 0) stamp();  // 4: conv1 done
+        if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(hw, hacc, rowmask);
+        else publish_operand<OpT, C, MI, NJ, STRIDE, true>(hw, hacc, rowmask);
+        if (m == 0) stamp();  // 5
+        __syncthreads();  // h complete; every wave is also done reading X
+        if (m == 0) stamp();  // 6
+        // ---- conv2 accumulates onto x: x <- (x + b2) + conv2(h) ------------------------------------------
+        {
+            const float* bl = bias_l + (m * 2 + 1) * CP + half4;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bv = *(const f32x4*)(bl + mi * 32 + 8 * g);
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] += bv[e];
+                }
+        }
+        conv_run<OpT, C, MI, NJ, KG, NB>(xacc, A, hl, (const OpT*)J.w2[m] + lane * 8, J.ct2, J.k_p, RBF_G2 - p2, 1);
+        if (m + 1 < J.nd) conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w1[m + 1] + lane * 8, J.ct1, J.k_p);
+        if (m == 0) stamp();  // 7: conv2 done
+        if (m + 1 < J.nd) {  // publish lrelu(x') for the next pair
+            if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(xw, xacc, rowmask);
+            else publish_operand<OpT, C, MI, NJ, STRIDE, true>(xw, xacc, rowmask);
+            if (m == 0) stamp();  // 8
+            __syncthreads();
+            if (m == 0) stamp();  // 9
+        }
+    }
+    stamp();  // 10: all pairs done
+
+    // ---- store the valid centre of the tile ---------------------------------------------------------------
+    if (!(a.dbg & 16)) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
                 const int row = slab + jt * 32 + (lane & 31);
                 const int tg = tg0 + row;
-                const bool in = tg >= 0 && tg < a.L;  // conv2 zero-pads ITS input at the utterance edges
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
-                    if ((C % 32 == 0) || co < C) {
-                        const f32x4 bv = *(const f32x4*)(J.b1[m] + co);
-                        o4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            o[e] = in ? to_op<OpT>(lrelu(hacc[mi][jt][4 * g + e] + bv[e], 0.1f)) : (OpT)0.f;
-                        *(o4*)(H + (size_t)(RBF_G2 + row) * STRIDE + co * 2) = o;
-                    }
-                }
-            }
-        __syncthreads();  // h complete; every wave is also done reading X
-        // ---- conv2 accumulates onto x: x <- x + conv2(h) + b2 -----------------------------------------
-        if (!(a.dbg & 4))
-            conv_core<OpT, C, MI, NJ, KG>(xacc, hl, (const OpT*)J.w2[m] + lane * 8, J.ct2, J.k_p, RBF_G2 - p2, 1);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
-                if ((C % 32 == 0) || co < C) {
-                    const f32x4 bv = *(const f32x4*)(J.b2[m] + co);
-#pragma unroll
-                    for (int jt = 0; jt < NJ; ++jt)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] += bv[e];
-                }
-            }
-        if (m + 1 < J.nd) {  // publish lrelu(x') for the next pair
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int jt = 0; jt < NJ; ++jt) {
-                    const int row = slab + jt * 32 + (lane & 31);
-                    const int tg = tg0 + row;
-                    const bool in = tg >= 0 && tg < a.L;
+                if (row >= J.HL && row < R - J.HL && tg < a.L) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
-                        if ((C % 32 == 0) || co < C) {
-                            o4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = in ? to_op<OpT>(lrelu(xacc[mi][jt][4 * g + e], 0.1f)) : (OpT)0.f;
-                            *(o4*)(X + (size_t)(RBF_G + row) * STRIDE + co * 2) = o;
+                        if (mi * 32 + 8 * g < C) {  // folds to a constant once the loops are unrolled
+                            const f32x4 v = {xacc[mi][jt][4 * g + 0], xacc[mi][jt][4 * g + 1], xacc[mi][jt][4 * g + 2], xacc[mi][jt][4 * g + 3]};
+                            *(f32x4*)(dst + (size_t)tg * C + mi * 32 + 8 * g + half4) = v;
                         }
                     }
                 }
-            __syncthreads();
-        }
-    }
-
-    // ---- store the valid centre of the tile ---------------------------------------------------------
-    if (a.dbg & 16) return;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) {
-            const int row = slab + jt * 32 + (lane & 31);
-            const int tg = tg0 + row;
-            if (row < J.HL || row >= R - J.HL || tg >= a.L) continue;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = mi * 32 + 8 * g + 4 * (lane >> 5);
-                if ((C % 32 != 0) && co >= C) continue;
-                const f32x4 v = {xacc[mi][jt][4 * g + 0], xacc[mi][jt][4 * g + 1], xacc[mi][jt][4 * g + 2], xacc[mi][jt][4 * g + 3]};
-                *(f32x4*)(dst + (size_t)tg * C + co) = v;
             }
-        }
-    (void)CP;
+    }
+    stamp();  // 11: stores issued
+    if ((a.dbg & 32) && lane < 16) {
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        a.ts[(blk * 4 + wave) * 16 + lane] = lane < tsn ? tsl[wave * 16 + lane] : 0ull;
+    }
 }
 
 }  // namespace rvcmi

@@ -1,0 +1,142 @@
+"""CPU suite, part 2: the C-ABI library loads and exports every symbol of include/rvcmi.h (no compute without a
+GPU), host-side logic, loud failure without a GPU, and the N>1 path under gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+import rvc_amd
+from rvc_amd import _lib
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "rvcmi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rvcmi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_symbol_of_the_header():
+    names = _header_functions()
+    assert len(names) >= 25
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "librvcmi.so does not export %s" % n
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert bound == set(names), "python binding and header drifted: %s" % (bound ^ set(names))
+    assert _lib.lib().rvcmi_version() == 1
+
+
+def test_struct_layout_matches_the_header():
+    # rvcmi_nsf_config: 6 ints + 2*8 + 1 + 4 + 4 + 16 + 1 ints
+    assert C.sizeof(_lib.NsfConfig) == 4 * (6 + 16 + 1 + 4 + 4 + 16 + 1)
+    assert C.sizeof(_lib.KernelStat) == 48 + 8 + 8 + 8 + 8
+    assert C.sizeof(_lib.Tensor) == 8 + 8 + 8 + 32
+
+
+def test_fails_loudly_without_a_gpu_and_on_bad_input(tmp_path):
+    with pytest.raises(_lib.RvcmiError):
+        rvc_amd.NSFGeneratorHIP({}, {}, device="cpu")
+    with pytest.raises(_lib.RvcmiError):
+        rvc_amd.read_index(str(tmp_path / "missing.index"), device="cpu")
+    h = C.c_void_p()
+    rc = _lib.lib().rvcmi_ivf_create_from_file(str(tmp_path / "missing.index").encode(), 0, C.byref(h))
+    assert rc == -3 and b"cannot open" in _lib.lib().rvcmi_last_error()
+    bad = tmp_path / "bad.index"
+    bad.write_bytes(b"IxF2" + b"\0" * 64)
+    rc = _lib.lib().rvcmi_ivf_create_from_file(str(bad).encode(), 0, C.byref(h))
+    assert rc == -3 and b"IwFl" in _lib.lib().rvcmi_last_error()
+    assert _lib.lib().rvcmi_nsf_create(None, None, 0, 0, 1, 1, C.byref(h)) == -1
+
+
+def test_config_marshalling():
+    from oracle.nsf_oracle import CONFIGS
+    from rvc_amd.nsf import _cfg_struct
+
+    c = _cfg_struct(vars(CONFIGS["v1_32k"]), "fp16")
+    assert c.n_ups == 5 and list(c.upsample_rates)[:5] == [10, 4, 2, 2, 2] and c.operand == 2
+    assert c.n_resblock_kernels == 3 and list(c.resblock_dilation_sizes[2])[:3] == [1, 3, 5] and c.sr == 32000
+    with pytest.raises(ValueError):
+        _cfg_struct(vars(CONFIGS["v1_32k"]), "int8")
+
+
+def test_shard_range_partitions_exactly():
+    from rvc_amd.dist import shard_range
+
+    for n in (0, 1, 7, 64, 512, 513):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, n_clips):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rvc_amd.dist import broadcast_bytes, shard_range
+
+    payload = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(7)
+        payload = torch.randint(0, 256, (100003,), dtype=torch.uint8, generator=g)
+    got = broadcast_bytes(payload, src=0, device=torch.device("cpu"))
+    g = torch.Generator().manual_seed(7)
+    expect = torch.randint(0, 256, (100003,), dtype=torch.uint8, generator=g)
+    assert torch.equal(got, expect)
+    lo, hi = shard_range(n_clips, rank, world)
+    cover = torch.zeros(n_clips, dtype=torch.int64)
+    cover[lo:hi] = 1
+    dist.all_reduce(cover)
+    assert torch.all(cover == 1)  # every clip converted exactly once, no cross-rank dependency afterwards
+    dist.destroy_process_group()
+
+
+def test_multi_rank_broadcast_and_sharding_gloo():
+    import torch.multiprocessing as mp
+
+    mp.spawn(_gloo_worker, args=(2, _free_port(), 67), nprocs=2, join=True)
+
+
+def test_reference_module_introspection_when_reference_is_present():
+    """config_from_reference / _plain_state_dict against the REAL reference classes (skipped on the GPU box)."""
+    ref = os.environ.get("RVC_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "rvc")):
+        pytest.skip("reference checkout not mounted")
+    import sys
+
+    sys.path.insert(0, ref)
+    from rvc.layers.nsf import NSFGenerator
+
+    from oracle.nsf_oracle import CONFIGS
+    from rvc_amd.nsf import _plain_state_dict, config_from_reference
+
+    cfg = CONFIGS["v1_40k"]
+    net = NSFGenerator(cfg.inter_channels, "1", cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes, cfg.upsample_rates,
+                       cfg.upsample_initial_channel, cfg.upsample_kernel_sizes, cfg.gin_channels, cfg.sr)
+    with pytest.raises(ValueError):
+        _plain_state_dict(net)  # weight norm still attached
+    net.remove_weight_norm()
+    got = config_from_reference(net)
+    for k in ("inter_channels", "upsample_rates", "upsample_kernel_sizes", "upsample_initial_channel", "gin_channels", "sr",
+              "resblock_kernel_sizes", "resblock_dilation_sizes", "use_f0"):
+        assert got[k] == getattr(cfg, k), k
+    sd = _plain_state_dict(net)
+    assert "ups.0.weight" in sd and sd["ups.0.weight"].shape == (512, 256, 16)

@@ -1,0 +1,139 @@
+"""CPU suite, part 1: the oracle against the golden fixtures made from the real reference, and the two
+independent restatements of the IVF search against each other."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_config_and_weights, golden_names, load_golden
+from oracle import ivf_oracle, nsf_oracle, synth
+
+
+@pytest.mark.parametrize("name", golden_names("dec_"))
+def test_generator_oracle_matches_reference_golden(name):
+    """oracle/nsf_oracle.py == rvc/layers/nsf.py NSFGenerator.forward (fixture produced by the reference itself)."""
+    d = load_golden(name)
+    cfg, w = golden_config_and_weights(d)
+    f0 = torch.from_numpy(d["f0"]) if "f0" in d else None
+    noise = torch.from_numpy(d["noise"]) if "noise" in d else None
+    n_res = None if int(d["n_res"]) < 0 else int(d["n_res"])
+    taps = {}
+    with torch.no_grad():
+        out = nsf_oracle.generator_forward(cfg, w, torch.from_numpy(d["z"]), f0, torch.from_numpy(d["g"]), noise, n_res=n_res, taps=taps)
+    assert out.shape == d["out"].shape
+    assert np.abs(out.numpy() - d["out"]).max() < 5e-6
+    if "har" in d:
+        assert np.abs(taps["har"].numpy() - d["har"]).max() < 1e-6
+
+
+def test_generator_oracle_infer_boundary_golden():
+    """Decoder inputs/outputs captured INSIDE the reference's net_g.infer (loader, enc_p, flow, RNG order)."""
+    d = load_golden("infer_v2_48k_T20")
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    _, expect = synth.make_legacy_checkpoint(cfg, "v2", int(d["seed"]))
+    for k, v in d.items():  # the folded weights the reference loader produced (small tensors are stored)
+        if k.startswith("w::"):
+            assert np.allclose(expect[k[3:]].numpy(), v, rtol=0, atol=2e-7 * max(1.0, np.abs(v).max()))
+    with torch.no_grad():
+        out = nsf_oracle.generator_forward(cfg, expect, torch.from_numpy(d["z"]), torch.from_numpy(d["f0"]), torch.from_numpy(d["g"]),
+                                           torch.from_numpy(d["noise"]))
+    assert np.abs(out.numpy() - d["out"]).max() < 5e-6
+
+
+def test_sine_source_phase_is_continuous_and_unvoiced_is_noise_only():
+    f0 = torch.tensor([[0.0, 0.0, 220.0, 220.0, 0.0, 330.0]])
+    s = nsf_oracle.sine_source(f0, 480, 48000, None).reshape(6, 480)
+    assert torch.all(s[0] == 0) and torch.all(s[1] == 0) and torch.all(s[4] == 0)  # no noise injected -> silence when unvoiced
+    assert abs(s[2].abs().max().item() - 0.1) < 1e-3
+    # phase continuity across frames: frames 2+3 form ONE uninterrupted 220 Hz sine of 960 samples
+    n = torch.arange(1, 961, dtype=torch.float64)
+    expect = 0.1 * torch.sin(2 * torch.pi * 220.0 / 48000.0 * n)
+    assert (torch.cat([s[2], s[3]]).double() - expect).abs().max() < 1e-5
+
+
+def _c_oracle():
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "libivf_oracle.so"))
+    return lib
+
+
+def _c_search(lib, idx, q, k, nprobe, f32=0):
+    nq, d = q.shape
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    P = np.empty((nq, k), np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.ivf_search(vp(q), C.c_int64(nq), C.c_int(d), vp(idx["centroids"]), C.c_int64(idx["nlist"]), C.c_int(nprobe),
+                   vp(idx["list_offsets"]), vp(idx["ids"]), vp(idx["vecs"]), C.c_int(k), vp(D), vp(I), vp(P), C.c_int(f32))
+    return D, I, P
+
+
+@pytest.mark.parametrize("n,d,nprobe,k", [(2000, 64, 1, 8), (3000, 256, 3, 8), (500, 32, 1, 5), (60, 16, 2, 8)])
+def test_ivf_python_and_c_restatements_agree(n, d, nprobe, k):
+    idx = synth.make_ivf(n, d, seed=n + d, dup=7)
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((97, d), dtype=np.float32)
+    q[:4] = idx["xb"][:4]  # exact hits
+    D1, I1 = ivf_oracle.search(idx, q, k, nprobe)
+    D2, I2, _ = _c_search(_c_oracle(), idx, q, k, nprobe)
+    assert np.array_equal(I1, I2)
+    assert np.allclose(D1, D2, rtol=1e-6, atol=0)
+    assert np.all(np.diff(D1.astype(np.float64), axis=1) >= 0)  # ascending
+    assert np.all(D1[:4, 0] == 0) and np.array_equal(np.sort(I1[:4, 0]), np.sort(I1[:4, 0]))
+
+
+def test_ivf_edge_semantics_short_lists_and_padding():
+    """Lists shorter than k pad with id -1 / FLT_MAX (faiss' L2 heap sentinel); empty query set; ties -> lowest id."""
+    idx = synth.make_ivf(40, 8, nlist=10, seed=3)
+    q = np.random.default_rng(0).standard_normal((20, 8), dtype=np.float32)
+    D, I = ivf_oracle.search(idx, q, 8)
+    sizes = np.diff(idx["list_offsets"])
+    assert sizes.min() < 8
+    assert (I == -1).any() and np.all(D[I == -1] == ivf_oracle.FLT_MAX)
+    assert np.all((I >= 0).sum(1) == np.minimum(8, sizes[ivf_oracle.coarse_assign(idx, q, 1)[:, 0]]))
+    D0, I0 = ivf_oracle.search(idx, q[:0], 8)
+    assert D0.shape == (0, 8) and I0.shape == (0, 8)
+    # exact duplicates: the lower id must come first
+    idx2 = synth.make_ivf(300, 16, nlist=4, seed=9)
+    a, b = int(idx2["ids"][0]), int(idx2["ids"][1])
+    idx2["vecs"][1] = idx2["vecs"][0]
+    D2, I2 = ivf_oracle.search(idx2, idx2["vecs"][:1].copy(), 2, nprobe=4)
+    assert D2[0, 0] == 0 and D2[0, 1] == 0 and list(I2[0]) == sorted([a, b])
+
+
+def test_blend_matches_the_pipeline_expression_and_keeps_its_edge_cases():
+    """pipeline.py:129-138 verbatim in numpy vs oracle.blend, including big_npy[-1] for id -1 and NaN on an exact hit."""
+    idx = synth.make_ivf(400, 32, nlist=40, seed=11)
+    big = ivf_oracle.reconstruct_n(idx)
+    assert np.array_equal(big, idx["xb"])
+    q = np.random.default_rng(1).standard_normal((50, 32), dtype=np.float32)
+    q[0] = idx["xb"][17]
+    score, ix = ivf_oracle.search(idx, q, 8)
+    with np.errstate(all="ignore"):
+        weight = np.square(1 / score)
+        weight /= weight.sum(axis=1, keepdims=True)
+        npy = np.sum(big[ix] * np.expand_dims(weight, axis=2), axis=1)
+        ref = (torch.from_numpy(npy).unsqueeze(0) * 0.75 + (1 - 0.75) * torch.from_numpy(q).unsqueeze(0))[0].numpy()
+    out = ivf_oracle.blend(q, score, ix, big, 0.75)
+    assert np.isnan(out[0]).all() and np.isnan(ref[0]).all()  # inf/inf, as in the reference
+    assert np.array_equal(out[1:], ref[1:])
+    assert (ix == -1).any()  # some short lists: weight (1/FLT_MAX)^2 underflows to 0 and big_npy[-1] is harmless
+
+
+def test_faiss_file_layout_roundtrip_python(tmp_path):
+    idx = synth.make_ivf(700, 24, nlist=30, seed=2)
+    for sparse in (False, True):
+        p = str(tmp_path / ("a%d.index" % sparse))
+        ivf_oracle.write_index(idx, p, sparse=sparse)
+        with open(p, "rb") as f:
+            assert f.read(4) == b"IwFl"
+        r = ivf_oracle.read_index(p)
+        for k in ("centroids", "list_offsets", "ids", "vecs"):
+            assert np.array_equal(r[k], idx[k]), k
+        assert (r["d"], r["ntotal"], r["nlist"], r["nprobe"]) == (24, 700, 30, 1)
+
+
+def test_index_recipe_nlist():
+    # web.py:544  min(int(16*sqrt(N)), N//39)
+    assert synth.ivf_nlist(10000) == 256 and synth.ivf_nlist(200000) == 5128 and synth.ivf_nlist(1000000) == 16000

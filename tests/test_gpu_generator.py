@@ -1,0 +1,189 @@
+"""GPU parity of the HIP generator (through the Python mirror -> ctypes -> C ABI of include/rvcmi.h) against
+(a) golden fixtures produced by the REAL reference modules and (b) the oracle at other sizes, plus size-independent
+properties at BASELINE's full clip size.  Tolerances: the north star's bar is <= 1e-3 RMS on the waveform."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_config_and_weights, golden_names, load_golden, rms
+from oracle import nsf_oracle, synth
+
+pytestmark = pytest.mark.gpu
+
+# RMS bars per operand type.  fp32: exact-arithmetic class.  fp16 (default): the north-star bar.  bf16 operands do NOT
+# meet 1e-3 on these deliberately hard variance-preserving weights (2.7e-3 measured) -- documented in DESIGN.md; the
+# test pins that it stays in its known class rather than silently regressing.
+BAR = {"fp32": 2e-5, "fp16": 1e-3, "bf16": 6e-3}
+
+_gens = {}
+
+
+def hip_gen(cfg, w, operand, gpu):
+    import rvc_amd
+
+    key = (id(w), operand)
+    if key not in _gens:
+        cls = rvc_amd.NSFGeneratorHIP if cfg.use_f0 else rvc_amd.GeneratorHIP
+        _gens.clear()  # one live handle at a time keeps the workspace small
+        _gens[key] = cls(vars(cfg), w, device=gpu, operand=operand, max_B=2, max_T=80)
+    return _gens[key]
+
+
+def run_golden(d, cfg, w, operand, gpu):
+    gen = hip_gen(cfg, w, operand, gpu)
+    z = torch.from_numpy(d["z"]).to(gpu)
+    g = torch.from_numpy(d["g"]).to(gpu)
+    n_res = None if int(d.get("n_res", -1)) < 0 else int(d["n_res"])
+    if cfg.use_f0:
+        out = gen(z, torch.from_numpy(d["f0"]).to(gpu), g, n_res, noise=torch.from_numpy(d["noise"]).to(gpu))
+    else:
+        out = gen(z, g, n_res)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("operand", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("name", golden_names("dec_"))
+def test_generator_matches_reference_golden(name, operand, gpu):
+    d = load_golden(name)
+    cfg, w = golden_config_and_weights(d)
+    out = run_golden(d, cfg, w, operand, gpu)
+    assert out.shape == d["out"].shape
+    assert torch.isfinite(out).all()
+    e = rms(out, d["out"])
+    assert e <= BAR[operand], "%s/%s: RMS error %.3e vs the reference exceeds %.1e" % (name, operand, e, BAR[operand])
+
+
+@pytest.mark.parametrize("operand", ["fp32", "fp16"])
+def test_generator_inside_the_reference_infer_flow(operand, gpu):
+    """z*x_mask, pitchf, g as the reference's own enc_p/flow produced them inside net_g.infer, weights as its loader
+    folded them from a legacy fp16 weight-norm checkpoint (fixture infer_v2_48k_T20)."""
+    import rvc_amd
+
+    d = load_golden("infer_v2_48k_T20")
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    _, w = synth.make_legacy_checkpoint(cfg, "v2", int(d["seed"]))
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand=operand, max_B=1, max_T=32)
+    out = gen(torch.from_numpy(d["z"]).to(gpu), torch.from_numpy(d["f0"]).to(gpu), torch.from_numpy(d["g"]).to(gpu),
+              noise=torch.from_numpy(d["noise"]).to(gpu)).cpu()
+    assert rms(out, d["out"]) <= BAR[operand]
+
+
+def test_sine_source_and_stage_taps_fp32(gpu):
+    """Per-layer parity (har, conv_pre, every ups+noise_conv, every resblock stage) of the exact-fp32 path."""
+    import rvc_amd
+
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    w = synth.make_dec_weights(cfg, 99)
+    B, T = 2, 33
+    z, f0, g = synth.make_dec_inputs(cfg, B, T, 99)
+    noise = nsf_oracle.reference_noise(B, T, cfg.upp, 5)
+    taps = {}
+    with torch.no_grad():
+        nsf_oracle.generator_forward(cfg, w, z, f0, g, noise, taps=taps)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp32", max_B=B, max_T=T)
+    for k, v in taps.items():
+        got = gen.debug_tap(k, z.to(gpu), f0.to(gpu), g.to(gpu), noise=noise.to(gpu))
+        exp = v * cfg.num_kernels if k.startswith("stage") else v
+        assert got.shape == exp.shape, k
+        assert rms(got, exp) <= 3e-6 * max(1.0, float(exp.abs().max())), k
+
+
+def test_mfma_stage_taps_fp16(gpu):
+    import rvc_amd
+
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    w = synth.make_dec_weights(cfg, 7)
+    B, T = 1, 40
+    z, f0, g = synth.make_dec_inputs(cfg, B, T, 7)
+    noise = nsf_oracle.reference_noise(B, T, cfg.upp, 6)
+    taps = {}
+    with torch.no_grad():
+        nsf_oracle.generator_forward(cfg, w, z, f0, g, noise, taps=taps)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T)
+    for k, v in taps.items():
+        got = gen.debug_tap(k, z.to(gpu), f0.to(gpu), g.to(gpu), noise=noise.to(gpu))
+        exp = v * cfg.num_kernels if k.startswith("stage") else v
+        rel = rms(got, exp) / float(exp.pow(2).mean().sqrt())
+        assert rel <= (1e-6 if k == "har" else 2e-3), "%s: relative RMS %.2e" % (k, rel)
+
+
+def test_rng_stream_matches_torch_draw_order(gpu):
+    """noise=None draws rand(1,1,1) then randn([B,T*upp,1]) on f0's device, like generators.py:164,192."""
+    import rvc_amd
+
+    cfg = nsf_oracle.CONFIGS["v1_40k"]
+    w = synth.make_dec_weights(cfg, 3)
+    B, T = 1, 12
+    z, f0, g = synth.make_dec_inputs(cfg, B, T, 3)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T)
+    zd, fd, gd = z.to(gpu), f0.to(gpu), g.to(gpu)
+    torch.manual_seed(1234)
+    a = gen(zd, fd, gd)
+    torch.manual_seed(1234)
+    b = gen(zd, fd, gd)
+    torch.manual_seed(1234)
+    torch.rand(1, 1, 1, device=gpu)
+    noise = torch.randn(B, T * cfg.upp, 1, device=gpu)
+    c = gen(zd, fd, gd, noise=noise)
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert not torch.equal(a, gen(zd, fd, gd))  # the stream advanced
+
+
+def test_handle_rejects_bad_shapes_and_grows_its_workspace(gpu):
+    import rvc_amd
+
+    cfg = nsf_oracle.CONFIGS["v1_40k"]
+    w = synth.make_dec_weights(cfg, 3)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=1, max_T=8)
+    z, f0, g = synth.make_dec_inputs(cfg, 2, 20, 3)
+    with pytest.raises(ValueError):
+        gen(z.to(gpu)[:, :100], f0.to(gpu), g.to(gpu))
+    with pytest.raises(ValueError):
+        gen(z.to(gpu), None, g.to(gpu))
+    out = gen(z.to(gpu), f0.to(gpu), g.to(gpu), noise=torch.zeros(2, 20 * cfg.upp, device=gpu))  # beyond max_B/max_T: re-created
+    assert out.shape == (2, 1, 20 * cfg.upp)
+    bad = dict(w)
+    bad.pop("ups.1.bias")
+    with pytest.raises(rvc_amd.RvcmiError, match="missing weight"):
+        rvc_amd.NSFGeneratorHIP(vars(cfg), bad, device=gpu)
+
+
+def test_full_clip_size_properties(gpu):
+    """BASELINE size (v2/48k, T = 1198 frames = one 10 s clip): determinism, batch independence and locality.
+    Locality is the size-independent property of a conv stack: the waveform of frames [a, b) computed from the
+    whole clip equals the one computed from a window with a receptive-field margin -- across completely different
+    tile boundaries, phase offsets and grid sizes -- so it exercises every halo / tiling decision at full scale."""
+    import rvc_amd
+
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    w = synth.make_dec_weights(cfg, 1234)
+    T = 1198
+    z, f0, g = synth.make_dec_inputs(cfg, 1, T, 1234)
+    f0 = torch.zeros_like(f0)  # unvoiced everywhere: the harmonic phase carries no history, so locality is exact
+    noise = nsf_oracle.reference_noise(1, T, cfg.upp, 114514)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=2, max_T=T)
+    zd, fd, gd, nd = z.to(gpu), f0.to(gpu), g.to(gpu), noise.to(gpu)
+    full = gen(zd, fd, gd, noise=nd)
+    assert torch.isfinite(full).all() and full.shape == (1, 1, T * cfg.upp)
+    assert torch.equal(full, gen(zd, fd, gd, noise=nd))  # bitwise reproducible
+    # batch independence: the same clip twice in a batch of 2
+    both = gen(zd.repeat(2, 1, 1), fd.repeat(2, 1), gd.repeat(2, 1, 1), noise=nd.repeat(2, 1))
+    assert torch.equal(both[0], full[0]) and torch.equal(both[1], full[0])
+    # locality: window [400, 700) with a 40-frame margin each side (receptive field of the stack < 30 frames)
+    a, b, m = 400, 700, 40
+    win = gen(zd[:, :, a - m:b + m].contiguous(), fd[:, a - m:b + m].contiguous(), gd,
+              noise=nd[:, (a - m) * cfg.upp:(b + m) * cfg.upp].contiguous())
+    x = full[0, 0, a * cfg.upp:b * cfg.upp]
+    y = win[0, 0, m * cfg.upp:(m + b - a) * cfg.upp]
+    assert rms(x, y) <= 2e-6, "tiling / halo inconsistency at full size: %.3e" % rms(x, y)
+    # and against the oracle on that window only (the oracle needs ~1 s for 380 frames)
+    with torch.no_grad():
+        ref = nsf_oracle.generator_forward(cfg, w, z[:, :, a - m:b + m], f0[:, a - m:b + m], g, noise[:, (a - m) * cfg.upp:(b + m) * cfg.upp])
+    assert rms(win.cpu(), ref) <= 1e-3
+
+
+def test_smoke_entry_point(gpu):
+    import __graft_entry__
+
+    __graft_entry__.smoke()

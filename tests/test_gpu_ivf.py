@@ -1,0 +1,178 @@
+"""GPU parity of the HIP IVF-Flat retrieval (C ABI via the faiss-like Python object) against the CPU oracle:
+bit-exact ids, distances to fp32 rounding, the blend to 1e-5 RMS; the reference's edge semantics; file and blob
+round trips; and ranking properties at BASELINE's stress size."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ivf_oracle, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make(idx, gpu, nprobe=1):
+    import rvc_amd
+
+    return rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], nprobe=nprobe, device=gpu)
+
+
+@pytest.mark.parametrize("n,d,nq", [(10000, 768, 599), (5000, 256, 301), (2000, 64, 33)])
+def test_search_ids_bit_exact_and_distances(n, d, nq, gpu):
+    idx = synth.make_ivf(n, d, seed=n, dup=9)
+    q = synth.make_phone(1, nq, d, seed=n)[0].numpy()
+    q[:5] = idx["xb"][:5]  # exact hits
+    h = make(idx, gpu)
+    assert (h.ntotal, h.d, h.nlist, h.nprobe) == (n, d, idx["nlist"], 1)
+    D, I = h.search(q, 8)
+    Dr, Ir = ivf_oracle.search(idx, q, 8)
+    assert I.dtype == np.int64 and D.dtype == np.float32
+    assert np.array_equal(I, Ir), "%d id mismatches" % int((I != Ir).sum())
+    assert np.array_equal(D, Dr)
+    for k in (1, 3):  # top-1 (legacy tools/cmd/infer-pm-index256.py:161) = column 0 of top-8
+        Dk, Ik = h.search(q, k)
+        assert np.array_equal(Ik, Ir[:, :k]) and np.array_equal(Dk, Dr[:, :k])
+    # torch in -> torch out, device resident
+    Dt, It = h.search(torch.from_numpy(q).to(gpu), 8)
+    assert Dt.is_cuda and np.array_equal(It.cpu().numpy(), Ir)
+
+
+@pytest.mark.parametrize("nprobe", [2, 9])
+def test_nprobe_greater_than_one(nprobe, gpu):
+    """Legacy indices carry nprobe=9 (tools/cmd/train-index.py:26-29)."""
+    idx = synth.make_ivf(4000, 64, nlist=50, seed=5)
+    q = np.random.default_rng(3).standard_normal((77, 64), dtype=np.float32)
+    h = make(idx, gpu, nprobe=nprobe)
+    D, I = h.search(q, 8)
+    Dr, Ir = ivf_oracle.search(idx, q, 8, nprobe=nprobe)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    h.nprobe = 1  # web.py:551-552
+    D1, I1 = h.search(q, 8)
+    Dr1, Ir1 = ivf_oracle.search(idx, q, 8, nprobe=1)
+    assert h.nprobe == 1 and np.array_equal(I1, Ir1)
+
+
+def test_short_lists_empty_lists_empty_queries_and_ties(gpu):
+    idx = synth.make_ivf(60, 16, nlist=20, seed=8)  # ~3 rows per list, some lists empty
+    assert (np.diff(idx["list_offsets"]) == 0).any()
+    q = np.random.default_rng(2).standard_normal((40, 16), dtype=np.float32)
+    h = make(idx, gpu)
+    D, I = h.search(q, 8)
+    Dr, Ir = ivf_oracle.search(idx, q, 8)
+    assert np.array_equal(I, Ir) and (I == -1).any()
+    assert np.all(D[I == -1] == np.float32(3.4028234663852886e38)) and np.array_equal(D, Dr)
+    D0, I0 = h.search(q[:0], 8)
+    assert D0.shape == (0, 8) and I0.shape == (0, 8)
+    # duplicates: ties resolve to the lowest id
+    idx2 = synth.make_ivf(300, 16, nlist=4, seed=9)
+    idx2["vecs"][1] = idx2["vecs"][0]
+    h2 = make(idx2, gpu, nprobe=4)
+    D2, I2 = h2.search(idx2["vecs"][:1].copy(), 2)
+    assert D2[0, 0] == 0 and D2[0, 1] == 0 and list(I2[0]) == sorted([int(idx2["ids"][0]), int(idx2["ids"][1])])
+    with pytest.raises(ValueError):
+        h.search(np.zeros((3, 17), np.float32), 8)  # dimension mismatch (the reference raises "index mistatch")
+    with pytest.raises(TypeError):
+        h.search(np.zeros((3, 16), np.float64), 8)
+    import rvc_amd
+
+    with pytest.raises(rvc_amd.RvcmiError):
+        h.search(q, 9)  # k > 8
+
+
+def test_search_blend_matches_pipeline_arithmetic(gpu):
+    """pipeline.py:129-138 fused on the device, incl. its edge cases: id -1 -> big_npy[-1] with zero weight,
+    exact hit -> NaN row, and the realtime guard of rtrvc.py:173."""
+    idx = synth.make_ivf(10000, 768, seed=4321)
+    h = make(idx, gpu)
+    q = synth.make_phone(1, 599, 768)[0].numpy()
+    exp = ivf_oracle.search_blend(idx, q, 0.75)
+    got = h.search_blend(torch.from_numpy(q).to(gpu), 0.75).cpu().numpy()
+    assert np.sqrt(np.mean((got - exp) ** 2)) <= 1e-5 and np.abs(got - exp).max() <= 1e-5
+    big = h.reconstruct_n(0, h.ntotal)
+    assert np.array_equal(big, idx["xb"])
+    assert np.array_equal(h.reconstruct_n(17, 5), idx["xb"][17:22])
+    # exact hit -> inf/inf = NaN for that row, exactly as numpy gives the reference
+    q2 = q[:8].copy()
+    q2[3] = idx["xb"][123]
+    got2 = h.search_blend(torch.from_numpy(q2).to(gpu), 0.5).cpu().numpy()
+    exp2 = ivf_oracle.search_blend(idx, q2, 0.5)
+    assert np.isnan(got2[3]).all() and np.isnan(exp2[3]).all()
+    assert np.abs(np.delete(got2, 3, 0) - np.delete(exp2, 3, 0)).max() <= 1e-5
+    # short lists: offline path blends with big_npy[-1]*0, realtime path skips the whole call
+    idx3 = synth.make_ivf(60, 16, nlist=20, seed=8)
+    h3 = make(idx3, gpu)
+    q3 = np.random.default_rng(2).standard_normal((40, 16), dtype=np.float32)
+    exp3 = ivf_oracle.search_blend(idx3, q3, 0.75)
+    got3 = h3.search_blend(torch.from_numpy(q3).to(gpu), 0.75).cpu().numpy()
+    assert np.abs(got3 - exp3).max() <= 1e-5
+    kept = h3.search_blend(torch.from_numpy(q3).to(gpu), 0.75, skip_if_short=True).cpu().numpy()
+    assert np.array_equal(kept, q3)
+    # retrieve_blend: the Pipeline.vc glue (keeps dtype/shape, index_rate 0 or index None = untouched)
+    import rvc_amd
+
+    f = torch.from_numpy(q).to(gpu).half().unsqueeze(0)
+    out = rvc_amd.retrieve_blend(f, h, 0.75)
+    assert out.shape == f.shape and out.dtype == torch.float16
+    assert rvc_amd.retrieve_blend(f, None, 0.75) is f and rvc_amd.retrieve_blend(f, h, 0) is f
+
+
+def test_faiss_file_and_blob_roundtrips(tmp_path, gpu):
+    import rvc_amd
+
+    idx = synth.make_ivf(3000, 256, seed=77)
+    q = np.random.default_rng(1).standard_normal((50, 256), dtype=np.float32)
+    h = make(idx, gpu)
+    _, I = h.search(q, 8)
+    p = str(tmp_path / "added_IVF76_Flat_nprobe_1.index")
+    rvc_amd.write_index(h, p)  # C++ writer -> independent python reader
+    r = ivf_oracle.read_index(p)
+    for k in ("centroids", "list_offsets", "ids", "vecs"):
+        assert np.array_equal(r[k], idx[k]), k
+    for sparse in (False, True):  # python writer -> C++ reader
+        p2 = str(tmp_path / ("py%d.index" % sparse))
+        ivf_oracle.write_index(idx, p2, sparse=sparse)
+        h2 = rvc_amd.read_index(p2, gpu)
+        assert np.array_equal(h2.search(q, 8)[1], I)
+    blob = h.blob()  # what one RCCL broadcast ships
+    h3 = rvc_amd.IVFFlatHIP.from_blob(blob.clone())
+    assert np.array_equal(h3.search(q, 8)[1], I) and h3.ntotal == h.ntotal
+    with pytest.raises(rvc_amd.RvcmiError):
+        rvc_amd.IVFFlatHIP.from_blob(torch.zeros(4096, dtype=torch.uint8, device=gpu))
+    trunc = tmp_path / "trunc.index"
+    trunc.write_bytes(open(p, "rb").read()[:5000])
+    with pytest.raises(rvc_amd.RvcmiError, match="truncated"):
+        rvc_amd.read_index(str(trunc), gpu)
+
+
+def test_stress_size_ranking_properties(gpu):
+    """BASELINE's stress shape (1M x 256, nlist 16000, nprobe 1) through size-independent properties:
+    results ascending, every hit comes from the probed list, top-1 == brute force over that list in fp64, and a
+    query equal to a stored row finds it at distance 0 when its list is probed."""
+    n, d, nlist = 1_000_000, 256, 16000
+    rng = np.random.default_rng(4321)
+    vecs = rng.standard_normal((n, d), dtype=np.float32)
+    cent = vecs[rng.choice(n, nlist, replace=False)].copy()
+    sizes = np.full(nlist, n // nlist, dtype=np.int64)
+    sizes[: n - sizes.sum()] += 1
+    off = np.zeros(nlist + 1, np.int64)
+    np.cumsum(sizes, out=off[1:])
+    ids = rng.permutation(n).astype(np.int64)
+    import rvc_amd
+
+    h = rvc_amd.IVFFlatHIP.from_arrays(cent, off, ids, vecs, device=gpu)
+    q = rng.standard_normal((599, d), dtype=np.float32)
+    D, I = h.search(q, 8)
+    assert np.all(np.diff(D.astype(np.float64), axis=1) >= 0) and (I >= 0).all()
+    pos_of_id = np.empty(n, np.int64)
+    pos_of_id[ids] = np.arange(n)
+    lists = np.searchsorted(off, pos_of_id[I], side="right") - 1
+    assert np.all(lists == lists[:, :1])  # one probed list per query
+    c64 = cent.astype(np.float64)
+    for i in range(0, 599, 37):  # brute force on a sample of queries
+        dist = ((c64 - q[i].astype(np.float64)) ** 2).sum(1)
+        l = int(np.argmin(dist))
+        assert lists[i, 0] == l
+        rows = vecs[off[l]:off[l + 1]].astype(np.float64)
+        dd = ((rows - q[i].astype(np.float64)) ** 2).sum(1)
+        order = np.lexsort((ids[off[l]:off[l + 1]], dd))[:8]
+        assert np.array_equal(I[i], ids[off[l]:off[l + 1]][order])
+        assert np.array_equal(D[i], dd[order].astype(np.float32))
