@@ -52,13 +52,19 @@ def test_nprobe_greater_than_one(nprobe, gpu):
 
 
 def test_short_lists_empty_lists_empty_queries_and_ties(gpu):
-    idx = synth.make_ivf(60, 16, nlist=20, seed=8)  # ~3 rows per list, some lists empty
-    assert (np.diff(idx["list_offsets"]) == 0).any()
+    idx = synth.make_ivf(60, 16, nlist=20, seed=8)  # ~3 rows per list: shorter than k
+    # plus one EMPTY list whose centroid sits far away: a query next to it gets nothing but -1 / FLT_MAX padding
+    far = np.full((1, 16), 50.0, np.float32)
+    idx["centroids"] = np.concatenate([idx["centroids"][:5], far, idx["centroids"][5:]])
+    idx["list_offsets"] = np.concatenate([idx["list_offsets"][:6], idx["list_offsets"][5:]])
+    idx["nlist"] = 21
+    assert (np.diff(idx["list_offsets"]) == 0).sum() == 1
     q = np.random.default_rng(2).standard_normal((40, 16), dtype=np.float32)
+    q[7] = far[0] + 0.01
     h = make(idx, gpu)
     D, I = h.search(q, 8)
     Dr, Ir = ivf_oracle.search(idx, q, 8)
-    assert np.array_equal(I, Ir) and (I == -1).any()
+    assert np.array_equal(I, Ir) and (I == -1).any() and (I[7] == -1).all()
     assert np.all(D[I == -1] == np.float32(3.4028234663852886e38)) and np.array_equal(D, Dr)
     D0, I0 = h.search(q[:0], 8)
     assert D0.shape == (0, 8) and I0.shape == (0, 8)
