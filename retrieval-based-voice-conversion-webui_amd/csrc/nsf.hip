@@ -140,6 +140,8 @@ struct Stage {
     // noise conv (nsf.py:103-115)
     int nk = 0, ns = 1, npad = 0;
     DevBuf noise_w, noise_b;
+    ConvLayer nz;          // the same noise conv as a 2-tap MFMA conv over frames of `ns` samples (when ns % 8 == 0)
+    bool nz_mfma = false;
     // resblocks[j].pair[m] = {conv1, conv2}
     std::vector<std::vector<std::pair<ConvLayer, ConvLayer>>> rb;
 };
@@ -164,7 +166,7 @@ struct rvcmi_nsf {
     size_t S = 0;  // elements per activation buffer
     // P: conv_pre output.  X0: ups(+noise) output = input of the stage's resblocks.  Ya[j]/Yb[j]: ping-pong
     // fp32 streams of resblock j (its final output is one of them; the consumer sums the nk of them).
-    DevBuf P, X0, Ya[RVCMI_MAX_RB], Yb[RVCMI_MAX_RB], H, har, har2, x2, phase, condv, dbg;
+    DevBuf P, X0, Ya[RVCMI_MAX_RB], Yb[RVCMI_MAX_RB], H, NZ, har, har2, x2, phase, condv, dbg;
     size_t ws_bytes = 0;
     Profiler prof;
 };
@@ -289,6 +291,15 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
                 for (int j = 0; j < s.nk; ++j) wt[(size_t)j * s.cout + co] = w.data[(size_t)co * s.nk + j];
             upload(s.noise_w, wt);
             upload(s.noise_b, std::vector<float>(b.data, b.data + s.cout));
+            if (op != RVCMI_OPERAND_F32 && !last && s.ns % 8 == 0 && s.ns <= 64) {
+                const int cinp = s.ns <= 16 ? 16 : (s.ns <= 32 ? 32 : 64);
+                int nt = 2, off = 0;
+                const float* wd = w.data;
+                const int ns = s.ns, nkk = s.nk;
+                build_conv(s.nz, cinp, s.cout, 1, &nt, &off, 1,
+                           [=](int co, int ci, int, int tap) { return ci < ns ? wd[(size_t)co * nkk + tap * ns + ci] : 0.f; }, b.data, op);
+                s.nz_mfma = true;
+            }
         }
         s.rb.resize(cfg->n_resblock_kernels);
         for (int j = 0; j < cfg->n_resblock_kernels; ++j) {  // ResBlock1   residuals.py:19-58
@@ -336,6 +347,15 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
         h->Yb[j].alloc(fb);
     }
     if (op == RVCMI_OPERAND_F32) h->H.alloc(fb);
+    {
+        size_t nz = 0;
+        long Ls = max_T;
+        for (int i = 0; i < cfg->n_ups; ++i) {
+            Ls *= cfg->upsample_rates[i];
+            if (h->stages[i].nz_mfma) nz = std::max(nz, (size_t)Ls * h->stages[i].cout);
+        }
+        if (nz) h->NZ.alloc(nz * max_B * sizeof(float));
+    }
     const size_t hb = (size_t)max_B * max_T * upp * sizeof(float);
     h->har.alloc(hb);
     h->har2.alloc(hb);
@@ -426,7 +446,7 @@ static void set_lds_limits() {
 
 template <typename OpT, int C, int MI, int NW, int KG>
 static void launch_rb_inst(const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
-    const size_t smem = (size_t)rows * Tile<C>::STRIDE;
+    const size_t smem = (size_t)rows * Tile<C>::STRIDE + 2 * 32 * MI * NW * 4;  // tile + the two bias vectors
     if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "resblock LDS tile too large (%zu B)", smem);
     hipLaunchKernelGGL((k_rb_pair<OpT, C, MI, NW, KG>), dim3(tiles, nj, B), dim3(64 * NW), smem, st, ra);
 }
@@ -756,7 +776,23 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             ua.bias = U.bias.as<float>();
             ua.out = h->X0.as<float>();
             ua.out_bstride = L * C;
-            if (c.use_f0) {
+            if (c.use_f0 && s.nz_mfma) {  // noise_convs[i](har) as a 2-tap MFMA conv over frames -> NZ, added in k_ups' epilogue
+                ConvArgs na = base_args();
+                na.in = har;
+                na.in_bstride = (long)Te * upp;
+                na.Lin = Te * upp;
+                na.in_mode = IN_HAR;
+                na.hs = s.ns;
+                na.hpad = s.npad;
+                na.Lq = (int)L;
+                na.out_mode = OUT_F32;
+                na.out = h->NZ.p;
+                na.out_bstride = L * C;
+                na.out_C = C;
+                snprintf(nm, sizeof(nm), "noise_mfma_c%d", C);
+                run_conv(h, s.nz, na, B, nm, st);
+                ua.addend = h->NZ.as<float>();
+            } else if (c.use_f0) {
                 ua.har = har;
                 ua.Lh = Te * upp;
                 ua.Wn = s.noise_w.as<float>();

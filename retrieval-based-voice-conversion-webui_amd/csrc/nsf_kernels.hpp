@@ -123,7 +123,8 @@ __global__ void __launch_bounds__(256) k_cond(const float* __restrict__ g, const
 enum InMode : int {
     IN_F32_ACT = 0,   // fp32 channels-last, apply v = lrelu(v / div, slope) on load
     IN_OP_RAW = 1,    // already-activated operand copy (OpT in MFMA mode, fp32 in F32 mode)
-    IN_F32_CF = 2     // fp32 channel-first [B][C][L] raw (conv_pre input, the reference layout)
+    IN_F32_CF = 2,    // fp32 channel-first [B][C][L] raw (conv_pre input, the reference layout)
+    IN_HAR = 3        // the excitation viewed as frames: row t, channel c = har[t*hs - hpad + c] (c < hs), else 0
 };
 enum OutMode : int {
     OUT_ACT = 0,      // out = lrelu(acc + bias, slope_out) stored as operand type
@@ -139,6 +140,7 @@ struct ConvArgs {
     int Lin;           // valid input rows
     int cin;
     int in_mode;
+    int hs, hpad;      // IN_HAR: frame length (= noise-conv stride) and left padding; Lin counts SAMPLES of har
     float slope_in, div_in;
     // weights
     const void* w;     // F32: [taps][cin][cout] fp32.  MFMA: packed fragments (see pack_conv_weights)
@@ -362,7 +364,19 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
         frag v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (OpT)0.f;
-        if (gr >= 0 && gr < a.Lin) {
+        if (a.in_mode == IN_HAR) {
+            // noise_convs[i] (nsf.py:103-115) is Conv1d(1, C, k=2s, stride s, pad s/2): over frames of s samples it is
+            // a plain 2-tap conv with C_in = s, so it runs on the MFMA path.  s % 8 == 0 keeps every 8-sample
+            // chunk entirely inside or outside the signal and 16-byte aligned.
+            const long base = (long)gr * a.hs - a.hpad + c8 * 8;
+            if (c8 * 8 < a.hs && base >= 0 && base + 8 <= a.Lin) {
+                const float4* p = (const float4*)((const float*)a.in + (size_t)b * a.in_bstride + base);
+                const float4 lo = p[0], hi = p[1];
+                const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(f[e]);
+            }
+        } else if (gr >= 0 && gr < a.Lin) {
             if (a.in_mode == IN_OP_RAW) {
                 v = *(const frag*)((const OpT*)a.in + (size_t)b * a.in_bstride + (size_t)gr * CIN + c8 * 8);
             } else if (a.in_mode == IN_F32_ACT) {
@@ -556,6 +570,36 @@ __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
     }
 }
 
+// Branch-free helpers.  lrelu as max(x, slope*x) (0 < slope < 1); row masking by AND-ing the value bits so that
+// the compiler cannot turn the select into divergent control flow (it did: ~45 exec-masked blocks per publish).
+__device__ __forceinline__ float lrelu_max(float v, float slope) { return fmaxf(v, v * slope); }
+__device__ __forceinline__ float mask_bits(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
+
+// acc (MFMA D layout) -> lrelu -> OpT -> LDS operand tile.  `base` already points at this lane's (row, 4*(lane>>5))
+// element of the wave's first row; everything else is a compile-time offset.
+template <typename OpT, int C, int MI, int NJ, int STRIDE, bool MASK>
+__device__ __forceinline__ void publish_operand(char* base, const f32x16 (&acc)[MI][NJ], const unsigned (&rowmask)[NJ],
+                                                int cbase = 0) {
+    using o4 = __attribute__((ext_vector_type(4))) OpT;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if ((C % 32 == 0) || cbase + mi * 32 + 8 * g < C) {  // compile-time true for C % 32 == 0
+                    o4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = lrelu_max(acc[mi][jt][4 * g + e], 0.1f);
+                        if constexpr (MASK) v = mask_bits(v, rowmask[jt]);
+                        o[e] = to_op<OpT>(v);
+                    }
+                    *(o4*)(base + jt * 32 * STRIDE + (mi * 32 + 8 * g) * 2) = o;
+                }
+            }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused ResBlock1 pair (residuals.py:73-82):   x <- conv2(lrelu(conv1_dil(lrelu(x)) + b1)) + b2 + x
 // ------------------------------------------------------------------------------------------------
@@ -603,6 +647,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
     constexpr int C8 = C / 8;
     constexpr int NT = 64 * NW;
     constexpr int NJ = RB_ROWS / 32;
+    constexpr int NB = 2;
+    constexpr int CP = 32 * MI * NW;  // padded channel count
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const RbJob& J = a.job[blockIdx.y];
@@ -615,9 +661,19 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
     const int x0 = h0 - p1;                     // global time of X row 0
     const int xrows = RB_ROWS + (J.k_p - 1) * J.dil;
     const float* src = J.src + (size_t)b * a.bstride;
+    float* bias_l = (float*)(smem + (size_t)xrows * STRIDE);  // [2][CP]: b1 then b2
 
-    // ---- 1. stage lrelu(x) -> OpT tile.  SB independent 32-byte loads in flight per thread: the
-    //         accumulators are not live yet, so the whole register file is available as a landing zone.
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int ct0 = wave * MI;
+    const int half4 = 4 * (lane >> 5);
+
+    // conv1's first weight groups are requested before anything else: their latency hides behind the staging
+    frag A[NB][KG][MI];
+    conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w1 + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p);
+
+    // ---- 1. stage lrelu(x) -> OpT tile.  SB independent 32-byte loads in flight per thread (the accumulators are
+    //         not live yet); clamped addresses keep every load unconditional (no exec-masked block per load).
     constexpr int SB = 8;
     const int total = xrows * C8;
     for (int base = threadIdx.x; base < total; base += SB * NT) {
@@ -628,12 +684,11 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
             const int r = idx / C8;
             const int c8 = idx - r * C8;
             const int gr = x0 + r;
-            const bool ok = gr >= 0 && gr < a.L;
-            const int grc = min(max(gr, 0), a.L - 1);  // clamped address: unconditional loads, no branch per load
+            const int grc = min(max(gr, 0), a.L - 1);
             const float4* p = (const float4*)(src + (size_t)grc * C + c8 * 8);
             lo[u] = p[0];
             hi[u] = p[1];
-            if (!ok) {
+            if (gr < 0 || gr >= a.L) {
                 lo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 hi[u] = lo[u];
             }
@@ -647,83 +702,86 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
             const float f[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
             frag v;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(lrelu(f[e], 0.1f));
+            for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(lrelu_max(f[e], 0.1f));
             *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
         }
     }
-    __syncthreads();
-
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const int ct0 = wave * MI;
-    const char* lds_lane = smem + (size_t)(lane & 31) * STRIDE + (lane >> 5) * 16;
-
-    f32x16 acc[MI][NJ];
-    auto zero = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int jt = 0; jt < NJ; ++jt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][jt][r] = 0.f;
-    };
-
-    // ---- 2. conv1 -----------------------------------------------------------------------------------
-    zero();
-    if (!(a.dbg & 2))
-        conv_core<OpT, C, MI, NJ, KG>(acc, lds_lane, (const OpT*)J.w1 + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p, 0, J.dil);
-    __syncthreads();  // every wave has finished reading X
-
-    // ---- 3. h = lrelu(conv1 + b1) -> OpT, in place over X (zero outside the utterance) --------------
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) {
-            const int hrow = jt * 32 + (lane & 31);
-            const int th = h0 + hrow;
-            const bool inside = th >= 0 && th < a.L;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = cobase + 8 * g;
-                using o4 = __attribute__((ext_vector_type(4))) OpT;
-                o4 o;
-                if ((C % 32 == 0) || co < C) {
-                    const f32x4 bv = *(const f32x4*)(J.b1 + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        o[e] = inside ? to_op<OpT>(lrelu(acc[mi][jt][4 * g + e] + bv[e], 0.1f)) : (OpT)0.f;
-                    *(o4*)(smem + (size_t)hrow * STRIDE + co * 2) = o;
-                }
-            }
-        }
+    for (int i = threadIdx.x; i < 2 * CP; i += NT) {
+        const int c = i % CP;
+        bias_l[i] = c < C ? (i < CP ? J.b1[c] : J.b2[c]) : 0.f;
     }
     __syncthreads();
 
-    // ---- 4. conv2 -----------------------------------------------------------------------------------
-    zero();
-    if (!(a.dbg & 4))
-        conv_core<OpT, C, MI, NJ, KG>(acc, lds_lane, (const OpT*)J.w2 + (size_t)ct0 * J.ct2 + lane * 8, J.ct2, J.k_p, 0, 1);
-
-    // ---- 5. epilogue: x' = conv2 + b2 + x ------------------------------------------------------------
-    float* dst = J.dst + (size_t)b * a.bstride;
+    const char* lds_lane = smem + (size_t)(lane & 31) * STRIDE + (lane >> 5) * 16;
+    f32x16 acc[MI][NJ];
+    auto init_bias = [&](const float* bl) {  // accumulators start from the bias: no add in the epilogues
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int jt = 0; jt < NJ; ++jt) {
-            const int o = jt * 32 + (lane & 31);
-            const int t = t0 + o;
-            if (o >= J.tt2 || t >= a.L) continue;
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = cobase + 8 * g;
-                if ((C % 32 != 0) && co >= C) continue;
-                f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
-                v += *(const f32x4*)(J.b2 + co);
-                if (!(a.dbg & 8)) v += *(const f32x4*)(src + (size_t)t * C + co);
-                if (!(a.dbg & 16)) *(f32x4*)(dst + (size_t)t * C + co) = v;
+                const f32x4 bv = *(const f32x4*)(bl + (ct0 + mi) * 32 + 8 * g + half4);
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mi][jt][4 * g + e] = bv[e];
             }
+    };
+
+    // ---- 2. conv1 -----------------------------------------------------------------------------------
+    init_bias(bias_l);
+    if (!(a.dbg & 2))
+        conv_run<OpT, C, MI, NJ, KG, NB>(acc, A, lds_lane, (const OpT*)J.w1 + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p, 0, J.dil);
+    conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w2 + (size_t)ct0 * J.ct2 + lane * 8, J.ct2, J.k_p);  // across the barriers
+    __syncthreads();  // every wave has finished reading X
+
+    // ---- 3. h = lrelu(conv1 + b1) -> OpT, in place over X (zero outside the utterance: conv2 pads ITS input) ----
+    {
+        const bool interior = h0 >= 0 && h0 + RB_ROWS <= a.L;  // block-uniform: no masking needed
+        unsigned rowmask[NJ];
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            const int th = h0 + jt * 32 + (lane & 31);
+            rowmask[jt] = (th >= 0 && th < a.L) ? 0xffffffffu : 0u;
+        }
+        char* hw = smem + (size_t)(lane & 31) * STRIDE + (ct0 * 32 + half4) * 2;
+        if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(hw, acc, rowmask, ct0 * 32);
+        else publish_operand<OpT, C, MI, NJ, STRIDE, true>(hw, acc, rowmask, ct0 * 32);
+    }
+    __syncthreads();
+
+    // ---- 4. conv2 (accumulators start from b2) -----------------------------------------------------------
+    init_bias(bias_l + CP);
+    if (!(a.dbg & 4))
+        conv_run<OpT, C, MI, NJ, KG, NB>(acc, A, lds_lane, (const OpT*)J.w2 + (size_t)ct0 * J.ct2 + lane * 8, J.ct2, J.k_p, 0, 1);
+
+    // ---- 5. epilogue: x' = (conv2 + b2) + x --------------------------------------------------------------
+    float* dst = J.dst + (size_t)b * a.bstride;
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        const int o = jt * 32 + (lane & 31);
+        const int t = t0 + o;
+        const bool valid = o < J.tt2 && t < a.L;
+        const int tc = min(t, a.L - 1);
+        f32x4 r[MI][4];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if ((ct0 + mi) * 0 + mi * 32 + 8 * g < CP)  // always true; keeps the loads unconditional
+                    r[mi][g] = (C % 32 == 0 || (ct0 + mi) * 32 + 8 * g + half4 < C)
+                                   ? *(const f32x4*)(src + (size_t)tc * C + min((ct0 + mi) * 32 + 8 * g + half4, C - 4))
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (valid && !(a.dbg & 16)) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = (ct0 + mi) * 32 + 8 * g + half4;
+                    if ((C % 32 != 0) && co >= C) continue;
+                    f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
+                    v += r[mi][g];
+                    *(f32x4*)(dst + (size_t)t * C + co) = v;
+                }
         }
     }
 }
@@ -754,7 +812,8 @@ struct UpsArgs {
     const float* bias;
     float* out;
     long out_bstride;
-    const float* har;  // [B][Lh] or nullptr (no-f0 generator)
+    const float* addend;  // optional [B][Lin*u][cout] fp32 added in the epilogue (noise conv done by the MFMA conv)
+    const float* har;  // [B][Lh] or nullptr (no-f0 generator / addend in use)
     int Lh;
     const float* Wn;   // [nk][cout]
     const float* bn;
@@ -849,51 +908,49 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
         const OpT* wlane = (const OpT*)a.w + a.ph_w_off[r] + (size_t)ct0 * a.ct_stride + lane * 8;
         if (!(a.dbg & 2)) conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.ct_stride, a.ntaps_p, a.ph_in_off[r] - a.lo, -1);
 
+        const float* addend = a.addend ? a.addend + (size_t)b * a.out_bstride : nullptr;
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             const int q = q0 + tw0 + jt * 32 + (lane & 31);
-            if (q >= a.Lin) continue;
-            const int t = q * a.u + r;
+            const bool valid = q < a.Lin;
+            const int t = min(q, a.Lin - 1) * a.u + r;  // clamped: loads below stay unconditional
             // noise conv for this output row: nv[mi][g] (4 channels each) += har[t*s - pad + j] * Wn[j][co]
             f32x4 nv[MI][4];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) nv[mi][g] = {0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < 4; ++g) {
+                    const int co = min((ct0 + mi) * 32 + 8 * g + 4 * (lane >> 5), a.cout - 4);
+                    nv[mi][g] = addend ? *(const f32x4*)(addend + (size_t)t * a.cout + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             if (har && !(a.dbg & 4)) {
                 const int hb = t * a.ns - a.npad;
                 for (int j = 0; j < a.nk; ++j) {
                     const int hi = hb + j;
                     const float hv = (hi >= 0 && hi < a.Lh) ? har[hi] : 0.f;
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int co = cobase + 8 * g;
-                            if (co < a.cout) {
-                                const f32x4 wv4 = *(const f32x4*)(a.Wn + (size_t)j * a.cout + co);
-                                nv[mi][g] += wv4 * hv;
-                            }
+                            const int co = min((ct0 + mi) * 32 + 8 * g + 4 * (lane >> 5), a.cout - 4);
+                            const f32x4 wv4 = *(const f32x4*)(a.Wn + (size_t)j * a.cout + co);
+                            nv[mi][g] += wv4 * hv;
                         }
-                    }
                 }
             }
+            if (valid && !(a.dbg & 16)) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co = cobase + 8 * g;
-                    if (co >= a.cout) continue;
-                    f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
-                    v += *(const f32x4*)(a.bias + co);
-                    if (har) {  // x + (noise_conv + its bias): same association as nsf.py:173-174
-                        const f32x4 nb = nv[mi][g] + *(const f32x4*)(a.bn + co);
-                        v += nb;
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = (ct0 + mi) * 32 + 8 * g + 4 * (lane >> 5);
+                        if (co >= a.cout) continue;
+                        f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
+                        v += *(const f32x4*)(a.bias + co);
+                        if (har) v += nv[mi][g] + *(const f32x4*)(a.bn + co);  // x + (noise_conv + its bias), nsf.py:173-174
+                        else if (addend) v += nv[mi][g];                       // the addend already carries the noise bias
+                        *(f32x4*)(out + (size_t)t * a.cout + co) = v;
                     }
-                    if (!(a.dbg & 16)) *(f32x4*)(out + (size_t)t * a.cout + co) = v;
-                }
             }
         }
     }
@@ -935,35 +992,6 @@ struct RbFullArgs {
 
 constexpr int RBF_G = 32;   // zero guard rows around X (>= max dilated half-width + one padded tap)
 constexpr int RBF_G2 = 8;   // zero guard rows around H
-
-// Branch-free helpers.  lrelu as max(x, slope*x) (0 < slope < 1); row masking by AND-ing the value bits so that
-// the compiler cannot turn the select into divergent control flow (it did: ~45 exec-masked blocks per publish).
-__device__ __forceinline__ float lrelu_max(float v, float slope) { return fmaxf(v, v * slope); }
-__device__ __forceinline__ float mask_bits(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
-
-// acc (MFMA D layout) -> lrelu -> OpT -> LDS operand tile.  `base` already points at this lane's (row, 4*(lane>>5))
-// element of the wave's first row; everything else is a compile-time offset.
-template <typename OpT, int C, int MI, int NJ, int STRIDE, bool MASK>
-__device__ __forceinline__ void publish_operand(char* base, const f32x16 (&acc)[MI][NJ], const unsigned (&rowmask)[NJ]) {
-    using o4 = __attribute__((ext_vector_type(4))) OpT;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int jt = 0; jt < NJ; ++jt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (mi * 32 + 8 * g < C) {  // folds to a constant once the loops are unrolled
-                    o4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = lrelu_max(acc[mi][jt][4 * g + e], 0.1f);
-                        if constexpr (MASK) v = mask_bits(v, rowmask[jt]);
-                        o[e] = to_op<OpT>(v);
-                    }
-                    *(o4*)(base + jt * 32 * STRIDE + (mi * 32 + 8 * g) * 2) = o;
-                }
-            }
-}
 
 template <typename OpT, int C, int MI, int NJ, int KG, int NB>
 __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
