@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
                                               const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
                                               const float* __restrict__ vecs, int64_t nq, int d, int k,
                                               float* __restrict__ D, int64_t* __restrict__ I, int64_t* __restrict__ P,
-                                              int* __restrict__ any_short) {
+                                              int* __restrict__ any_short, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int64_t qi = blockIdx.x;
     float* qs = (float*)smem_raw;
@@ -214,12 +214,12 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int c = c0 + 16 * u;
-                    v[u] = c < d4 ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[u] = (c < d4 && !(dbg & 2)) ? row[c] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int c = c0 + 16 * u;
-                    if (c < d4) {
+                    if (c < d4 && !(dbg & 1)) {
                         const float4 qq = *(const float4*)(qs + c * 4);
                         double t0 = (double)qq.x - (double)v[u].x, t1 = (double)qq.y - (double)v[u].y;
                         double t2 = (double)qq.z - (double)v[u].z, t3 = (double)qq.w - (double)v[u].w;
@@ -231,14 +231,16 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
                 }
             }
             for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-            topk_insert(t, acc, ids[r], r);
+            if (dbg & 1) acc = (double)(r & 1023);
+            if (!(dbg & 4)) topk_insert(t, acc, ids[r], r);
+            else if (acc < t.d[0]) { t.d[0] = acc; t.id[0] = r; t.pos[0] = r; }
         }
     }
     if (sub == 0) merge[grp] = t;
     __syncthreads();
     // 16 sorted lists x 8 = 128 candidates; thread i ranks candidate i against all others (broadcast LDS reads)
     // under the strict order (distance, id, slot) and, if it lands in the first k, writes that output slot.
-    if (threadIdx.x < SCAN_GROUPS * KMAX) {
+    if (threadIdx.x < SCAN_GROUPS * KMAX && !(dbg & 8)) {
         const int me = threadIdx.x;
         const int mg = me / KMAX, ms = me % KMAX;
         const double md = merge[mg].d[ms];
@@ -588,7 +590,8 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
     const size_t smem = align_up((size_t)d * 4, 16) + SCAN_GROUPS * sizeof(TopK);
     h->prof.launch("ivf_scan", 3.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
         hipLaunchKernelGGL(k_scan, dim3((unsigned)nq), dim3(256), smem, st, q, h->assign.as<int64_t>(), np,
-                           h->list_off(), h->ids(), h->vecs(), nq, d, k, D, I, h->P.as<int64_t>(), h->flag.as<int>());
+                           h->list_off(), h->ids(), h->vecs(), nq, d, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(),
+                           getenv("RVCMI_IVF_DBG") ? atoi(getenv("RVCMI_IVF_DBG")) : 0);
     });
     HIP_CHECK(hipGetLastError());
 }

@@ -368,10 +368,14 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
             // noise_convs[i] (nsf.py:103-115) is Conv1d(1, C, k=2s, stride s, pad s/2): over frames of s samples it is
             // a plain 2-tap conv with C_in = s, so it runs on the MFMA path.  s % 8 == 0 keeps every 8-sample
             // chunk entirely inside or outside the signal and 16-byte aligned.
+            // (hs % 8 == 0, hpad = hs/2 and Lin % 4 == 0 make every 4-sample half either fully inside or fully
+            // outside the signal; an 8-sample chunk may straddle its start/end, so validity is per half.)
             const long base = (long)gr * a.hs - a.hpad + c8 * 8;
-            if (c8 * 8 < a.hs && base >= 0 && base + 8 <= a.Lin) {
-                const float4* p = (const float4*)((const float*)a.in + (size_t)b * a.in_bstride + base);
-                const float4 lo = p[0], hi = p[1];
+            if (c8 * 8 < a.hs) {
+                const float* hp = (const float*)a.in + (size_t)b * a.in_bstride;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 lo = (base >= 0 && base + 4 <= a.Lin) ? *(const float4*)(hp + base) : z4;
+                const float4 hi = (base + 4 >= 0 && base + 8 <= a.Lin) ? *(const float4*)(hp + base + 4) : z4;
                 const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(f[e]);
@@ -447,40 +451,35 @@ __device__ __forceinline__ void conv_run(f32x16 (&acc)[MI][NJ], typename Op<OpT>
     constexpr int STRIDE = TL::STRIDE;
     static_assert((CC >= KGROUP) ? (CC % KGROUP == 0) : (KGROUP % CC == 0), "k-group must tile a tap");
     static_assert(NB >= 2 && NB <= 4, "2..4 weight buffers");
+    static_assert(KGROUP % 2 == 0, "the B ping-pong needs an even k-group");
     const int NG = ntaps_p * CC / KGROUP;
+    const int NK = NG * KGROUP;
 
+    // B fragments ping-pong between two register sets with COMPILE-TIME indices (k & 1): the ds_reads of k-step s+1
+    // are issued before the MFMAs of k-step s, so with one wave per SIMD the ~128-cycle LDS latency is covered by
+    // the 32*MI*NJ cycles of MFMA issue instead of being exposed once per k-step.
+    frag Bf[2][NJ];
+    auto readB = [&](frag(&B)[NJ], int ks) {
+        const int tap = ks / CC, cc = ks - tap * CC;
+        const char* bp = lds_lane + (roff + tap * dstep) * STRIDE + cc * 32;
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) B[jt] = *(const frag*)(bp + jt * 32 * STRIDE);
+    };
+    readB(Bf[0], 0);
     for (int grp = 0; grp < NG; grp += NB) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int g = grp + u;
             if (g < NG) {
                 if (g + NB - 1 < NG) conv_load_group<OpT, MI, KGROUP, NB>(A[(u + NB - 1) % NB], wlane, ct_stride, g + NB - 1);
-                int tap0, cc0;
-                if constexpr (CC >= KGROUP) {
-                    tap0 = (g * KGROUP) / CC;
-                    cc0 = (g * KGROUP) % CC;
-                } else {
-                    tap0 = g * (KGROUP / CC);
-                    cc0 = 0;
-                }
 #pragma unroll
                 for (int k = 0; k < KGROUP; ++k) {
-                    int tap, cc;
-                    if constexpr (CC >= KGROUP) {
-                        tap = tap0;
-                        cc = cc0 + k;
-                    } else {
-                        tap = tap0 + k / CC;
-                        cc = k % CC;
-                    }
-                    const char* bp = lds_lane + (roff + tap * dstep) * STRIDE + cc * 32;
-                    frag B[NJ];
-#pragma unroll
-                    for (int jt = 0; jt < NJ; ++jt) B[jt] = *(const frag*)(bp + jt * 32 * STRIDE);
+                    const int ks = g * KGROUP + k;
+                    readB(Bf[(k + 1) & 1], min(ks + 1, NK - 1));  // (the very last one re-reads a valid tile; unused)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int jt = 0; jt < NJ; ++jt) acc[mi][jt] = Op<OpT>::mfma(A[u][k][mi], B[jt], acc[mi][jt]);
+                        for (int jt = 0; jt < NJ; ++jt) acc[mi][jt] = Op<OpT>::mfma(A[u][k][mi], Bf[k & 1][jt], acc[mi][jt]);
                 }
             }
         }
