@@ -31,7 +31,9 @@ struct BlobHeader {  // first 128 bytes of the device blob; everything the kerne
     uint64_t off_centroids, off_list_offsets, off_ids, off_vecs;
     uint64_t total_bytes;
     uint64_t off_centroids_t;  // [d/4][nlist] float4: the coarse pass reads it lane-per-centroid, coalesced
-    uint64_t reserved[4];
+    uint64_t off_cnorm;        // [nlist] fp32(|c|^2) (rounded from fp64) for the fp32 prefilter
+    double cmax;               // max |c| over the centroids (error bound of the prefilter)
+    uint64_t reserved[2];
 };
 static_assert(sizeof(BlobHeader) == 128, "blob header must be 128 bytes");
 static const uint64_t kMagic = 0x465649494d435652ull;  // "RVCMIIVF" little-endian
@@ -112,6 +114,114 @@ __global__ void __launch_bounds__(256) k_coarse1(const float* __restrict__ q, co
         }
         assign[q0 + k] = biv;
     }
+}
+
+// ---- nprobe == 1 fast path: fp32 prefilter on the exact-fp32 MFMA, fp64 verification of the near-ties -------------
+//
+// k_coarse_gemm: S[q][c] = fl32(|c|^2) - 2*dot32(q, c) with v_mfma_f32_32x32x2_f32 (an fmaf chain, so the classic
+// dot-product error bound holds: |err| <= d*u*|q||c|, u = 2^-24).  Block = 64 queries x 128 centroids, K chunks of 32
+// staged in LDS (row stride 33 floats: conflict-free ds_read_b32 for both operands).
+constexpr int CG_Q = 64, CG_C = 128, CG_K = 32, CG_S = 33;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+__global__ void __launch_bounds__(256) k_coarse_gemm(const float* __restrict__ q, const float* __restrict__ cent,
+                                                     const float* __restrict__ cn, int64_t nq, int64_t nlist, int d,
+                                                     float* __restrict__ S) {
+    __shared__ float Qs[CG_Q * CG_S];
+    __shared__ float Cs[CG_C * CG_S];
+    const int64_t q0 = (int64_t)blockIdx.y * CG_Q, c0 = (int64_t)blockIdx.x * CG_C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
+    for (int k0 = 0; k0 < d; k0 += CG_K) {
+        // stage 64 query rows and 128 centroid rows x 32 floats (clamped rows: unconditional loads)
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+            const int idx = threadIdx.x + it * 256;  // 0 .. 1535 float4 slots
+            const int row = idx >> 3, c4 = idx & 7;
+            const int kk = k0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < CG_Q) {
+                const int64_t qr = min(q0 + row, nq - 1);
+                if (kk < d) v = *(const float4*)(q + qr * d + kk);
+                float* dst = Qs + row * CG_S + c4 * 4;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            } else {
+                const int cr_ = row - CG_Q;
+                const int64_t cr = min(c0 + cr_, nlist - 1);
+                if (kk < d) v = *(const float4*)(cent + cr * d + kk);
+                float* dst = Cs + cr_ * CG_S + c4 * 4;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+        }
+        __syncthreads();
+        const float* qa = Qs + (lane & 31) * CG_S + (lane >> 5);
+        const float* cb = Cs + (wave * 32 + (lane & 31)) * CG_S + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < CG_K / 2; ++ks) {
+            const float a0 = qa[2 * ks], a1 = qa[32 * CG_S + 2 * ks], b = cb[2 * ks];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int64_t c = c0 + wave * 32 + (lane & 31);
+    if (c < nlist) {
+        const float cnc = cn[c];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t qr = q0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (qr < nq) S[qr * nlist + c] = cnc - 2.f * acc[mi][r];
+            }
+    }
+}
+
+// k_coarse_pick: one wave per query.  m = min_c S[q][c]; every centroid with S <= m + margin is a candidate
+// (margin = 2 * rigorous rounding bound, so the exact winner is always among them -- usually alone); candidates are
+// re-evaluated cooperatively in fp64 as sum((q-c)^2) and the exact (distance, id) minimum wins.
+__global__ void __launch_bounds__(256) k_coarse_pick(const float* __restrict__ q, const float* __restrict__ cent,
+                                                     const float* __restrict__ S, int64_t nq, int64_t nlist, int d, double cmax,
+                                                     int64_t* __restrict__ assign) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= nq) return;
+    const float* row = S + qi * nlist;
+    const float* qp = q + qi * d;
+    double qn2 = 0.0;
+    for (int e = lane; e < d; e += 64) qn2 = fma((double)qp[e], (double)qp[e], qn2);
+    float m = INFINITY;
+    for (int64_t c = lane; c < nlist; c += 64) m = fminf(m, row[c]);
+    for (int off = 32; off >= 1; off >>= 1) {
+        qn2 += __shfl_xor(qn2, off, 64);
+        m = fminf(m, __shfl_xor(m, off, 64));
+    }
+    // |S_hat - S| <= (2d+4) u (|q| cmax + cmax^2), u = 2^-24; two such errors separate a false winner from the true one
+    const double E = (2.0 * d + 4.0) * 5.9604644775390625e-08 * (sqrt(qn2) * cmax + cmax * cmax);
+    const float thr = (float)((double)m + 2.0 * E + 1e-30) ;
+    const float thr_up = __uint_as_float(__float_as_uint(fabsf(thr)) + 2u);  // round the threshold outwards
+    const float lim = thr >= 0.f ? thr_up : -__uint_as_float(__float_as_uint(fabsf(thr)) - 2u);
+    double best = INFINITY;
+    int64_t besti = INT64_MAX;
+    for (int64_t c0 = 0; c0 < nlist; c0 += 64) {
+        const int64_t c = c0 + lane;
+        const bool cand = c < nlist && row[c] <= lim;
+        unsigned long long mask = __ballot(cand);
+        while (mask) {
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float* cp = cent + (c0 + b) * d;
+            double acc = 0.0;
+            for (int e = lane; e < d; e += 64) {
+                const double t = (double)qp[e] - (double)cp[e];
+                acc = fma(t, t, acc);
+            }
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (acc < best || (acc == best && c0 + b < besti)) { best = acc; besti = c0 + b; }
+        }
+    }
+    if (lane == 0) assign[qi] = besti;
 }
 
 // General nprobe: full fp64 distance rows into scratch, then one wave per query extracts the nprobe
@@ -267,6 +377,88 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
     }
 }
 
+// Specialised scan for d = 64*V (V = 12 for the 768-d v2 index, 4 for the 256-d v1 index): the query chunk of each
+// lane lives in registers, every load of TWO rows is in flight before anything is consumed (one memory round trip per
+// pair of rows instead of three per row), row indices are clamped so no load sits behind a branch.
+template <int V>
+__global__ void __launch_bounds__(256) k_scan_v(const float* __restrict__ q, const int64_t* __restrict__ assign, int nprobe,
+                                                const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
+                                                const float* __restrict__ vecs, int64_t nq, int k, float* __restrict__ D,
+                                                int64_t* __restrict__ I, int64_t* __restrict__ P, int* __restrict__ any_short) {
+    constexpr int d = 64 * V;
+    constexpr int RU = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    TopK* merge = (TopK*)smem_raw;
+    const int64_t qi = blockIdx.x;
+    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    float4 qv[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) qv[i] = *(const float4*)(q + qi * d + (sub + 16 * i) * 4);
+    TopK t;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { t.d[s] = INFINITY; t.id[s] = INT64_MAX; t.pos[s] = -1; }
+    for (int p = 0; p < nprobe; ++p) {
+        const int64_t l = assign[qi * nprobe + p];
+        if (l < 0) continue;
+        const int64_t beg = list_off[l], end = list_off[l + 1];
+        if (end <= beg) continue;
+        for (int64_t r0 = beg + grp; r0 < end; r0 += SCAN_GROUPS * RU) {
+            float4 v[RU][V];
+            int64_t rr[RU], idv[RU];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                rr[u] = r0 + u * SCAN_GROUPS;
+                const int64_t rc = rr[u] < end ? rr[u] : end - 1;  // clamped: loads stay unconditional
+                const float4* row = (const float4*)(vecs + rc * d);
+#pragma unroll
+                for (int i = 0; i < V; ++i) v[u][i] = row[sub + 16 * i];
+                idv[u] = ids[rc];
+            }
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    const double t0 = (double)qv[i].x - (double)v[u][i].x, t1 = (double)qv[i].y - (double)v[u][i].y;
+                    const double t2 = (double)qv[i].z - (double)v[u][i].z, t3 = (double)qv[i].w - (double)v[u][i].w;
+                    acc = fma(t0, t0, acc);
+                    acc = fma(t1, t1, acc);
+                    acc = fma(t2, t2, acc);
+                    acc = fma(t3, t3, acc);
+                }
+                for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                if (rr[u] < end) topk_insert(t, acc, idv[u], rr[u]);
+            }
+        }
+    }
+    if (sub == 0) merge[grp] = t;
+    __syncthreads();
+    if (threadIdx.x < SCAN_GROUPS * KMAX) {
+        const int me = threadIdx.x;
+        const int mg = me / KMAX, ms = me % KMAX;
+        const double md = merge[mg].d[ms];
+        const int64_t mid = merge[mg].id[ms];
+        int rank = 0;
+        for (int o = 0; o < SCAN_GROUPS * KMAX; ++o) {
+            const double od = merge[o / KMAX].d[o % KMAX];
+            const int64_t oid = merge[o / KMAX].id[o % KMAX];
+            rank += (od < md || (od == md && (oid < mid || (oid == mid && o < me)))) ? 1 : 0;
+        }
+        if (rank < k) {
+            if (mid == INT64_MAX) {
+                D[qi * k + rank] = FLT_MAX;
+                I[qi * k + rank] = -1;
+                P[qi * k + rank] = -1;
+                atomicOr(any_short, 1);
+            } else {
+                D[qi * k + rank] = (float)md;
+                I[qi * k + rank] = mid;
+                P[qi * k + rank] = merge[mg].pos[ms];
+            }
+        }
+    }
+}
+
 // pipeline.py:129-138 with numpy's fp32 operation order:
 //   weight = np.square(1/score); weight /= weight.sum(axis=1, keepdims=True)      (pairwise sum of 8)
 //   npy = np.sum(big_npy[ix] * weight[..., None], axis=1)                          (sequential over k)
@@ -318,10 +510,12 @@ struct rvcmi_ivf {
     // search workspace (grown on demand; see rvcmi_ivf_reserve)
     int64_t cap_nq = 0;
     int cap_nprobe = 0;
-    DevBuf assign, P, Dtmp, Itmp, flag, cdist;
+    DevBuf assign, P, Dtmp, Itmp, flag, cdist, cscore;
+    int64_t cap_chunk = 0;  // queries per coarse-score chunk (bounds the nq x nlist fp32 scratch)
     Profiler prof;
     const float* centroids() const { return (const float*)(blob + hdr.off_centroids); }
     const float4* centroids_t() const { return (const float4*)(blob + hdr.off_centroids_t); }
+    const float* cnorm() const { return (const float*)(blob + hdr.off_cnorm); }
     const int64_t* list_off() const { return (const int64_t*)(blob + hdr.off_list_offsets); }
     const int64_t* ids() const { return (const int64_t*)(blob + hdr.off_ids); }
     const float* vecs() const { return (const float*)(blob + hdr.off_vecs); }
@@ -367,11 +561,24 @@ static std::vector<char> build_blob(int d, int64_t n, int64_t nlist, int nprobe,
     off = align_up(off + (uint64_t)std::max<int64_t>(n, 1) * d * 4, 256);
     h.off_centroids_t = off;
     off = align_up(off + (uint64_t)nlist * d * 4, 256);
+    h.off_cnorm = off;
+    off = align_up(off + (uint64_t)nlist * 4, 256);
     h.total_bytes = off;
     std::vector<char> blob(off, 0);
     memcpy(blob.data(), &h, sizeof(h));
     memcpy(blob.data() + h.off_centroids, centroids, (size_t)nlist * d * 4);
     memcpy(blob.data() + h.off_list_offsets, list_offsets, (size_t)(nlist + 1) * 8);
+    {
+        float* cnp = (float*)(blob.data() + h.off_cnorm);
+        double cmax2 = 0.0;
+        for (int64_t c = 0; c < nlist; ++c) {
+            double n2 = 0.0;
+            for (int e = 0; e < d; ++e) n2 += (double)centroids[c * d + e] * (double)centroids[c * d + e];
+            cnp[c] = (float)n2;
+            cmax2 = std::max(cmax2, n2);
+        }
+        ((BlobHeader*)blob.data())->cmax = std::sqrt(cmax2);
+    }
     {
         float* ct = (float*)(blob.data() + h.off_centroids_t);
         const int d4 = d / 4;
@@ -548,7 +755,8 @@ static void write_faiss(const rvcmi_ivf* h, const char* path) {
 
 static void reserve(rvcmi_ivf* h, int64_t nq) {
     const int np = (int)std::min<int64_t>(h->hdr.nprobe, h->hdr.nlist);
-    if (nq <= h->cap_nq && np <= h->cap_nprobe && h->flag.p) return;
+    const bool have_scores = np > 1 || (h->cscore.p && h->cap_chunk > 0);
+    if (nq <= h->cap_nq && np <= h->cap_nprobe && h->flag.p && have_scores) return;
     HIP_CHECK(hipSetDevice(h->device));
     nq = std::max<int64_t>(nq, h->cap_nq);
     h->assign.alloc((size_t)std::max<int64_t>(nq, 1) * np * 8);
@@ -557,6 +765,11 @@ static void reserve(rvcmi_ivf* h, int64_t nq) {
     h->Itmp.alloc((size_t)std::max<int64_t>(nq, 1) * KMAX * 8);
     if (!h->flag.p) h->flag.alloc(256);
     if (np > 1) h->cdist.alloc((size_t)std::max<int64_t>(nq, 1) * h->hdr.nlist * 8);
+    else {
+        const int64_t per = std::max<int64_t>(64, (int64_t)(512ll << 20) / (h->hdr.nlist * 4));  // <= 512 MiB of scores
+        h->cap_chunk = std::min<int64_t>(std::max<int64_t>(nq, 1), per);
+        h->cscore.alloc((size_t)h->cap_chunk * h->hdr.nlist * 4);
+    }
     h->cap_nq = nq;
     h->cap_nprobe = np;
 }
@@ -571,7 +784,20 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
     const int np = (int)std::min<int64_t>(b.nprobe, b.nlist);
     HIP_CHECK(hipMemsetAsync(h->flag.p, 0, 4, st));
     const double cflops = 3.0 * (double)nq * b.nlist * d;
-    if (np == 1) {
+    if (np == 1 && !getenv("RVCMI_IVF_COARSE_F64")) {
+        // fp32 MFMA prefilter + fp64 verification (exactly the fp64 argmin; see k_coarse_pick)
+        h->prof.launch("ivf_coarse", 2.0 * (double)nq * b.nlist * d, (double)nq * d * 4 + (double)b.nlist * d * 4 + 2.0 * nq * b.nlist * 4, st, [&] {
+            if (h->cap_chunk <= 0 || !h->cscore.p) RVCMI_FAIL(RVCMI_ERR_INVALID, "coarse score scratch not reserved");
+            for (int64_t qs = 0; qs < nq; qs += h->cap_chunk) {
+                const int64_t nqc = std::min<int64_t>(h->cap_chunk, nq - qs);
+                dim3 grid((unsigned)((b.nlist + CG_C - 1) / CG_C), (unsigned)((nqc + CG_Q - 1) / CG_Q));
+                hipLaunchKernelGGL(k_coarse_gemm, grid, dim3(256), 0, st, q + qs * d, h->centroids(), h->cnorm(), nqc, b.nlist, d,
+                                   h->cscore.as<float>());
+                hipLaunchKernelGGL(k_coarse_pick, dim3((unsigned)((nqc + 3) / 4)), dim3(256), 0, st, q + qs * d, h->centroids(),
+                                   h->cscore.as<float>(), nqc, b.nlist, d, b.cmax, h->assign.as<int64_t>() + qs);
+            }
+        });
+    } else if (np == 1) {
         const size_t smem = align_up((size_t)QT * d * 4, 16) + 4 * QT * 16;
         h->prof.launch("ivf_coarse", cflops, (double)nq * d * 4 + (double)b.nlist * d * 4, st, [&] {
             hipLaunchKernelGGL(k_coarse1, dim3((unsigned)((nq + QT - 1) / QT)), dim3(256), smem, st, q, h->centroids_t(), nq,
@@ -589,6 +815,17 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
     const double rows = b.nlist ? (double)b.ntotal / (double)b.nlist * np : 0;
     const size_t smem = align_up((size_t)d * 4, 16) + SCAN_GROUPS * sizeof(TopK);
     h->prof.launch("ivf_scan", 3.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
+        const size_t sm2 = SCAN_GROUPS * sizeof(TopK);
+        if (d == 768 && !getenv("RVCMI_IVF_GENERIC")) {
+            hipLaunchKernelGGL(k_scan_v<12>, dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
+                               h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>());
+            return;
+        }
+        if (d == 256 && !getenv("RVCMI_IVF_GENERIC")) {
+            hipLaunchKernelGGL(k_scan_v<4>, dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
+                               h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>());
+            return;
+        }
         hipLaunchKernelGGL(k_scan, dim3((unsigned)nq), dim3(256), smem, st, q, h->assign.as<int64_t>(), np,
                            h->list_off(), h->ids(), h->vecs(), nq, d, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(),
                            getenv("RVCMI_IVF_DBG") ? atoi(getenv("RVCMI_IVF_DBG")) : 0);

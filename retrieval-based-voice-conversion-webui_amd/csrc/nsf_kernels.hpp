@@ -441,10 +441,16 @@ __device__ __forceinline__ void conv_prefetch(typename Op<OpT>::frag (&A)[NB][KG
         if (i < NG) conv_load_group<OpT, MI, KGROUP, NB>(A[i], wlane, ct_stride, i);
 }
 
+// One wave per SIMD issues in order, so every non-MFMA instruction must sit in the 32-cycle shadow of an MFMA:
+//   * B addresses are a running per-group base + compile-time immediates (no per-k-step scalar math),
+//   * every load is unconditional (clamped indices instead of branches, so a whole k-group is one scheduling region),
+//   * the ds_reads of the NEXT k-step and the global weight loads of group g+NB-1 are spread one per MFMA and the
+//     order is pinned with sched_group_barrier (MFMA, DS_READ, MFMA, DS_READ, ..., MFMA, VMEM, ...).
+// Measured in tools/ubench/kloop.hip (C=64, k=7): 58.5 -> see DESIGN.md cycles per MFMA.
 template <typename OpT, int CIN, int MI, int NJ, int KGROUP, int NB>
 __device__ __forceinline__ void conv_run(f32x16 (&acc)[MI][NJ], typename Op<OpT>::frag (&A)[NB][KGROUP][MI],
                                          const char* lds_lane, const OpT* wlane, long ct_stride, int ntaps_p, int roff,
-                                         int dstep) {
+                                         int dstep, int dbg = 0) {
     using frag = typename Op<OpT>::frag;
     using TL = Tile<CIN>;
     constexpr int CC = TL::CC;
@@ -452,34 +458,61 @@ __device__ __forceinline__ void conv_run(f32x16 (&acc)[MI][NJ], typename Op<OpT>
     static_assert((CC >= KGROUP) ? (CC % KGROUP == 0) : (KGROUP % CC == 0), "k-group must tile a tap");
     static_assert(NB >= 2 && NB <= 4, "2..4 weight buffers");
     static_assert(KGROUP % 2 == 0, "the B ping-pong needs an even k-group");
+    constexpr int GPT = (CC >= KGROUP) ? CC / KGROUP : 1;  // k-groups per tap
+    constexpr int TPG = (CC >= KGROUP) ? 1 : KGROUP / CC;  // taps per k-group
     const int NG = ntaps_p * CC / KGROUP;
-    const int NK = NG * KGROUP;
+    const int dS = dstep * STRIDE;
+    (void)dbg;
 
-    // B fragments ping-pong between two register sets with COMPILE-TIME indices (k & 1): the ds_reads of k-step s+1
-    // are issued before the MFMAs of k-step s, so with one wave per SIMD the ~128-cycle LDS latency is covered by
-    // the 32*MI*NJ cycles of MFMA issue instead of being exposed once per k-step.
-    frag Bf[2][NJ];
-    auto readB = [&](frag(&B)[NJ], int ks) {
-        const int tap = ks / CC, cc = ks - tap * CC;
-        const char* bp = lds_lane + (roff + tap * dstep) * STRIDE + cc * 32;
+    // byte offset of k-step k of a group relative to the group base
+    auto koff = [&](int k) { return (CC >= KGROUP) ? k * 32 : (k / CC) * dS + (k % CC) * 32; };
+    auto readB = [&](frag(&B)[NJ], const char* base, int k) {
+        const char* bp = base + koff(k);
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) B[jt] = *(const frag*)(bp + jt * 32 * STRIDE);
     };
-    readB(Bf[0], 0);
+
+    const char* gb = lds_lane + roff * STRIDE;  // B base of the current group
+    int gi = 0;                                 // group index inside the current tap (CC >= KGROUP only)
+    const OpT* an = wlane + (size_t)min(NB - 1, NG - 1) * KGROUP * 512;  // weights of the group to request next
+    int gn = min(NB - 1, NG - 1);
+
+    frag Bf[2][NJ];
+    readB(Bf[0], gb, 0);
     for (int grp = 0; grp < NG; grp += NB) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int g = grp + u;
             if (g < NG) {
-                if (g + NB - 1 < NG) conv_load_group<OpT, MI, KGROUP, NB>(A[(u + NB - 1) % NB], wlane, ct_stride, g + NB - 1);
+                const char* gbn;
+                if constexpr (CC >= KGROUP) gbn = (gi + 1 == GPT) ? gb - (GPT - 1) * KGROUP * 32 + dS : gb + KGROUP * 32;
+                else gbn = gb + TPG * dS;
 #pragma unroll
                 for (int k = 0; k < KGROUP; ++k) {
-                    const int ks = g * KGROUP + k;
-                    readB(Bf[(k + 1) & 1], min(ks + 1, NK - 1));  // (the very last one re-reads a valid tile; unused)
+                    // next k-step's B fragments (first k-step of the next group at the group boundary; past the very
+                    // last group this reads a few rows beyond the tile -- in-bounds of LDS or zero, never used)
+                    if (k + 1 < KGROUP) readB(Bf[(k + 1) & 1], gb, k + 1);
+                    else readB(Bf[0], gbn, 0);
+                    // MI of the KGROUP*MI weight fragments of group g+NB-1 (clamped: re-requests the last group at the tail)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        A[(u + NB - 1) % NB][k][mi] = *(const frag*)(an + (size_t)mi * ct_stride + k * 512);
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                         for (int jt = 0; jt < NJ; ++jt) acc[mi][jt] = Op<OpT>::mfma(A[u][k][mi], Bf[k & 1][jt], acc[mi][jt]);
+#pragma unroll
+                    for (int i = 0; i < MI * NJ; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // 1 MFMA
+                        if (i < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
+                        else if (i < NJ + MI) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+                    }
+                }
+                gb = gbn;
+                if constexpr (CC >= KGROUP) gi = (gi + 1 == GPT) ? 0 : gi + 1;
+                if (gn < NG - 1) {
+                    ++gn;
+                    an += KGROUP * 512;
                 }
             }
         }
@@ -1106,7 +1139,7 @@ __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
                         for (int e = 0; e < 4; ++e) hacc[mi][jt][4 * g + e] = bv[e];
                 }
         }
-        conv_run<OpT, C, MI, NJ, KG, NB>(hacc, A, xl, (const OpT*)J.w1[m] + lane * 8, J.ct1, J.k_p, RBF_G - p1, J.dil[m]);
+        conv_run<OpT, C, MI, NJ, KG, NB>(hacc, A, xl, (const OpT*)J.w1[m] + lane * 8, J.ct1, J.k_p, RBF_G - p1, J.dil[m], a.dbg);
         conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w2[m] + lane * 8, J.ct2, J.k_p);  // in flight across the publish + barrier
         if (m == 0) stamp();  // 4: conv1 done
         if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(hw, hacc, rowmask);
@@ -1128,7 +1161,7 @@ __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
                         for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] += bv[e];
                 }
         }
-        conv_run<OpT, C, MI, NJ, KG, NB>(xacc, A, hl, (const OpT*)J.w2[m] + lane * 8, J.ct2, J.k_p, RBF_G2 - p2, 1);
+        conv_run<OpT, C, MI, NJ, KG, NB>(xacc, A, hl, (const OpT*)J.w2[m] + lane * 8, J.ct2, J.k_p, RBF_G2 - p2, 1, a.dbg);
         if (m + 1 < J.nd) conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w1[m + 1] + lane * 8, J.ct1, J.k_p);
         if (m == 0) stamp();  // 7: conv2 done
         if (m + 1 < J.nd) {  // publish lrelu(x') for the next pair

@@ -1,0 +1,69 @@
+// Micro-benchmark of the generator's K loop (conv_prefetch / conv_run from nsf_kernels.hpp) in isolation:
+// one block of 4 waves per CU, each wave runs REPS convs of `k` taps on a resident LDS tile; reports cycles per MFMA.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../retrieval-based-voice-conversion-webui_amd/csrc/nsf_kernels.hpp"
+using namespace rvcmi;
+#ifndef VARIANT
+#define VARIANT 0
+#endif
+template <int C, int MI, int NJ, int KG, int NB>
+__global__ void __launch_bounds__(256, 1) kloop(const _Float16* w, long ct, int k_p, int dil, int reps, int dbg, float* out,
+                                                unsigned long long* ticks) {
+    using TL = Tile<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rows = 4 * 32 * NJ + 64;
+    for (int i = threadIdx.x; i < rows * TL::STRIDE / 4; i += 256) ((float*)smem)[i] = 0.001f * (i % 97);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const char* xl = smem + (size_t)(wave * 32 * NJ + (lane & 31)) * TL::STRIDE + (lane >> 5) * 16;
+    f32x16 acc[MI][NJ];
+    for (int mi = 0; mi < MI; ++mi) for (int jt = 0; jt < NJ; ++jt) for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
+    typename Op<_Float16>::frag A[NB][KG][MI];
+    conv_prefetch<_Float16, C, MI, KG, NB>(A, w + lane * 8, ct, k_p);
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int r = 0; r < reps; ++r) {
+        conv_run<_Float16, C, MI, NJ, KG, NB>(acc, A, xl, w + lane * 8, ct, k_p, 32 - dil * (k_p - 1) / 2, dil, dbg);
+        conv_prefetch<_Float16, C, MI, KG, NB>(A, w + lane * 8, ct, k_p);
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int mi = 0; mi < MI; ++mi) for (int jt = 0; jt < NJ; ++jt) for (int e = 0; e < 16; ++e) s += acc[mi][jt][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (lane == 0) ticks[blockIdx.x * 4 + wave] = t1 - t0;
+}
+template <int C, int MI, int NJ, int KG, int NB>
+void run(int k, int dil, int dbg) {
+    using TL = Tile<C>;
+    const int CC = C / 16;
+    const int tpg = CC >= KG ? 1 : KG / CC;
+    const int k_p = (k + tpg - 1) / tpg * tpg;
+    const long ct = (long)k_p * CC * 512;
+    std::vector<_Float16> hw((size_t)MI * ct);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = (_Float16)(0.01f * ((int)(i % 13) - 6));
+    _Float16* w; float* out; unsigned long long* ticks;
+    const int blocks = 256, reps = 200;
+    hipMalloc(&w, hw.size() * 2); hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    hipMalloc(&out, blocks * 256 * 4); hipMalloc(&ticks, blocks * 4 * 8);
+    const size_t smem = (size_t)(4 * 32 * NJ + 64) * TL::STRIDE;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&kloop<C, MI, NJ, KG, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB>), dim3(blocks), dim3(256), smem, 0, w, ct, k_p, dil, 2, dbg, out, ticks);
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB>), dim3(blocks), dim3(256), smem, 0, w, ct, k_p, dil, reps, dbg, out, ticks);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks * 4);
+    hipMemcpy(h.data(), ticks, h.size() * 8, hipMemcpyDeviceToHost);
+    double avg = 0; for (auto v : h) avg += v; avg /= h.size();
+    const double nm = (double)reps * k_p * CC * MI * NJ;
+    printf("C=%d MI=%d NJ=%d KG=%d NB=%d k=%d dil=%d dbg=%d: %.1f cycles/MFMA (%.0f cycles per conv)\n", C, MI, NJ, KG, NB, k, dil, dbg,
+           avg / nm, avg / reps);
+    hipFree(w); hipFree(out); hipFree(ticks);
+}
+int main() {
+    for (int dbg : {0, 64, 128, 192}) run<64, 2, 3, 4, 3>(7, 3, dbg);
+    for (int dbg : {0, 192}) run<32, 1, 6, 4, 3>(7, 3, dbg);
+    for (int dbg : {0, 192}) run<128, 2, 4, 4, 2>(7, 3, dbg);
+    return 0;
+}
