@@ -142,6 +142,8 @@ struct Stage {
     DevBuf noise_w, noise_b;
     ConvLayer nz;          // the same noise conv as a 2-tap MFMA conv over frames of `ns` samples (when ns % 8 == 0)
     bool nz_mfma = false;
+    DevBuf nz_k1_w;        // ... or, for windows of <= 16 samples, as ONE extra k-step inside k_ups
+    bool nz_k1 = false;
     // resblocks[j].pair[m] = {conv1, conv2}
     std::vector<std::vector<std::pair<ConvLayer, ConvLayer>>> rb;
 };
@@ -299,6 +301,21 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
                 build_conv(s.nz, cinp, s.cout, 1, &nt, &off, 1,
                            [=](int co, int ci, int, int tap) { return ci < ns ? wd[(size_t)co * nkk + tap * ns + ci] : 0.f; }, b.data, op);
                 s.nz_mfma = true;
+            } else if (op != RVCMI_OPERAND_F32 && s.nk >= 2 && s.nk <= 16 && s.ns % 2 == 0) {
+                const int ctiles = (s.cout + 31) / 32;
+                std::vector<uint16_t> pk((size_t)ctiles * 512, 0);
+                for (int ct = 0; ct < ctiles; ++ct)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = ct * 32 + (lane & 31), kk = 8 * (lane >> 5) + e;
+                            if (co < s.cout && kk < s.nk) {
+                                const float v = w.data[(size_t)co * s.nk + kk];
+                                pk[(size_t)ct * 512 + lane * 8 + e] = op == RVCMI_OPERAND_BF16 ? f32_to_bf16(v) : f32_to_f16(v);
+                            }
+                        }
+                s.nz_k1_w.alloc(pk.size() * 2);
+                HIP_CHECK(hipMemcpy(s.nz_k1_w.p, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+                s.nz_k1 = true;
             }
         }
         s.rb.resize(cfg->n_resblock_kernels);
@@ -446,7 +463,7 @@ static void set_lds_limits() {
 
 template <typename OpT, int C, int MI, int NW, int KG>
 static void launch_rb_inst(const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
-    const size_t smem = (size_t)rows * Tile<C>::STRIDE + 2 * 32 * MI * NW * 4;  // tile + the two bias vectors
+    const size_t smem = (size_t)rows * Tile<C>::STRIDE + 2 * 32 * MI * NW * 4 + NW * 64;  // tile + the two bias vectors + dev stamps
     if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "resblock LDS tile too large (%zu B)", smem);
     hipLaunchKernelGGL((k_rb_pair<OpT, C, MI, NW, KG>), dim3(tiles, nj, B), dim3(64 * NW), smem, st, ra);
 }
@@ -477,7 +494,7 @@ static void set_lds_rb() {
 template <typename OpT, int CIN, int MI, int WV>
 static void launch_ups_inst(const UpsArgs& a, int B, hipStream_t st) {
     constexpr int TQ = 32 * 4 * (4 / WV);
-    const size_t smem = (size_t)a.tile_rows * Tile<CIN>::STRIDE;
+    const size_t smem = (size_t)a.tile_rows * Tile<CIN>::STRIDE + (a.nz_k1 ? (size_t)(TQ * a.u * a.ns + 16) * 2 : 0);
     if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "upsampler LDS tile too large (%zu B)", smem);
     const int per_block = WV * a.vpw;
     dim3 grid((a.Lin + TQ - 1) / TQ, (a.nvt + per_block - 1) / per_block, B);
@@ -793,6 +810,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 run_conv(h, s.nz, na, B, nm, st);
                 ua.addend = h->NZ.as<float>();
             } else if (c.use_f0) {
+                ua.nz_k1 = s.nz_k1 ? 1 : 0;
+                ua.wnz = s.nz_k1_w.p;
                 ua.har = har;
                 ua.Lh = Te * upp;
                 ua.Wn = s.noise_w.as<float>();
@@ -809,7 +828,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             ua.tile_rows = TQ + (hi - lo);
             const long qtiles = (Lin + TQ - 1) / TQ;
             int vpw = (ua.nvt + wv - 1) / wv;  // everything in one block ...
-            while (vpw > 1 && qtiles * B * ((ua.nvt + wv * vpw - 1) / (wv * vpw)) < 512) --vpw;  // ... unless the grid would starve
+            while (vpw > 1 && qtiles * B * ((ua.nvt + wv * vpw - 1) / (wv * vpw)) < 300) --vpw;  // ... unless the grid would starve
             ua.vpw = vpw;
             snprintf(nm, sizeof(nm), "ups_c%d", s.cin);
             const double flops = U.flops_per_pos * (double)Lin * B + 2.0 * s.nk * (double)L * C * B;
@@ -978,7 +997,33 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
                     bytes += (double)B * L * C * 8 + 2.0 * J.k * C * C * 2;
                 }
+                const int NWp = C >= 64 ? C / 64 : 1;
+                const size_t nblk = (size_t)max_tiles * nj * B;
+                if (ra.dbg & 32) {
+                    if (h->dbg.bytes < nblk * NWp * 64) h->dbg.alloc(nblk * NWp * 64);
+                    HIP_CHECK(hipMemsetAsync(h->dbg.p, 0, nblk * NWp * 64, st));
+                    ra.ts = h->dbg.as<unsigned long long>();
+                }
                 h->prof.launch(nm, flops, bytes, st, [&] { launch_rb_pair(op, C, ra, max_tiles, nj, B, max_rows, st); });
+                if ((ra.dbg & 32) && m == 0) {  // dev only: per-phase cycles of pair level 0, per kernel size
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    std::vector<unsigned long long> ts(nblk * NWp * 8);
+                    HIP_CHECK(hipMemcpy(ts.data(), h->dbg.p, ts.size() * 8, hipMemcpyDeviceToHost));
+                    for (int oj = 0; oj < nj; ++oj) {
+                        double sum[8] = {0};
+                        long cnt = 0;
+                        for (int t = 0; t < ra.job[oj].ntiles; ++t)
+                            for (int w = 0; w < NWp; ++w) {
+                                const unsigned long long* p = &ts[(((size_t)oj * max_tiles + t) * NWp + w) * 8];
+                                if (!p[0]) continue;
+                                for (int i = 1; i < 8; ++i) sum[i] += (double)(p[i] - p[i - 1]);
+                                ++cnt;
+                            }
+                        fprintf(stderr, "[rvcmi ts] %s k=%d tiles=%d:", nm, ra.job[oj].k, ra.job[oj].ntiles);
+                        for (int i = 1; i < 8; ++i) fprintf(stderr, " %.0f", cnt ? sum[i] / cnt : 0.0);
+                        fprintf(stderr, "\n");
+                    }
+                }
                 for (int j = 0; j < nk; ++j)
                     if (dsts[j]) src[j] = dsts[j];
             }

@@ -666,7 +666,8 @@ struct RbPairArgs {
     RbJob job[4];
     int L;
     long bstride;
-    int dbg;  // timing ablations only (RVCMI_DBG): 1 skip staging loads, 2 skip conv1, 4 skip conv2, 8 skip residual read, 16 skip store
+    int dbg;  // timing ablations only (RVCMI_DBG): 2 skip conv1, 4 skip conv2, 16 skip store, 32 phase stamps
+    unsigned long long* ts;
 };
 
 constexpr int RB_ROWS = 128;  // conv1 output rows per tile = 4 MFMA column tiles per wave
@@ -694,6 +695,15 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
     const int xrows = RB_ROWS + (J.k_p - 1) * J.dil;
     const float* src = J.src + (size_t)b * a.bstride;
     float* bias_l = (float*)(smem + (size_t)xrows * STRIDE);  // [2][CP]: b1 then b2
+    unsigned long long* tsl = (unsigned long long*)(bias_l + 2 * CP);  // dev-only phase stamps (dbg & 32)
+    int tsn = 0;
+    auto stamp = [&]() {
+#ifdef RVCMI_DEV_STAMPS
+        if ((a.dbg & 32) && (threadIdx.x & 63) == 0 && tsn < 8) tsl[(threadIdx.x >> 6) * 8 + tsn] = __builtin_readcyclecounter();
+#endif
+        ++tsn;
+    };
+    stamp();  // 0
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -742,7 +752,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
         const int c = i % CP;
         bias_l[i] = c < C ? (i < CP ? J.b1[c] : J.b2[c]) : 0.f;
     }
+    stamp();  // 1: staged
     __syncthreads();
+    stamp();  // 2
 
     const char* lds_lane = smem + (size_t)(lane & 31) * STRIDE + (lane >> 5) * 16;
     f32x16 acc[MI][NJ];
@@ -764,6 +776,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
     if (!(a.dbg & 2))
         conv_run<OpT, C, MI, NJ, KG, NB>(acc, A, lds_lane, (const OpT*)J.w1 + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p, 0, J.dil);
     conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w2 + (size_t)ct0 * J.ct2 + lane * 8, J.ct2, J.k_p);  // across the barriers
+    stamp();  // 3: conv1 done
     __syncthreads();  // every wave has finished reading X
 
     // ---- 3. h = lrelu(conv1 + b1) -> OpT, in place over X (zero outside the utterance: conv2 pads ITS input) ----
@@ -779,13 +792,16 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
         if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(hw, acc, rowmask, ct0 * 32);
         else publish_operand<OpT, C, MI, NJ, STRIDE, true>(hw, acc, rowmask, ct0 * 32);
     }
+    stamp();  // 4: h published
     __syncthreads();
+    stamp();  // 5
 
     // ---- 4. conv2 (accumulators start from b2) -----------------------------------------------------------
     init_bias(bias_l + CP);
     if (!(a.dbg & 4))
         conv_run<OpT, C, MI, NJ, KG, NB>(acc, A, lds_lane, (const OpT*)J.w2 + (size_t)ct0 * J.ct2 + lane * 8, J.ct2, J.k_p, 0, 1);
 
+    stamp();  // 6: conv2 done
     // ---- 5. epilogue: x' = (conv2 + b2) + x --------------------------------------------------------------
     float* dst = J.dst + (size_t)b * a.bstride;
 #pragma unroll
@@ -816,6 +832,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
                 }
         }
     }
+    stamp();  // 7: stores issued
+#ifdef RVCMI_DEV_STAMPS
+    if ((a.dbg & 32) && (threadIdx.x & 63) < 8) {
+        const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        a.ts[(blk * NW + (threadIdx.x >> 6)) * 8 + (threadIdx.x & 63)] = tsl[(threadIdx.x >> 6) * 8 + (threadIdx.x & 63)];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -850,12 +873,14 @@ struct UpsArgs {
     const float* Wn;   // [nk][cout]
     const float* bn;
     int nk, ns, npad;
+    const void* wnz;   // nz_k1: noise weights packed as ONE MFMA k-step [co_tile][lane][8] (taps >= nk are zero)
+    int nz_k1;         // 1: the <=16-tap noise conv runs as one extra k-step fed from an fp16 copy of the har span in LDS
     int nvt, cog, vpw;
     int dbg;  // timing ablations only: 1 skip staging loads, 2 skip MFMA, 4 skip noise conv, 16 skip store
 };
 
 template <typename OpT, int CIN, int MI, int WV>
-__global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
+__global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks per CU: one block stages / stores while the other multiplies
     using TL = Tile<CIN>;
     using frag = typename Op<OpT>::frag;
     constexpr int STRIDE = TL::STRIDE;
@@ -863,7 +888,7 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
     constexpr int NJ = 4;
     constexpr int WT = 4 / WV;
     constexpr int TQ = 32 * NJ * WT;
-    constexpr int SB = 4;
+    constexpr int SB = 8;  // independent chunk loads (x up to 3 inputs) in flight per thread; the accumulators are not live yet
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.z;
     const int q0 = blockIdx.x * TQ;
@@ -915,6 +940,18 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
             *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
         }
     }
+    // nz_k1: fp16 copy of the excitation samples every output row of this block can touch (zero outside the signal)
+    OpT* har16 = (OpT*)(smem + (size_t)a.tile_rows * STRIDE);
+    const int us = a.u * a.ns;
+    if (a.nz_k1) {
+        const long hbase = (long)q0 * us - a.npad;
+        const float* hp = a.har + (size_t)b * a.Lh;
+        const int span = TQ * us + 16;
+        for (int i = threadIdx.x; i < span; i += 256) {
+            const long idx = hbase + i;
+            har16[i] = (idx >= 0 && idx < a.Lh) ? to_op<OpT>(hp[idx]) : (OpT)0.f;
+        }
+    }
     __syncthreads();
 
     const int wave = threadIdx.x >> 6;
@@ -922,7 +959,7 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
     const int wv = wave % WV, wt = wave / WV;
     const int tw0 = wt * NJ * 32;
     const char* lds_lane = smem + (size_t)(tw0 + (lane & 31)) * STRIDE + (lane >> 5) * 16;
-    const float* har = a.har ? a.har + (size_t)b * a.Lh : nullptr;
+    const float* har = (a.har && !a.nz_k1) ? a.har + (size_t)b * a.Lh : nullptr;  // VALU noise path only
     float* out = a.out + (size_t)b * a.out_bstride;
 
     for (int i = 0; i < a.vpw; ++i) {
@@ -939,6 +976,24 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
                 for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
         const OpT* wlane = (const OpT*)a.w + a.ph_w_off[r] + (size_t)ct0 * a.ct_stride + lane * 8;
         if (!(a.dbg & 2)) conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.ct_stride, a.ntaps_p, a.ph_in_off[r] - a.lo, -1);
+        if (a.nz_k1) {  // + noise_convs[i](har): one k-step, B = the row's 16-sample window (nsf.py:173-174)
+            frag An[MI], Bn[NJ];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) An[mi] = *(const frag*)((const OpT*)a.wnz + (size_t)(ct0 + mi) * 512 + lane * 8);
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                const int ql = tw0 + jt * 32 + (lane & 31);
+                const unsigned* wp = (const unsigned*)(har16 + ql * us + r * a.ns + 8 * (lane >> 5));  // 4-byte aligned (ns even)
+                union { unsigned u[4]; frag f; } cv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cv.u[e] = wp[e];
+                Bn[jt] = cv.f;
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) acc[mi][jt] = Op<OpT>::mfma(An[mi], Bn[jt], acc[mi][jt]);
+        }
 
         const float* addend = a.addend ? a.addend + (size_t)b * a.out_bstride : nullptr;
 #pragma unroll
@@ -981,6 +1036,7 @@ __global__ void __launch_bounds__(256) k_ups(UpsArgs a) {
                         v += *(const f32x4*)(a.bias + co);
                         if (har) v += nv[mi][g] + *(const f32x4*)(a.bn + co);  // x + (noise_conv + its bias), nsf.py:173-174
                         else if (addend) v += nv[mi][g];                       // the addend already carries the noise bias
+                        else if (a.nz_k1) v += *(const f32x4*)(a.bn + co);
                         *(f32x4*)(out + (size_t)t * a.cout + co) = v;
                     }
             }
@@ -1051,32 +1107,13 @@ __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
     const int half4 = 4 * (lane >> 5);
 
     int tsn = 0;
-    auto stamp = [&]() {  // dev-only: kept in LDS and flushed once at the end (a global store would sit in front of
-        if ((a.dbg & 32) && lane == 0 && tsn < 16) tsl[wave * 16 + tsn] = __builtin_readcyclecounter();  // barriers)
+    auto stamp = [&]() {  // dev-only (-DRVCMI_DEV_STAMPS): kept in LDS and flushed once at the end (a global store
+#ifdef RVCMI_DEV_STAMPS   // per stamp would sit in front of the next barrier's vmcnt(0))
+        if ((a.dbg & 32) && lane == 0 && tsn < 16) tsl[wave * 16 + tsn] = __builtin_readcyclecounter();
+#endif
         ++tsn;
     };
     stamp();  // 0
-
-    // zero the guard rows once (nobody writes them afterwards); stage every bias vector of the resblock in LDS
-    {
-        constexpr int W = STRIDE / 16;  // 16-byte words per row
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        for (int i = threadIdx.x; i < 2 * RBF_G * W; i += 256) {
-            const int r = i / W, c = i - r * W;
-            const int row = r < RBF_G ? r : RBF_G + R + (r - RBF_G);
-            *(uint4*)(X + (size_t)row * STRIDE + c * 16) = z;
-        }
-        for (int i = threadIdx.x; i < 2 * RBF_G2 * W; i += 256) {
-            const int r = i / W, c = i - r * W;
-            const int row = r < RBF_G2 ? r : RBF_G2 + R + (r - RBF_G2);
-            *(uint4*)(H + (size_t)row * STRIDE + c * 16) = z;
-        }
-        for (int i = threadIdx.x; i < J.nd * 2 * CP; i += 256) {
-            const int m = i / (2 * CP), w = (i / CP) & 1, c = i % CP;
-            const float* bp = w ? J.b2[m] : J.b1[m];
-            bias_l[i] = c < C ? bp[c] : 0.f;
-        }
-    }
 
     // Rows of this lane's NJ column tiles that lie outside the utterance must read as zero in every operand tile
     // (each conv zero-pads ITS input).  Interior tiles (the vast majority) skip the masking altogether.
@@ -1108,6 +1145,28 @@ __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
                 }
             }
         }
+    // (the x loads above are in flight while this runs) zero the guard rows once -- nobody writes them afterwards --
+    // and stage every bias vector of the resblock in LDS
+    {
+        constexpr int W = STRIDE / 16;  // 16-byte words per row
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < 2 * RBF_G * W; i += 256) {
+            const int r = i / W, c = i - r * W;
+            const int row = r < RBF_G ? r : RBF_G + R + (r - RBF_G);
+            *(uint4*)(X + (size_t)row * STRIDE + c * 16) = z;
+        }
+        for (int i = threadIdx.x; i < 2 * RBF_G2 * W; i += 256) {
+            const int r = i / W, c = i - r * W;
+            const int row = r < RBF_G2 ? r : RBF_G2 + R + (r - RBF_G2);
+            *(uint4*)(H + (size_t)row * STRIDE + c * 16) = z;
+        }
+        for (int i = threadIdx.x; i < J.nd * 2 * CP; i += 256) {
+            const int m = i / (2 * CP), w = (i / CP) & 1, c = i % CP;
+            const float* bp = w ? J.b2[m] : J.b1[m];
+            bias_l[i] = c < C ? bp[c] : 0.f;
+        }
+    }
+
     stamp();  // 1: x loaded
     typename Op<OpT>::frag A[NB][KG][MI];  // weight register ring, requested one phase ahead of its use
     conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w1[0] + lane * 8, J.ct1, J.k_p);
@@ -1194,10 +1253,12 @@ __global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
             }
     }
     stamp();  // 11: stores issued
+#ifdef RVCMI_DEV_STAMPS
     if ((a.dbg & 32) && lane < 16) {
         const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         a.ts[(blk * 4 + wave) * 16 + lane] = lane < tsn ? tsl[wave * 16 + lane] : 0ull;
     }
+#endif
 }
 
 }  // namespace rvcmi
