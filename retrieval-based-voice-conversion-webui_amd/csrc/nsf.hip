@@ -528,13 +528,19 @@ static void set_lds_ups() {
 }
 
 // ---- fully fused resblock (C <= 64) ----------------------------------------------------------------
+#ifndef RBF32_NJ
+#define RBF32_NJ 3
+#define RBF32_OCC 2
+#endif
 template <int C> struct RbFullGeom;
 // C=64 uses 3 column tiles per wave (R = 384): x(96) + h(96) accumulators + operands stay under 512 registers without spills
 // (NJ = 4 spilled ~100 registers to scratch)
-template <> struct RbFullGeom<64> { static constexpr int MI = 2, NJ = 3, KG = 4; };
-template <> struct RbFullGeom<32> { static constexpr int MI = 1, NJ = 6, KG = 4; };
-template <> struct RbFullGeom<16> { static constexpr int MI = 1, NJ = 6, KG = 4; };
-static int rbf_rows(int C) { return C == 64 ? 384 : 768; }
+template <> struct RbFullGeom<64> { static constexpr int MI = 2, NJ = 3, KG = 4, OCC = 1; };
+// C <= 32: R = 384 keeps the two operand tiles at 68 KB and the kernel under 256 registers => 2 blocks per CU, so one
+// block's load / publish / store phases overlap the other's MFMA phases (worth more than the extra overlap-save waste)
+template <> struct RbFullGeom<32> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC; };
+template <> struct RbFullGeom<16> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC; };
+static int rbf_rows(int C) { return C == 64 ? 384 : 4 * 32 * RBF32_NJ; }
 static int rbf_nb() {  // weight-prefetch depth (register buffers); RVCMI_NB overrides for A/B experiments
     const char* e = getenv("RVCMI_NB");
     const int v = e ? atoi(e) : 3;
@@ -546,9 +552,9 @@ static void launch_rbf_inst(const RbFullArgs& ra, int tiles, int nj, int B, hipS
     constexpr int R = 4 * 32 * G::NJ;
     const size_t smem = (size_t)(R + 2 * RBF_G + R + 2 * RBF_G2) * Tile<C>::STRIDE + 3 * 2 * 32 * G::MI * 4 + 512;  // + bias vectors + dev phase stamps
     const int nb = rbf_nb();
-    if (nb == 2) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 2>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
-    else if (nb == 3) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 3>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
-    else hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 4>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
+    if (nb == 2) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 2, G::OCC>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
+    else if (nb == 3) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 3, G::OCC>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
+    else hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 4, G::OCC>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
 }
 template <typename OpT>
 static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
@@ -562,7 +568,7 @@ static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, 
 template <typename OpT>
 static void set_lds_rbf() {
 #define RBF_ATTR1(C_, NB_)                                                                                                  \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, C_, RbFullGeom<C_>::MI, RbFullGeom<C_>::NJ, RbFullGeom<C_>::KG, NB_>), \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, C_, RbFullGeom<C_>::MI, RbFullGeom<C_>::NJ, RbFullGeom<C_>::KG, NB_, RbFullGeom<C_>::OCC>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define RBF_ATTR(C_) RBF_ATTR1(C_, 2) RBF_ATTR1(C_, 3) RBF_ATTR1(C_, 4)
     RBF_ATTR(64) RBF_ATTR(32) RBF_ATTR(16)

@@ -1081,8 +1081,8 @@ struct RbFullArgs {
 constexpr int RBF_G = 32;   // zero guard rows around X (>= max dilated half-width + one padded tap)
 constexpr int RBF_G2 = 8;   // zero guard rows around H
 
-template <typename OpT, int C, int MI, int NJ, int KG, int NB>
-__global__ void __launch_bounds__(256, 1) k_rb_full(RbFullArgs a) {
+template <typename OpT, int C, int MI, int NJ, int KG, int NB, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC) k_rb_full(RbFullArgs a) {
     using TL = Tile<C>;
     constexpr int STRIDE = TL::STRIDE;
     constexpr int SLAB = 32 * NJ;
