@@ -535,26 +535,35 @@ static void set_lds_ups() {
 template <int C> struct RbFullGeom;
 // C=64 uses 3 column tiles per wave (R = 384): x(96) + h(96) accumulators + operands stay under 512 registers without spills
 // (NJ = 4 spilled ~100 registers to scratch)
-template <> struct RbFullGeom<64> { static constexpr int MI = 2, NJ = 3, KG = 4, OCC = 1; };
+#ifndef RBF64_NWV
+#define RBF64_NWV 8
+#endif
+#if RBF64_NWV == 8
+// C=64: 8 waves (2 per SIMD) x 64 rows = R 512: the co-resident wave hides the K loop's issue overhead, and the
+// larger tile wastes less on overlap-save than R = 384 (x+h accumulators: 64+64 registers per wave)
+template <> struct RbFullGeom<64> { static constexpr int MI = 2, NJ = 2, KG = 4, OCC = 2, NWV = 8; };
+#else
+template <> struct RbFullGeom<64> { static constexpr int MI = 2, NJ = 3, KG = 4, OCC = 1, NWV = 4; };
+#endif
 // C <= 32: R = 384 keeps the two operand tiles at 68 KB and the kernel under 256 registers => 2 blocks per CU, so one
 // block's load / publish / store phases overlap the other's MFMA phases (worth more than the extra overlap-save waste)
-template <> struct RbFullGeom<32> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC; };
-template <> struct RbFullGeom<16> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC; };
-static int rbf_rows(int C) { return C == 64 ? 384 : 4 * 32 * RBF32_NJ; }
-static int rbf_nb() {  // weight-prefetch depth (register buffers); RVCMI_NB overrides for A/B experiments
+template <> struct RbFullGeom<32> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC, NWV = 4; };
+template <> struct RbFullGeom<16> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC, NWV = 4; };
+static int rbf_rows(int C) { return C == 64 ? RbFullGeom<64>::NWV * 32 * RbFullGeom<64>::NJ : 4 * 32 * RBF32_NJ; }
+static int rbf_nb(int dflt) {  // weight-prefetch depth (register buffers); RVCMI_NB overrides for A/B experiments
     const char* e = getenv("RVCMI_NB");
-    const int v = e ? atoi(e) : 3;
+    const int v = e ? atoi(e) : dflt;
     return v < 2 ? 2 : (v > 4 ? 4 : v);
 }
 template <typename OpT, int C>
 static void launch_rbf_inst(const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
     using G = RbFullGeom<C>;
-    constexpr int R = 4 * 32 * G::NJ;
+    constexpr int R = G::NWV * 32 * G::NJ;
     const size_t smem = (size_t)(R + 2 * RBF_G + R + 2 * RBF_G2) * Tile<C>::STRIDE + 3 * 2 * 32 * G::MI * 4 + 512;  // + bias vectors + dev phase stamps
-    const int nb = rbf_nb();
-    if (nb == 2) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 2, G::OCC>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
-    else if (nb == 3) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 3, G::OCC>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
-    else hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 4, G::OCC>), dim3(tiles, nj, B), dim3(256), smem, st, ra);
+    const int nb = rbf_nb(G::NWV == 8 ? 2 : 3);  // the 8-wave geometry has 256 registers per wave: a 2-deep ring fits without spills
+    if (nb == 2) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 2, G::OCC, G::NWV>), dim3(tiles, nj, B), dim3(64 * G::NWV), smem, st, ra);
+    else if (nb == 3) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 3, G::OCC, G::NWV>), dim3(tiles, nj, B), dim3(64 * G::NWV), smem, st, ra);
+    else hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 4, G::OCC, G::NWV>), dim3(tiles, nj, B), dim3(64 * G::NWV), smem, st, ra);
 }
 template <typename OpT>
 static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
@@ -568,7 +577,7 @@ static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, 
 template <typename OpT>
 static void set_lds_rbf() {
 #define RBF_ATTR1(C_, NB_)                                                                                                  \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, C_, RbFullGeom<C_>::MI, RbFullGeom<C_>::NJ, RbFullGeom<C_>::KG, NB_, RbFullGeom<C_>::OCC>), \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, C_, RbFullGeom<C_>::MI, RbFullGeom<C_>::NJ, RbFullGeom<C_>::KG, NB_, RbFullGeom<C_>::OCC, RbFullGeom<C_>::NWV>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define RBF_ATTR(C_) RBF_ATTR1(C_, 2) RBF_ATTR1(C_, 3) RBF_ATTR1(C_, 4)
     RBF_ATTR(64) RBF_ATTR(32) RBF_ATTR(16)
@@ -932,8 +941,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             }
             const size_t nblk = (size_t)max_tiles * nk * B;
             if (ra.dbg & 32) {
-                if (h->dbg.bytes < nblk * 4 * 16 * 8) h->dbg.alloc(nblk * 4 * 16 * 8);
-                HIP_CHECK(hipMemsetAsync(h->dbg.p, 0, nblk * 4 * 16 * 8, st));
+                if (h->dbg.bytes < nblk * 8 * 16 * 8) h->dbg.alloc(nblk * 8 * 16 * 8);
+                HIP_CHECK(hipMemsetAsync(h->dbg.p, 0, nblk * 8 * 16 * 8, st));
                 ra.ts = h->dbg.as<unsigned long long>();
             }
             h->prof.launch(nm, flops, bytes, st, [&] {

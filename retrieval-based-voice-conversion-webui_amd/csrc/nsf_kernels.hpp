@@ -1081,12 +1081,13 @@ struct RbFullArgs {
 constexpr int RBF_G = 32;   // zero guard rows around X (>= max dilated half-width + one padded tap)
 constexpr int RBF_G2 = 8;   // zero guard rows around H
 
-template <typename OpT, int C, int MI, int NJ, int KG, int NB, int OCC = 1>
-__global__ void __launch_bounds__(256, OCC) k_rb_full(RbFullArgs a) {
+template <typename OpT, int C, int MI, int NJ, int KG, int NB, int OCC = 1, int NWV = 4>
+__global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) {
+    constexpr int NT = 64 * NWV;  // NWV waves, each owning a slab of 32*NJ rows
     using TL = Tile<C>;
     constexpr int STRIDE = TL::STRIDE;
     constexpr int SLAB = 32 * NJ;
-    constexpr int R = 4 * SLAB;
+    constexpr int R = NWV * SLAB;
     constexpr int XROWS = R + 2 * RBF_G;
     constexpr int HROWS = R + 2 * RBF_G2;
     constexpr int CP = 32 * MI;  // padded channel count (C == 16 runs as one 32-channel tile)
@@ -1150,17 +1151,17 @@ __global__ void __launch_bounds__(256, OCC) k_rb_full(RbFullArgs a) {
     {
         constexpr int W = STRIDE / 16;  // 16-byte words per row
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (int i = threadIdx.x; i < 2 * RBF_G * W; i += 256) {
+        for (int i = threadIdx.x; i < 2 * RBF_G * W; i += NT) {
             const int r = i / W, c = i - r * W;
             const int row = r < RBF_G ? r : RBF_G + R + (r - RBF_G);
             *(uint4*)(X + (size_t)row * STRIDE + c * 16) = z;
         }
-        for (int i = threadIdx.x; i < 2 * RBF_G2 * W; i += 256) {
+        for (int i = threadIdx.x; i < 2 * RBF_G2 * W; i += NT) {
             const int r = i / W, c = i - r * W;
             const int row = r < RBF_G2 ? r : RBF_G2 + R + (r - RBF_G2);
             *(uint4*)(H + (size_t)row * STRIDE + c * 16) = z;
         }
-        for (int i = threadIdx.x; i < J.nd * 2 * CP; i += 256) {
+        for (int i = threadIdx.x; i < J.nd * 2 * CP; i += NT) {
             const int m = i / (2 * CP), w = (i / CP) & 1, c = i % CP;
             const float* bp = w ? J.b2[m] : J.b1[m];
             bias_l[i] = c < C ? bp[c] : 0.f;
@@ -1256,7 +1257,7 @@ __global__ void __launch_bounds__(256, OCC) k_rb_full(RbFullArgs a) {
 #ifdef RVCMI_DEV_STAMPS
     if ((a.dbg & 32) && lane < 16) {
         const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.ts[(blk * 4 + wave) * 16 + lane] = lane < tsn ? tsl[wave * 16 + lane] : 0ull;
+        a.ts[(blk * NWV + wave) * 16 + lane] = lane < tsn ? tsl[wave * 16 + lane] : 0ull;
     }
 #endif
 }
