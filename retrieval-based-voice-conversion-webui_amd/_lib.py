@@ -102,6 +102,8 @@ def build(verbose: bool = True, force: bool = False) -> str:
         o = os.path.join(CSRC, os.path.basename(s) + ".o")
         objs.append(o)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        for d_ in os.environ.get("RVCMI_DEFINES", "").split():
+            cmd.insert(1, "-D" + d_)  # dev: geometry experiments, e.g. RVCMI_DEFINES="RBF32_NWV=8"
         if os.environ.get("RVCMI_DEV_STAMPS"):
             cmd.insert(1, "-DRVCMI_DEV_STAMPS")  # per-phase s_memtime stamps in the fused kernels (RVCMI_DBG=32)
         if verbose:

@@ -470,8 +470,13 @@ static void launch_rb_inst(const RbPairArgs& ra, int tiles, int nj, int B, int r
 template <typename OpT>
 static void launch_rb_pair_t(int C, const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
     switch (C) {
+#ifdef RB_MI1  // experiment: 32-channel waves (64 accumulator registers) -> more waves per SIMD
+        case 256: return launch_rb_inst<OpT, 256, 1, 8, RB_KG>(ra, tiles, nj, B, rows, st);
+        case 128: return launch_rb_inst<OpT, 128, 1, 4, RB_KG>(ra, tiles, nj, B, rows, st);
+#else
         case 256: return launch_rb_inst<OpT, 256, 2, 4, RB_KG>(ra, tiles, nj, B, rows, st);
         case 128: return launch_rb_inst<OpT, 128, 2, 2, RB_KG>(ra, tiles, nj, B, rows, st);
+#endif
         case 64: return launch_rb_inst<OpT, 64, 2, 1, RB_KG>(ra, tiles, nj, B, rows, st);
         case 32: return launch_rb_inst<OpT, 32, 1, 1, RB_KG>(ra, tiles, nj, B, rows, st);
         case 16: return launch_rb_inst<OpT, 16, 1, 1, RB_KG>(ra, tiles, nj, B, rows, st);
@@ -487,7 +492,12 @@ static void set_lds_rb() {
 #define RB_ATTR(C_, MI_, NW_)                                                                                   \
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_pair<OpT, C_, MI_, NW_, RB_KG>),           \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    RB_ATTR(256, 2, 4) RB_ATTR(128, 2, 2) RB_ATTR(64, 2, 1) RB_ATTR(32, 1, 1) RB_ATTR(16, 1, 1)
+#ifdef RB_MI1
+    RB_ATTR(256, 1, 8) RB_ATTR(128, 1, 4)
+#else
+    RB_ATTR(256, 2, 4) RB_ATTR(128, 2, 2)
+#endif
+    RB_ATTR(64, 2, 1) RB_ATTR(32, 1, 1) RB_ATTR(16, 1, 1)
 #undef RB_ATTR
 }
 
@@ -547,9 +557,12 @@ template <> struct RbFullGeom<64> { static constexpr int MI = 2, NJ = 3, KG = 4,
 #endif
 // C <= 32: R = 384 keeps the two operand tiles at 68 KB and the kernel under 256 registers => 2 blocks per CU, so one
 // block's load / publish / store phases overlap the other's MFMA phases (worth more than the extra overlap-save waste)
-template <> struct RbFullGeom<32> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC, NWV = 4; };
-template <> struct RbFullGeom<16> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC, NWV = 4; };
-static int rbf_rows(int C) { return C == 64 ? RbFullGeom<64>::NWV * 32 * RbFullGeom<64>::NJ : 4 * 32 * RBF32_NJ; }
+#ifndef RBF32_NWV
+#define RBF32_NWV 4
+#endif
+template <> struct RbFullGeom<32> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC, NWV = RBF32_NWV; };
+template <> struct RbFullGeom<16> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC, NWV = RBF32_NWV; };
+static int rbf_rows(int C) { return C == 64 ? RbFullGeom<64>::NWV * 32 * RbFullGeom<64>::NJ : RBF32_NWV * 32 * RBF32_NJ; }
 static int rbf_nb(int dflt) {  // weight-prefetch depth (register buffers); RVCMI_NB overrides for A/B experiments
     const char* e = getenv("RVCMI_NB");
     const int v = e ? atoi(e) : dflt;
@@ -721,7 +734,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
     }
     // ---- conv_pre + cond                                                       nsf.py:164-166
     if (g && c.gin_channels) {
-        hipLaunchKernelGGL(k_cond, dim3((C0 + 255) / 256, B), dim3(256), 0, st, g, h->cond_w.as<float>(),
+        hipLaunchKernelGGL(k_cond, dim3((C0 + 3) / 4, B), dim3(256), 0, st, g, h->cond_w.as<float>(),
                            h->cond_b.as<float>(), h->condv.as<float>(), c.gin_channels, C0);
     }
     float* P = h->P.as<float>();
@@ -1012,7 +1025,11 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
                     bytes += (double)B * L * C * 8 + 2.0 * J.k * C * C * 2;
                 }
+#ifdef RB_MI1
+                const int NWp = C >= 128 ? C / 32 : (C >= 64 ? C / 64 : 1);
+#else
                 const int NWp = C >= 64 ? C / 64 : 1;
+#endif
                 const size_t nblk = (size_t)max_tiles * nj * B;
                 if (ra.dbg & 32) {
                     if (h->dbg.bytes < nblk * NWp * 64) h->dbg.alloc(nblk * NWp * 64);

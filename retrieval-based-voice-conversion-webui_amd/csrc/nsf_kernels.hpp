@@ -106,14 +106,17 @@ __global__ void __launch_bounds__(256) k_interp_linear(const float* __restrict__
 }
 
 // cond(g): a 1x1 conv over a length-1 sequence = one GEMV per utterance (nsf.py:165-166).
+// One wave per output channel: the weight row is read coalesced and reduced with xor-shuffles.
 __global__ void __launch_bounds__(256) k_cond(const float* __restrict__ g, const float* __restrict__ Wc,
                                               const float* __restrict__ bc, float* __restrict__ out, int gin, int C0) {
-    int b = blockIdx.y;
-    int co = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (co >= C0) return;
     float acc = 0.f;
-    for (int i = 0; i < gin; ++i) acc = fmaf(Wc[(size_t)co * gin + i], g[(size_t)b * gin + i], acc);
-    out[(size_t)b * C0 + co] = acc + bc[co];
+    for (int i = lane; i < gin; i += 64) acc = fmaf(Wc[(size_t)co * gin + i], g[(size_t)b * gin + i], acc);
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[(size_t)b * C0 + co] = acc + bc[co];
 }
 
 // ------------------------------------------------------------------------------------------------
