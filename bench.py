@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--stream", action="store_true",
+                   help="BASELINE configs[4]: realtime chunks (v1/40k generator, T=31 frames -> n_res, 16 queries); prints p50 latency")
     return p.parse_args()
 
 
@@ -102,8 +104,44 @@ def cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, index_rate):
                       % (idx["ntotal"], idx["d"], t_ivf, z.shape[-1], t_gen)}
 
 
+def stream_mode(a):
+    """Realtime chunk latency (gui.py geometry): block 0.256 s -> decoder T=31 frames
+    (n_res = 31, no formant shift), retrieval on the last 16 HuBERT frames; v1/40k generator, 768-d index.
+    Eager launches (a realtime loop cannot replay a fixed graph when f0/n_res vary); p50 over 200 chunks."""
+    import rvc_amd
+    from oracle import nsf_oracle, synth
+
+    dev = torch.device("cuda", 0)
+    cfg = nsf_oracle.CONFIGS["v1_40k"]
+    w = synth.make_dec_weights(cfg, 1234)
+    T, NQ = 31, 16
+    z, f0, g = synth.make_dec_inputs(cfg, 1, T)
+    noise = nsf_oracle.reference_noise(1, T, cfg.upp)
+    idx = synth.make_ivf(a.index_n, a.index_d, seed=4321, kmeans_iters=1)
+    index = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=dev).reserve(NQ)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=dev, operand=a.operand, max_B=1, max_T=64)
+    zd, fd, gd, nd = z.to(dev), f0.to(dev), g.to(dev), noise.to(dev)
+    feats = synth.make_phone(1, NQ, a.index_d)[0].to(dev).contiguous()
+    lat = []
+    for i in range(220):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        f = feats.clone()
+        index.search_blend(f, a.index_rate, 8, skip_if_short=True)
+        o = gen(zd, fd, gd, noise=nd)
+        torch.cuda.synchronize()
+        if i >= 20:
+            lat.append(1e3 * (time.perf_counter() - t0))
+    lat.sort()
+    print(json.dumps({"metric": "realtime chunk latency p50 (retrieval + NSF decode), v1/40k, 256 ms block", "value": lat[len(lat) // 2],
+                      "unit": "ms", "p90": lat[int(0.9 * len(lat))], "higher_is_better": False, "n_gpus": 1, "dtype": a.operand,
+                      "data": "synthetic", "config": {"workload": "BASELINE configs[4] (hot path only): T=31 frames -> 12400 samples, 16 queries, eager launches"}}))
+
+
 def main():
     a = parse()
+    if a.stream:
+        return stream_mode(a)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,7 +150,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("RVCMI_BENCH_FORCE_DIST") == "1"  # (the env switch exercises the RCCL path on one GPU)
+    if use_dist:
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import rvc_amd
@@ -133,7 +172,7 @@ def main():
         index = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=dev)
     else:
         index = None
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -172,18 +211,18 @@ def main():
     for _ in range(a.warmup):
         run()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         run()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -235,14 +274,14 @@ def main():
                                    "IVF %dx%d nlist=%d nprobe=1 k=8 index_rate=%.2f" % (
                                        1 if B == 1 else 2, B, T, a.index_n, a.index_d, index.nlist, a.index_rate),
                        "clips_per_gpu_per_step": B, "hipgraph": graph is not None,
-                       "index_broadcast_s": t_bcast if world > 1 else None},
+                       "index_broadcast_s": t_bcast if use_dist else None},
         }
         if roof is not None:
             line["roofline"] = roof
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

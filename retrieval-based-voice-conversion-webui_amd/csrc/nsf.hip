@@ -200,6 +200,10 @@ static void upload(DevBuf& d, const std::vector<float>& v) {
 
 static void set_lds_limits();
 constexpr int RB_KG = 4;  // k-steps per weight-prefetch group inside the fused resblock kernel
+#ifndef RB256_NJ
+#define RB256_NJ 4  // (96-row tiles, 2 blocks per CU, measured the same 0.33 ms at B=1; 128 rows reuse weights better)
+#endif
+static int rb_rows(int C) { return C == 256 ? 32 * RB256_NJ : RB_ROWS; }
 
 static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights, int n_weights, int device, int max_B,
                        int max_T, rvcmi_nsf** out) {
@@ -461,11 +465,11 @@ static void set_lds_limits() {
 }
 
 
-template <typename OpT, int C, int MI, int NW, int KG>
+template <typename OpT, int C, int MI, int NW, int KG, int NJ = RB_ROWS / 32>
 static void launch_rb_inst(const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
     const size_t smem = (size_t)rows * Tile<C>::STRIDE + 2 * 32 * MI * NW * 4 + NW * 64;  // tile + the two bias vectors + dev stamps
     if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "resblock LDS tile too large (%zu B)", smem);
-    hipLaunchKernelGGL((k_rb_pair<OpT, C, MI, NW, KG>), dim3(tiles, nj, B), dim3(64 * NW), smem, st, ra);
+    hipLaunchKernelGGL((k_rb_pair<OpT, C, MI, NW, KG, NJ>), dim3(tiles, nj, B), dim3(64 * NW), smem, st, ra);
 }
 template <typename OpT>
 static void launch_rb_pair_t(int C, const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
@@ -474,7 +478,7 @@ static void launch_rb_pair_t(int C, const RbPairArgs& ra, int tiles, int nj, int
         case 256: return launch_rb_inst<OpT, 256, 1, 8, RB_KG>(ra, tiles, nj, B, rows, st);
         case 128: return launch_rb_inst<OpT, 128, 1, 4, RB_KG>(ra, tiles, nj, B, rows, st);
 #else
-        case 256: return launch_rb_inst<OpT, 256, 2, 4, RB_KG>(ra, tiles, nj, B, rows, st);
+        case 256: return launch_rb_inst<OpT, 256, 2, 4, RB_KG, RB256_NJ>(ra, tiles, nj, B, rows, st);
         case 128: return launch_rb_inst<OpT, 128, 2, 2, RB_KG>(ra, tiles, nj, B, rows, st);
 #endif
         case 64: return launch_rb_inst<OpT, 64, 2, 1, RB_KG>(ra, tiles, nj, B, rows, st);
@@ -495,7 +499,9 @@ static void set_lds_rb() {
 #ifdef RB_MI1
     RB_ATTR(256, 1, 8) RB_ATTR(128, 1, 4)
 #else
-    RB_ATTR(256, 2, 4) RB_ATTR(128, 2, 2)
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_pair<OpT, 256, 2, 4, RB_KG, RB256_NJ>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    RB_ATTR(128, 2, 2)
 #endif
     RB_ATTR(64, 2, 1) RB_ATTR(32, 1, 1) RB_ATTR(16, 1, 1)
 #undef RB_ATTR
@@ -1018,10 +1024,10 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     J.k = c1.ntaps[0];
                     J.k_p = c1.ntaps_p;
                     J.dil = c1.dstep;
-                    J.tt2 = RB_ROWS - (J.k - 1);
+                    J.tt2 = rb_rows(C) - (J.k - 1);
                     J.ntiles = (int)((L + J.tt2 - 1) / J.tt2);
                     max_tiles = std::max(max_tiles, J.ntiles);
-                    max_rows = std::max(max_rows, RB_ROWS + (J.k_p - 1) * J.dil);
+                    max_rows = std::max(max_rows, rb_rows(C) + (J.k_p - 1) * J.dil);
                     flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
                     bytes += (double)B * L * C * 8 + 2.0 * J.k * C * C * 2;
                 }

@@ -673,16 +673,17 @@ struct RbPairArgs {
     unsigned long long* ts;
 };
 
-constexpr int RB_ROWS = 128;  // conv1 output rows per tile = 4 MFMA column tiles per wave
+constexpr int RB_ROWS = 128;  // default conv1 output rows per tile = 4 MFMA column tiles per wave (template NJ overrides)
 
-template <typename OpT, int C, int MI, int NW, int KG>
+template <typename OpT, int C, int MI, int NW, int KG, int NJ_ = RB_ROWS / 32>
 __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
+    constexpr int ROWS = 32 * NJ_;  // conv1 output rows per tile
     using TL = Tile<C>;
     using frag = typename Op<OpT>::frag;
     constexpr int STRIDE = TL::STRIDE;
     constexpr int C8 = C / 8;
     constexpr int NT = 64 * NW;
-    constexpr int NJ = RB_ROWS / 32;
+    constexpr int NJ = NJ_;
     constexpr int NB = 2;
     constexpr int CP = 32 * MI * NW;  // padded channel count
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -695,7 +696,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
     const int t0 = blockIdx.x * J.tt2;          // first output time of this tile
     const int h0 = t0 - p2;                     // global time of h row 0
     const int x0 = h0 - p1;                     // global time of X row 0
-    const int xrows = RB_ROWS + (J.k_p - 1) * J.dil;
+    const int xrows = ROWS + (J.k_p - 1) * J.dil;
     const float* src = J.src + (size_t)b * a.bstride;
     float* bias_l = (float*)(smem + (size_t)xrows * STRIDE);  // [2][CP]: b1 then b2
     unsigned long long* tsl = (unsigned long long*)(bias_l + 2 * CP);  // dev-only phase stamps (dbg & 32)
@@ -784,7 +785,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
 
     // ---- 3. h = lrelu(conv1 + b1) -> OpT, in place over X (zero outside the utterance: conv2 pads ITS input) ----
     {
-        const bool interior = h0 >= 0 && h0 + RB_ROWS <= a.L;  // block-uniform: no masking needed
+        const bool interior = h0 >= 0 && h0 + ROWS <= a.L;  // block-uniform: no masking needed
         unsigned rowmask[NJ];
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
