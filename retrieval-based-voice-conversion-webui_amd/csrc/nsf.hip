@@ -465,11 +465,11 @@ static void set_lds_limits() {
 }
 
 
-template <typename OpT, int C, int MI, int NW, int KG, int NJ = RB_ROWS / 32>
+template <typename OpT, int C, int MI, int NW, int KG, int NJ = RB_ROWS / 32, int NWT = 1, int OCC = 2>
 static void launch_rb_inst(const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
-    const size_t smem = (size_t)rows * Tile<C>::STRIDE + 2 * 32 * MI * NW * 4 + NW * 64;  // tile + the two bias vectors + dev stamps
+    const size_t smem = (size_t)rows * Tile<C>::STRIDE + 2 * 32 * MI * NW * 4 + NW * NWT * 64;  // tile + the two bias vectors + dev stamps
     if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "resblock LDS tile too large (%zu B)", smem);
-    hipLaunchKernelGGL((k_rb_pair<OpT, C, MI, NW, KG, NJ>), dim3(tiles, nj, B), dim3(64 * NW), smem, st, ra);
+    hipLaunchKernelGGL((k_rb_pair<OpT, C, MI, NW, KG, NJ, NWT, OCC>), dim3(tiles, nj, B), dim3(64 * NW * NWT), smem, st, ra);
 }
 template <typename OpT>
 static void launch_rb_pair_t(int C, const RbPairArgs& ra, int tiles, int nj, int B, int rows, hipStream_t st) {
@@ -478,8 +478,13 @@ static void launch_rb_pair_t(int C, const RbPairArgs& ra, int tiles, int nj, int
         case 256: return launch_rb_inst<OpT, 256, 1, 8, RB_KG>(ra, tiles, nj, B, rows, st);
         case 128: return launch_rb_inst<OpT, 128, 1, 4, RB_KG>(ra, tiles, nj, B, rows, st);
 #else
+#ifdef RB_TSPLIT  // experiment: 128 rows split over 2 time slabs (NJ = 2, 64 accumulator registers) -> 2x the waves per tile
+        case 256: return launch_rb_inst<OpT, 256, 2, 4, RB_KG, 2, 2, 2>(ra, tiles, nj, B, rows, st);
+        case 128: return launch_rb_inst<OpT, 128, 2, 2, RB_KG, 2, 2, RB_TSPLIT>(ra, tiles, nj, B, rows, st);
+#else
         case 256: return launch_rb_inst<OpT, 256, 2, 4, RB_KG, RB256_NJ>(ra, tiles, nj, B, rows, st);
         case 128: return launch_rb_inst<OpT, 128, 2, 2, RB_KG>(ra, tiles, nj, B, rows, st);
+#endif
 #endif
         case 64: return launch_rb_inst<OpT, 64, 2, 1, RB_KG>(ra, tiles, nj, B, rows, st);
         case 32: return launch_rb_inst<OpT, 32, 1, 1, RB_KG>(ra, tiles, nj, B, rows, st);
@@ -499,9 +504,16 @@ static void set_lds_rb() {
 #ifdef RB_MI1
     RB_ATTR(256, 1, 8) RB_ATTR(128, 1, 4)
 #else
+#ifdef RB_TSPLIT
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_pair<OpT, 256, 2, 4, RB_KG, 2, 2, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_pair<OpT, 128, 2, 2, RB_KG, 2, 2, RB_TSPLIT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#else
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_pair<OpT, 256, 2, 4, RB_KG, RB256_NJ>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     RB_ATTR(128, 2, 2)
+#endif
 #endif
     RB_ATTR(64, 2, 1) RB_ATTR(32, 1, 1) RB_ATTR(16, 1, 1)
 #undef RB_ATTR
@@ -1031,11 +1043,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
                     bytes += (double)B * L * C * 8 + 2.0 * J.k * C * C * 2;
                 }
-#ifdef RB_MI1
-                const int NWp = C >= 128 ? C / 32 : (C >= 64 ? C / 64 : 1);
-#else
-                const int NWp = C >= 64 ? C / 64 : 1;
-#endif
+                const int NWp = 8;  // upper bound of waves per block across the pair-kernel geometries
                 const size_t nblk = (size_t)max_tiles * nj * B;
                 if (ra.dbg & 32) {
                     if (h->dbg.bytes < nblk * NWp * 64) h->dbg.alloc(nblk * NWp * 64);

@@ -675,14 +675,16 @@ struct RbPairArgs {
 
 constexpr int RB_ROWS = 128;  // default conv1 output rows per tile = 4 MFMA column tiles per wave (template NJ overrides)
 
-template <typename OpT, int C, int MI, int NW, int KG, int NJ_ = RB_ROWS / 32>
-__global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
-    constexpr int ROWS = 32 * NJ_;  // conv1 output rows per tile
+// Waves are laid out NW (output-channel slices of 32*MI) x NWT (time slabs of 32*NJ_ rows); OCC = waves per SIMD the
+// register budget is capped for.
+template <typename OpT, int C, int MI, int NW, int KG, int NJ_ = RB_ROWS / 32, int NWT = 1, int OCC = 2>
+__global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArgs a) {
+    constexpr int ROWS = 32 * NJ_ * NWT;  // conv1 output rows per tile
     using TL = Tile<C>;
     using frag = typename Op<OpT>::frag;
     constexpr int STRIDE = TL::STRIDE;
     constexpr int C8 = C / 8;
-    constexpr int NT = 64 * NW;
+    constexpr int NT = 64 * NW * NWT;
     constexpr int NJ = NJ_;
     constexpr int NB = 2;
     constexpr int CP = 32 * MI * NW;  // padded channel count
@@ -711,7 +713,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int ct0 = wave * MI;
+    const int ct0 = (wave % NW) * MI;             // first 32-channel output tile of this wave
+    const int slab = (wave / NW) * 32 * NJ_;      // first row of this wave's time slab
     const int half4 = 4 * (lane >> 5);
 
     // conv1's first weight groups are requested before anything else: their latency hides behind the staging
@@ -760,7 +763,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
     __syncthreads();
     stamp();  // 2
 
-    const char* lds_lane = smem + (size_t)(lane & 31) * STRIDE + (lane >> 5) * 16;
+    const char* lds_lane = smem + (size_t)(slab + (lane & 31)) * STRIDE + (lane >> 5) * 16;
     f32x16 acc[MI][NJ];
     auto init_bias = [&](const float* bl) {  // accumulators start from the bias: no add in the epilogues
 #pragma unroll
@@ -789,10 +792,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
         unsigned rowmask[NJ];
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
-            const int th = h0 + jt * 32 + (lane & 31);
+            const int th = h0 + slab + jt * 32 + (lane & 31);
             rowmask[jt] = (th >= 0 && th < a.L) ? 0xffffffffu : 0u;
         }
-        char* hw = smem + (size_t)(lane & 31) * STRIDE + (ct0 * 32 + half4) * 2;
+        char* hw = smem + (size_t)(slab + (lane & 31)) * STRIDE + (ct0 * 32 + half4) * 2;
         if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(hw, acc, rowmask, ct0 * 32);
         else publish_operand<OpT, C, MI, NJ, STRIDE, true>(hw, acc, rowmask, ct0 * 32);
     }
@@ -810,7 +813,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
     float* dst = J.dst + (size_t)b * a.bstride;
 #pragma unroll
     for (int jt = 0; jt < NJ; ++jt) {
-        const int o = jt * 32 + (lane & 31);
+        const int o = slab + jt * 32 + (lane & 31);
         const int t = t0 + o;
         const bool valid = o < J.tt2 && t < a.L;
         const int tc = min(t, a.L - 1);
@@ -840,7 +843,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_rb_pair(RbPairArgs a) {
 #ifdef RVCMI_DEV_STAMPS
     if ((a.dbg & 32) && (threadIdx.x & 63) < 8) {
         const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.ts[(blk * NW + (threadIdx.x >> 6)) * 8 + (threadIdx.x & 63)] = tsl[(threadIdx.x >> 6) * 8 + (threadIdx.x & 63)];
+        a.ts[(blk * NW * NWT + (threadIdx.x >> 6)) * 8 + (threadIdx.x & 63)] = tsl[(threadIdx.x >> 6) * 8 + (threadIdx.x & 63)];
     }
 #endif
 }
