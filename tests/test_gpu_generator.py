@@ -183,6 +183,26 @@ def test_full_clip_size_properties(gpu):
     assert rms(win.cpu(), ref) <= 1e-3
 
 
+@pytest.mark.parametrize("cfg_name,T", [("v1_40k", 210), ("v2_32k", 170), ("v1_32k", 190), ("v1_48k", 150)])
+def test_every_shipped_config_multi_tile_vs_oracle(cfg_name, T, gpu):
+    """Several tiles per kernel at every stage for the other shipped configs (different polyphase tap patterns,
+    5-stage models whose last stage has 16 channels), fp16 operands against the oracle."""
+    import rvc_amd
+
+    cfg = nsf_oracle.CONFIGS[cfg_name]
+    w = synth.make_dec_weights(cfg, 21)
+    z, f0, g = synth.make_dec_inputs(cfg, 1, T, 21)
+    noise = nsf_oracle.reference_noise(1, T, cfg.upp, 9)
+    with torch.no_grad():
+        ref = nsf_oracle.generator_forward(cfg, w, z, f0, g, noise)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=1, max_T=T)
+    out = gen(z.to(gpu), f0.to(gpu), g.to(gpu), noise=noise.to(gpu)).cpu()
+    assert rms(out, ref) <= 1e-3, "%s: %.3e" % (cfg_name, rms(out, ref))
+    gen32 = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp32", max_B=1, max_T=T)
+    out32 = gen32(z.to(gpu), f0.to(gpu), g.to(gpu), noise=noise.to(gpu)).cpu()
+    assert rms(out32, ref) <= 2e-5
+
+
 def test_smoke_entry_point(gpu):
     import __graft_entry__
 

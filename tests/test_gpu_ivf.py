@@ -149,6 +149,33 @@ def test_faiss_file_and_blob_roundtrips(tmp_path, gpu):
         rvc_amd.read_index(str(trunc), gpu)
 
 
+def test_coarse_prefilter_is_exact_on_adversarial_near_ties(gpu):
+    """The nprobe=1 coarse pass scores centroids in fp32 (MFMA) and re-checks every centroid inside a rigorous error
+    margin in fp64.  Centroids that differ by ~1e-6 relative (far below fp32 dot-product resolution at d=768) make
+    nearly ALL of them candidates; the chosen list must still be the exact fp64 argmin with ties to the lowest id."""
+    rng = np.random.default_rng(77)
+    d, nlist, per = 768, 300, 4
+    base = rng.standard_normal(d).astype(np.float32) * 3
+    cent = (base[None, :] + 1e-5 * rng.standard_normal((nlist, d))).astype(np.float32)
+    cent[17] = cent[5]  # an exact duplicate centroid: the lower id must win
+    n = nlist * per
+    vecs = rng.standard_normal((n, d), dtype=np.float32)
+    off = np.arange(0, n + 1, per, dtype=np.int64)
+    ids = rng.permutation(n).astype(np.int64)
+    idx = dict(d=d, ntotal=n, nlist=nlist, nprobe=1, centroids=cent, list_offsets=off, ids=ids, vecs=vecs)
+    q = (base[None, :] + 1e-5 * rng.standard_normal((200, d))).astype(np.float32)
+    q[:3] = cent[[5, 100, 299]]
+    import rvc_amd
+
+    h = rvc_amd.IVFFlatHIP.from_arrays(cent, off, ids, vecs, device=gpu)
+    D, I = h.search(q, 4)
+    Dr, Ir = ivf_oracle.search(idx, q, 4)
+    assert np.array_equal(I, Ir), "%d mismatches" % int((I != Ir).sum())
+    assert np.array_equal(D, Dr)
+    lists = ivf_oracle.coarse_assign(idx, q, 1)[:, 0]
+    assert lists[0] == 5 and 17 not in lists  # duplicate centroid: lowest id
+
+
 def test_stress_size_ranking_properties(gpu):
     """BASELINE's stress shape (1M x 256, nlist 16000, nprobe 1) through size-independent properties:
     results ascending, every hit comes from the probed list, top-1 == brute force over that list in fp64, and a
