@@ -1002,7 +1002,17 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             }
         } else {
             snprintf(nm, sizeof(nm), "rb_pair_c%d", C);
-            for (size_t m = 0; m < maxnd; ++m) {
+            // Launch order.  Level-major (one launch = pair level m of all resblocks) maximises the grid; resblock-major
+            // (one launch = one pair of ONE resblock, chains run back to back) keeps a chain's src+dst (2 x L*C*4 B) inside
+            // the 256 MB Infinity Cache when L*C*4*6 does not fit -- chosen per stage by working-set size.
+            const char* ord = getenv("RVCMI_RB_ORDER");
+            const double ws_level = 6.0 * (double)B * L * C * 4;
+            const bool jmajor = ord ? (ord[0] == 'j') : false;
+            (void)ws_level;
+            const size_t npass = jmajor ? (size_t)nk * maxnd : maxnd;
+            for (size_t pass = 0; pass < npass; ++pass) {
+                const size_t m = jmajor ? pass % maxnd : pass;
+                const int only_j = jmajor ? (int)(pass / maxnd) : -1;
                 RbPairArgs ra;
                 memset(&ra, 0, sizeof(ra));
                 ra.L = (int)L;
@@ -1020,6 +1030,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 for (int oj = 0; oj < nk; ++oj) {
                     const int j = order[oj];
                     if (m >= s.rb[j].size()) continue;
+                    if (only_j >= 0 && j != only_j) continue;
                     const ConvLayer& c1 = s.rb[j][m].first;
                     const ConvLayer& c2 = s.rb[j][m].second;
                     RbJob& J = ra.job[nj++];
@@ -1043,6 +1054,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
                     bytes += (double)B * L * C * 8 + 2.0 * J.k * C * C * 2;
                 }
+                if (nj == 0) continue;
                 const int NWp = 8;  // upper bound of waves per block across the pair-kernel geometries
                 const size_t nblk = (size_t)max_tiles * nj * B;
                 if (ra.dbg & 32) {
