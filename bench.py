@@ -244,8 +244,17 @@ def main():
         ach = dom["flops"] / (dom["ms"] * 1e-3)
         tot_ms = sum(s["ms"] for s in gs) / 3.0
         gen_ach = GEN_FLOP_PER_CLIP * B * (T / T_CLIP) / (tot_ms * 1e-3)
+        traffic = None  # HBM-side bytes per launch of the dominant kernel: from the committed rocprofv3 --pmc passes, if any
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom["name"])
+            if pm and B == 1 and T == T_CLIP and a.operand == "fp16":
+                traffic = pm["bytes_per_launch"]
+        except Exception:  # noqa
+            pass
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": None,
+                "frac": ach / peak, "traffic": traffic,
+                "hbm_side": None if traffic is None else {"achieved": traffic / (dom["ms"] / dom["launches"] * 1e-3) / 1e9, "peak": 8000.0,
+                                                         "unit": "GB/s", "frac": traffic / (dom["ms"] / dom["launches"] * 1e-3) / 8e12},
                 "avg_launch_us": 1e3 * dom["ms"] / dom["launches"], "launches_per_step": dom["launches"] // 3,
                 "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
                 "generator_all_kernels": {"ms_per_step": tot_ms, "achieved": gen_ach / 1e12, "frac": gen_ach / peak},
