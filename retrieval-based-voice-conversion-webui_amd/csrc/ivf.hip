@@ -121,47 +121,58 @@ __global__ void __launch_bounds__(256) k_coarse1(const float* __restrict__ q, co
 // k_coarse_gemm: S[q][c] = fl32(|c|^2) - 2*dot32(q, c) with v_mfma_f32_32x32x2_f32 (an fmaf chain, so the classic
 // dot-product error bound holds: |err| <= d*u*|q||c|, u = 2^-24).  Block = 64 queries x 128 centroids, K chunks of 32
 // staged in LDS (row stride 33 floats: conflict-free ds_read_b32 for both operands).
-constexpr int CG_Q = 64, CG_C = 128, CG_K = 32, CG_S = 33;
+constexpr int CG_K = 32, CG_S = 33;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-__global__ void __launch_bounds__(256) k_coarse_gemm(const float* __restrict__ q, const float* __restrict__ cent,
-                                                     const float* __restrict__ cn, int64_t nq, int64_t nlist, int d,
-                                                     float* __restrict__ S) {
-    __shared__ float Qs[CG_Q * CG_S];
-    __shared__ float Cs[CG_C * CG_S];
-    const int64_t q0 = (int64_t)blockIdx.y * CG_Q, c0 = (int64_t)blockIdx.x * CG_C;
+// MQ query tiles of 32 per block, NWC waves each owning 32 centroids.  (2, 4): 64 x 128 tiles for big nlist;
+// (1, 1): one wave per 32 x 32 tile, so that small problems (nlist 256: 8 x 19 blocks) are not latency-bound.
+template <int MQ, int NWC>
+__global__ void __launch_bounds__(64 * NWC) k_coarse_gemm(const float* __restrict__ q, const float* __restrict__ cent,
+                                                          const float* __restrict__ cn, int64_t nq, int64_t nlist, int d,
+                                                          float* __restrict__ S) {
+    constexpr int NT = 64 * NWC, QR = 32 * MQ, CR = 32 * NWC;
+    __shared__ float Qs[QR * CG_S];
+    __shared__ float Cs[CR * CG_S];
+    const int64_t q0 = (int64_t)blockIdx.y * QR, c0 = (int64_t)blockIdx.x * CR;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    f32x16 acc[2];
+    f32x16 acc[MQ];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc[0][e] = 0.f; acc[1][e] = 0.f; }
-    for (int k0 = 0; k0 < d; k0 += CG_K) {
-        // stage 64 query rows and 128 centroid rows x 32 floats (clamped rows: unconditional loads)
+    for (int m = 0; m < MQ; ++m)
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
-            const int idx = threadIdx.x + it * 256;  // 0 .. 1535 float4 slots
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    constexpr int SLOTS = (QR + CR) * (CG_K / 4);  // float4 slots per K chunk
+    static_assert(SLOTS % NT == 0, "staging slots must divide evenly");
+    constexpr int PER = SLOTS / NT;
+    float4 pre[PER];
+    auto fetch = [&](int k0) {  // next chunk -> registers (clamped rows: unconditional loads)
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int idx = threadIdx.x + it * NT;
             const int row = idx >> 3, c4 = idx & 7;
-            const int kk = k0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < CG_Q) {
-                const int64_t qr = min(q0 + row, nq - 1);
-                if (kk < d) v = *(const float4*)(q + qr * d + kk);
-                float* dst = Qs + row * CG_S + c4 * 4;
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            } else {
-                const int cr_ = row - CG_Q;
-                const int64_t cr = min(c0 + cr_, nlist - 1);
-                if (kk < d) v = *(const float4*)(cent + cr * d + kk);
-                float* dst = Cs + cr_ * CG_S + c4 * 4;
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            }
+            const int kk = min(k0 + c4 * 4, d - 4);
+            const float* src = row < QR ? q + min(q0 + row, nq - 1) * d : cent + min(c0 + (row - QR), nlist - 1) * d;
+            const float4 v = *(const float4*)(src + kk);  // unconditional: no branch per load
+            const bool ok = k0 + c4 * 4 < d;
+            pre[it] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < d; k0 += CG_K) {
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int idx = threadIdx.x + it * NT;
+            const int row = idx >> 3, c4 = idx & 7;
+            float* dst = (row < QR ? Qs + row * CG_S : Cs + (row - QR) * CG_S) + c4 * 4;
+            dst[0] = pre[it].x; dst[1] = pre[it].y; dst[2] = pre[it].z; dst[3] = pre[it].w;
         }
         __syncthreads();
+        if (k0 + CG_K < d) fetch(k0 + CG_K);  // in flight while this chunk is multiplied
         const float* qa = Qs + (lane & 31) * CG_S + (lane >> 5);
         const float* cb = Cs + (wave * 32 + (lane & 31)) * CG_S + (lane >> 5);
 #pragma unroll
         for (int ks = 0; ks < CG_K / 2; ++ks) {
-            const float a0 = qa[2 * ks], a1 = qa[32 * CG_S + 2 * ks], b = cb[2 * ks];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+            const float bv = cb[2 * ks];
+#pragma unroll
+            for (int m = 0; m < MQ; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[m * 32 * CG_S + 2 * ks], bv, acc[m], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -169,11 +180,11 @@ __global__ void __launch_bounds__(256) k_coarse_gemm(const float* __restrict__ q
     if (c < nlist) {
         const float cnc = cn[c];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int m = 0; m < MQ; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t qr = q0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (qr < nq) S[qr * nlist + c] = cnc - 2.f * acc[mi][r];
+                const int64_t qr = q0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (qr < nq) S[qr * nlist + c] = cnc - 2.f * acc[m][r];
             }
     }
 }
@@ -790,9 +801,16 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
             if (h->cap_chunk <= 0 || !h->cscore.p) RVCMI_FAIL(RVCMI_ERR_INVALID, "coarse score scratch not reserved");
             for (int64_t qs = 0; qs < nq; qs += h->cap_chunk) {
                 const int64_t nqc = std::min<int64_t>(h->cap_chunk, nq - qs);
-                dim3 grid((unsigned)((b.nlist + CG_C - 1) / CG_C), (unsigned)((nqc + CG_Q - 1) / CG_Q));
-                hipLaunchKernelGGL(k_coarse_gemm, grid, dim3(256), 0, st, q + qs * d, h->centroids(), h->cnorm(), nqc, b.nlist, d,
-                                   h->cscore.as<float>());
+                const int64_t big_blocks = ((b.nlist + 127) / 128) * ((nqc + 63) / 64);
+                if (big_blocks >= 512) {
+                    dim3 grid((unsigned)((b.nlist + 127) / 128), (unsigned)((nqc + 63) / 64));
+                    hipLaunchKernelGGL((k_coarse_gemm<2, 4>), grid, dim3(256), 0, st, q + qs * d, h->centroids(), h->cnorm(), nqc,
+                                       b.nlist, d, h->cscore.as<float>());
+                } else {
+                    dim3 grid((unsigned)((b.nlist + 31) / 32), (unsigned)((nqc + 31) / 32));
+                    hipLaunchKernelGGL((k_coarse_gemm<1, 1>), grid, dim3(64), 0, st, q + qs * d, h->centroids(), h->cnorm(), nqc,
+                                       b.nlist, d, h->cscore.as<float>());
+                }
                 hipLaunchKernelGGL(k_coarse_pick, dim3((unsigned)((nqc + 3) / 4)), dim3(256), 0, st, q + qs * d, h->centroids(),
                                    h->cscore.as<float>(), nqc, b.nlist, d, b.cmax, h->assign.as<int64_t>() + qs);
             }
