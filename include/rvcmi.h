@@ -145,6 +145,64 @@ int rvcmi_nsf_profile_enable(rvcmi_nsf* h, int enable);
 int rvcmi_nsf_profile_read(rvcmi_nsf* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset);
 
 /* ------------------------------------------------------------------------------------------- */
+/* Synthesizer front: enc_p + prior sampling + flow^-1              */
+/* ------------------------------------------------------------------------------------------- */
+
+/* What SynthesizerTrnMsNSFsid.infer (rvc/layers/synthesizers.py:160-203) runs before self.dec:
+ *     m_p, logs_p, x_mask = self.enc_p(phone, pitch, phone_lengths, flow_head)   encoders.py:134-159
+ *     z_p = (m_p + exp(logs_p) * randn_like(m_p) * 0.66666) * x_mask             synthesizers.py:182-183
+ *     z   = self.flow(z_p, x_mask, g=g, reverse=True)                            residuals.py:319-321
+ * With this handle and rvcmi_nsf the whole `infer` runs without a torch op in between.
+ * Hyper-parameters are the positional config list of a checkpoint (configs/v2/48k.json:19-27). */
+typedef struct {
+    int in_channels;          /* 768 (v2, SynthesizerTrnMs768NSFsid) or 256 (v1)                */
+    int inter_channels;       /* 192                                                            */
+    int hidden_channels;      /* 192                                                            */
+    int filter_channels;      /* 768                                                            */
+    int n_heads;              /* 2                                                              */
+    int n_layers;             /* 6                                                              */
+    int kernel_size;          /* FFN kernel, 3                                                  */
+    int window_size;          /* relative-attention window, 10 (encoders.py:21)                 */
+    int gin_channels;         /* 256                                                            */
+    int use_f0;               /* emb_pitch present (encoders.py:107-108)                        */
+    int flow_n_flows;         /* 4  (residuals.py:275)                                          */
+    int flow_n_layers;        /* 3  (synthesizers.py:111-113)                                   */
+    int flow_kernel_size;     /* 5                                                              */
+    int flow_dilation_rate;   /* 1                                                              */
+    int operand;              /* RVCMI_OPERAND_F16 / _BF16 (MFMA operands; everything else fp32) */
+} rvcmi_front_config;
+
+typedef struct rvcmi_front rvcmi_front;
+
+/* Stands in for the enc_p / flow part of get_synthesizer (rvc/synthesizer.py:10-28).  `weights` are fp32 HOST
+ * tensors named by the keys of net_g.state_dict() AFTER remove_weight_norm(): "enc_p.emb_phone.weight",
+ * "enc_p.encoder.attn_layers.0.conv_q.weight", "enc_p.encoder.attn_layers.0.emb_rel_k", ...,
+ * "enc_p.proj.weight", "flow.flows.0.pre.weight", "flow.flows.0.enc.in_layers.0.weight", ...,
+ * "flow.flows.6.post.bias".  The channel Flip modules are folded into the packed weights.       */
+int rvcmi_front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* weights, int n_weights, int device,
+                       int max_B, int max_T, rvcmi_front** out);
+int rvcmi_front_destroy(rvcmi_front* h);
+
+/* One pass.  phone_dev [B][T][in_channels] fp32 (features after the x2 interpolation, pipeline.py:146-150);
+ * pitch_dev [B][T] int64 coarse bins or NULL (no-f0 models); lengths_dev [B] int64 (phone_lengths) or NULL = all T;
+ * g_dev [B][gin] fp32 = emb_g(sid); noise_dev [B][inter][T - flow_head] fp32 standing for randn_like(m_p);
+ * flow_head = max(skip_head - 24, 0) for the realtime partial decode (synthesizers.py:175-181), else 0.
+ * z_out_dev [B][inter][T - flow_head] fp32 = z * x_mask, the layout rvcmi_nsf_forward takes as x_dev.  */
+int rvcmi_front_forward(rvcmi_front* h, int B, int T, const float* phone_dev, const int64_t* pitch_dev,
+                        const int64_t* lengths_dev, const float* g_dev, const float* noise_dev, int flow_head,
+                        float* z_out_dev, void* stream);
+size_t rvcmi_front_workspace_bytes(const rvcmi_front* h);
+
+/* Test hook: stop after an internal stage and copy it to the host, channels-last [B][T'][192].
+ * what: "emb", "attn0", "layer0".."layer5" (encoder stream), "z_p", "flow3".."flow0" (flow stream after a coupling). */
+int rvcmi_front_debug_forward(rvcmi_front* h, int B, int T, const float* phone_dev, const int64_t* pitch_dev,
+                              const int64_t* lengths_dev, const float* g_dev, const float* noise_dev, int flow_head,
+                              const char* what, float* out_host, size_t capacity_floats, int64_t shape_out[3],
+                              void* stream);
+int rvcmi_front_profile_enable(rvcmi_front* h, int enable);
+int rvcmi_front_profile_read(rvcmi_front* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset);
+
+/* ------------------------------------------------------------------------------------------- */
 /* IVF-Flat retrieval (faiss IndexIVFFlat, METRIC_L2)                                           */
 /* ------------------------------------------------------------------------------------------- */
 

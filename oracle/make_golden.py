@@ -23,7 +23,8 @@ sys.path.insert(0, ROOT)
 REF = os.environ.get("RVC_REFERENCE", "/root/reference")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-from oracle import nsf_oracle, synth  # noqa: E402
+from oracle import front_oracle, nsf_oracle, synth  # noqa: E402
+from oracle.front_oracle import FrontConfig  # noqa: E402
 from oracle.nsf_oracle import CONFIGS, GenConfig  # noqa: E402
 
 
@@ -123,9 +124,113 @@ def infer_case(name: str = "infer_v2_48k_T20", T: int = 20, seed: int = 1234):
     return dec_sd
 
 
+def build_reference_net(cfg: GenConfig, fcfg: FrontConfig, w_dec, w_front):
+    """The reference's whole synthesizer (rvc/layers/synthesizers.py:23-113) carrying the seeded weights."""
+    sys.path.insert(0, REF)
+    from rvc.layers.synthesizers import SynthesizerTrnMsNSFsid
+
+    cl = [1025, 32, fcfg.inter_channels, fcfg.hidden_channels, fcfg.filter_channels, fcfg.n_heads, fcfg.n_layers, fcfg.kernel_size, 0, "1",
+          cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes, cfg.upsample_rates, cfg.upsample_initial_channel,
+          cfg.upsample_kernel_sizes, fcfg.spk_embed_dim, cfg.gin_channels, cfg.sr]
+    net = SynthesizerTrnMsNSFsid(*cl, encoder_dim=fcfg.in_channels, use_f0=True)
+    del net.enc_q
+    net.eval()
+    net.remove_weight_norm()
+    sd = net.state_dict()
+    for k, v in w_front.items():
+        assert k in sd and sd[k].shape == v.shape, k
+    sd.update(w_front)
+    sd.update({"dec." + k: v for k, v in w_dec.items()})
+    net.load_state_dict(sd, strict=True)
+    return net
+
+
+def front_case(name: str, B: int, T: int, lengths, flow_head=None, in_channels: int = 768, seed: int = 1234):
+    """enc_p + z_p + flow^-1 of the REFERENCE modules (encoders.py:134-159, synthesizers.py:182-183, residuals.py:319-321)
+    on seeded weights; the oracle restatement (oracle/front_oracle.py) is checked against them."""
+    cfg, fcfg = CONFIGS["v2_48k"], FrontConfig(in_channels=in_channels)
+    wf = synth.make_front_weights(fcfg, seed)
+    net = build_reference_net(cfg, fcfg, synth.make_dec_weights(cfg, seed), wf)
+    phone = synth.make_phone(B, T, in_channels, seed)
+    pitchf = synth.make_f0(B, T)
+    pitch = synth.make_pitch(pitchf)
+    lengths = torch.tensor(lengths, dtype=torch.long)
+    sid = torch.arange(B, dtype=torch.long) * 5
+    with torch.no_grad():
+        g = net.emb_g(sid).unsqueeze(-1)
+        m_p, logs_p, x_mask = net.enc_p(phone, pitch, lengths, flow_head)
+        gen = torch.Generator().manual_seed(seed + 9)
+        noise = torch.randn(m_p.shape, generator=gen)
+        z_p = (m_p + torch.exp(logs_p) * noise * 0.66666) * x_mask
+        z = net.flow(z_p, x_mask, g=g, reverse=True)
+        taps = {}
+        z2, m1, g2 = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, noise, flow_head, taps)
+    err = max((z2 - z).abs().max().item(), (taps["z_p"] - z_p).abs().max().item())
+    assert err < 2e-5, "%s: front oracle deviates from the reference by %g" % (name, err)
+    cl = lambda t: t.transpose(1, 2).contiguous().numpy()  # channels-last, the layout of the HIP debug taps
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), in_channels=in_channels, seed=seed, weights_sha256=synth.weights_sha256(wf),
+                        phone=phone.numpy(), pitch=pitch.numpy(), lengths=lengths.numpy(), sid=sid.numpy(), g=g.numpy(), noise=noise.numpy(),
+                        flow_head=-1 if flow_head is None else int(flow_head), z=(z * x_mask).numpy(), z_p=cl(z_p),
+                        emb=cl(taps["emb"]), attn0=cl(taps["attn0"]), layer0=cl(taps["layer0"]),
+                        layer5=cl(taps["layer%d" % (fcfg.n_layers - 1)]), oracle_max_abs_dev=err)
+    print("%-28s z rms %.3f  oracle-vs-reference max dev %.2e  (%d KB)" % (
+        name, z.pow(2).mean().sqrt().item(), err, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
+def infer_full_case(name: str, T: int, skip_head=None, return_length=None, return_length2=None, seed: int = 1234):
+    """The reference's whole ``net_g.infer`` (synthesizers.py:160-203) on seeded enc_p / flow / dec weights, RNG seeded with
+    the reference's own 114514; the three draws (z_p noise, rand_ini, generator noise) are re-derived and stored."""
+    cfg, fcfg = CONFIGS["v2_48k"], FrontConfig()
+    wd, wf = synth.make_dec_weights(cfg, seed), synth.make_front_weights(fcfg, seed)
+    net = build_reference_net(cfg, fcfg, wd, wf)
+    phone = synth.make_phone(1, T, 768, seed)
+    pitchf = synth.make_f0(1, T)
+    pitch = synth.make_pitch(pitchf)
+    lengths, sid = torch.tensor([T]), torch.tensor([3])
+    torch.manual_seed(114514)
+    with torch.no_grad():
+        o = net.infer(phone, lengths, sid, pitch, pitchf, skip_head, return_length, return_length2)
+    fh = 0 if skip_head is None else max(int(skip_head) - 24, 0)
+    Td = T if skip_head is None else int(return_length)
+    Te = Td if return_length2 is None else int(return_length2)
+    gen = torch.Generator().manual_seed(114514)
+    nz_zp = torch.randn(1, 192, T - fh, generator=gen)
+    torch.rand(1, 1, 1, generator=gen)
+    nz_dec = torch.randn(1, Td * cfg.upp, 1, generator=gen).squeeze(-1)  # drawn at the decoder's T, before the n_res interpolation (nsf.py:155-162)
+    with torch.no_grad():  # oracle front + oracle generator must reproduce the reference end to end
+        z, m1, g = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, nz_zp, fh if skip_head is not None else None)
+        z = z * m1
+        pf = pitchf
+        if skip_head is not None:
+            dh = int(skip_head) - fh
+            z = z[:, :, dh:dh + Td]
+            pf = pitchf[:, int(skip_head):int(skip_head) + Td]
+        ora = nsf_oracle.generator_forward(cfg, wd, z, pf, g, nz_dec, n_res=return_length2)
+    err = (ora - o).abs().max().item()
+    assert err < 2e-5, "%s: oracle deviates from the reference infer by %g" % (name, err)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), seed=seed, phone=phone.numpy(), pitch=pitch.numpy(), pitchf=pitchf.numpy(),
+                        sid=sid.numpy(), noise_zp=nz_zp.numpy(), noise_dec=nz_dec.numpy(), out=o.numpy(),
+                        skip_head=-1 if skip_head is None else int(skip_head), return_length=-1 if return_length is None else int(return_length),
+                        return_length2=-1 if return_length2 is None else int(return_length2), oracle_max_abs_dev=err,
+                        front_sha256=synth.weights_sha256(wf), dec_sha256=synth.weights_sha256(wd))
+    print("%-28s out rms %.3f  oracle-vs-reference max dev %.2e  (%d KB)" % (
+        name, o.pow(2).mean().sqrt().item(), err, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
+def main_front():
+    front_case("front_v2_B2_T50", 2, 50, [50, 43])
+    front_case("front_v2_B1_T100_head6", 1, 100, [100], flow_head=6)     # > one 64-row tile, realtime flow_head
+    front_case("front_v1_B1_T40", 1, 40, [40], in_channels=256)           # v1: 256-d features
+    infer_full_case("infer_full_v2_48k_T40", 40)
+    infer_full_case("infer_full_v2_48k_rt", 70, skip_head=40, return_length=20, return_length2=24)  # rtrvc.py:134-260 geometry
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    main_front()
+    if os.environ.get("GOLDEN_ONLY_FRONT"):
+        return
     dec_case("dec_v2_48k_B2_T24", "v2_48k", 2, 24)
     dec_case("dec_v2_48k_B1_T70", "v2_48k", 1, 70)           # > one fused-resblock tile at every stage
     dec_case("dec_v2_32k_B1_T16", "v2_32k", 1, 16)

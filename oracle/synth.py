@@ -16,6 +16,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 import torch
 
+from .front_oracle import FrontConfig
 from .nsf_oracle import GenConfig
 
 
@@ -66,6 +67,71 @@ def make_dec_weights(cfg: GenConfig, seed: int = 1234) -> "OrderedDict[str, torc
     ch = c0 // 2 ** n_up
     w["conv_post.weight"] = 0.25 * _randn(gen, 1, ch, 7) / math.sqrt(ch * 7)
     return w
+
+
+def make_front_weights(cfg: FrontConfig, seed: int = 1234) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded ``enc_p.* / flow.* / emb_g.weight`` tensors keyed like ``net_g.state_dict()`` after
+    ``remove_weight_norm()`` (shapes: rvc/layers/encoders.py:103-116, attentions.py:36-54,230-231,
+    residuals.py:190-201, norms.py:50-82).  The constructor's defaults would make the test blind
+    (``post`` is zero-initialised, residuals.py:200-201 => the flow is the identity), so every layer gets
+    O(1)-preserving random weights, including non-trivial LayerNorm gains and biases."""
+    gen = torch.Generator().manual_seed(seed + 77)
+    w: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    Hc, Fc, dk = cfg.hidden_channels, cfg.filter_channels, cfg.hidden_channels // cfg.n_heads
+    w["enc_p.emb_phone.weight"] = _randn(gen, Hc, cfg.in_channels) / math.sqrt(cfg.in_channels) / 4.0
+    w["enc_p.emb_phone.bias"] = 0.02 * _randn(gen, Hc)
+    if cfg.use_f0:
+        w["enc_p.emb_pitch.weight"] = 0.05 * _randn(gen, 256, Hc)
+    for i in range(cfg.n_layers):
+        a = "enc_p.encoder.attn_layers.%d." % i
+        w[a + "emb_rel_k"] = _randn(gen, 1, 2 * cfg.window_size + 1, dk) * dk ** -0.5
+        w[a + "emb_rel_v"] = _randn(gen, 1, 2 * cfg.window_size + 1, dk) * dk ** -0.5
+        for nm, gain in (("conv_q", 1.5), ("conv_k", 1.5), ("conv_v", 1.0), ("conv_o", 0.7)):
+            w[a + nm + ".weight"] = gain * _randn(gen, Hc, Hc, 1) / math.sqrt(Hc)
+            w[a + nm + ".bias"] = 0.1 * _randn(gen, Hc)
+        w["enc_p.encoder.norm_layers_1.%d.gamma" % i] = 1.0 + 0.1 * _randn(gen, Hc)
+        w["enc_p.encoder.norm_layers_1.%d.beta" % i] = 0.1 * _randn(gen, Hc)
+        f = "enc_p.encoder.ffn_layers.%d." % i
+        w[f + "conv_1.weight"] = 1.4 * _randn(gen, Fc, Hc, cfg.kernel_size) / math.sqrt(Hc * cfg.kernel_size)
+        w[f + "conv_1.bias"] = 0.1 * _randn(gen, Fc)
+        w[f + "conv_2.weight"] = 0.7 * _randn(gen, Hc, Fc, cfg.kernel_size) / math.sqrt(Fc * cfg.kernel_size)
+        w[f + "conv_2.bias"] = 0.1 * _randn(gen, Hc)
+        w["enc_p.encoder.norm_layers_2.%d.gamma" % i] = 1.0 + 0.1 * _randn(gen, Hc)
+        w["enc_p.encoder.norm_layers_2.%d.beta" % i] = 0.1 * _randn(gen, Hc)
+    pw = _randn(gen, 2 * cfg.inter_channels, Hc, 1) / math.sqrt(Hc)
+    pw[cfg.inter_channels:] *= 0.3  # logs rows: keep exp(logs) within a sane range
+    w["enc_p.proj.weight"] = pw
+    pb = 0.1 * _randn(gen, 2 * cfg.inter_channels)
+    pb[cfg.inter_channels:] -= 0.5
+    w["enc_p.proj.bias"] = pb
+    half = cfg.inter_channels // 2
+    for fl in range(cfg.flow_n_flows):
+        p = "flow.flows.%d." % (2 * fl)
+        w[p + "pre.weight"] = _randn(gen, Hc, half, 1) / math.sqrt(half)
+        w[p + "pre.bias"] = 0.1 * _randn(gen, Hc)
+        for l in range(cfg.flow_n_layers):
+            w[p + "enc.in_layers.%d.weight" % l] = _randn(gen, 2 * Hc, Hc, cfg.flow_kernel_size) / math.sqrt(Hc * cfg.flow_kernel_size)
+            w[p + "enc.in_layers.%d.bias" % l] = 0.1 * _randn(gen, 2 * Hc)
+            rs = 2 * Hc if l < cfg.flow_n_layers - 1 else Hc
+            w[p + "enc.res_skip_layers.%d.weight" % l] = 1.5 * _randn(gen, rs, Hc, 1) / math.sqrt(Hc)
+            w[p + "enc.res_skip_layers.%d.bias" % l] = 0.1 * _randn(gen, rs)
+        if cfg.gin_channels:
+            w[p + "enc.cond_layer.weight"] = 0.5 * _randn(gen, 2 * Hc * cfg.flow_n_layers, cfg.gin_channels, 1) / math.sqrt(cfg.gin_channels)
+            w[p + "enc.cond_layer.bias"] = 0.1 * _randn(gen, 2 * Hc * cfg.flow_n_layers)
+        w[p + "post.weight"] = 0.7 * _randn(gen, half, Hc, 1) / math.sqrt(Hc)
+        w[p + "post.bias"] = 0.05 * _randn(gen, half)
+    w["emb_g.weight"] = _randn(gen, cfg.spk_embed_dim, cfg.gin_channels)
+    return w
+
+
+def make_pitch(pitchf: torch.Tensor) -> torch.Tensor:
+    """Coarse pitch bins 1..255 from f0 in Hz (rvc/f0/gen.py:34-40: mel scale between 50 and 1100 Hz)."""
+    mel = 1127.0 * torch.log(1 + pitchf / 700.0)
+    lo, hi = 1127.0 * math.log(1 + 50.0 / 700.0), 1127.0 * math.log(1 + 1100.0 / 700.0)
+    mel = torch.where(mel > 0, (mel - lo) * 254.0 / (hi - lo) + 1.0, mel)
+    mel = torch.where(mel <= 1, torch.ones(()), mel)
+    mel = torch.where(mel > 255, torch.full((), 255.0), mel)
+    return torch.round(mel).long()
 
 
 def weights_sha256(w: Dict[str, torch.Tensor]) -> str:

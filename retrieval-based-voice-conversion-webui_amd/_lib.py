@@ -14,7 +14,7 @@ from typing import List
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librvcmi.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["nsf.hip", "ivf.hip"]
+SOURCES = ["nsf.hip", "ivf.hip", "front.hip"]
 
 RVCMI_MAX_UPS, RVCMI_MAX_RB, RVCMI_MAX_DIL = 8, 4, 4
 OPERANDS = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2}
@@ -36,6 +36,13 @@ class NsfConfig(C.Structure):
         ("resblock_dilation_sizes", (C.c_int * RVCMI_MAX_DIL) * RVCMI_MAX_RB),
         ("operand", C.c_int),
     ]
+
+
+class FrontConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "in_channels", "inter_channels", "hidden_channels", "filter_channels", "n_heads", "n_layers", "kernel_size",
+        "window_size", "gin_channels", "use_f0", "flow_n_flows", "flow_n_layers", "flow_kernel_size", "flow_dilation_rate",
+        "operand")]
 
 
 class Tensor(C.Structure):
@@ -61,6 +68,14 @@ SYMBOLS = [
                                           C.POINTER(C.c_int64), _P]),
     ("rvcmi_nsf_profile_enable", C.c_int, [_P, C.c_int]),
     ("rvcmi_nsf_profile_read", C.c_int, [_P, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int), C.c_int]),
+    ("rvcmi_front_create", C.c_int, [C.POINTER(FrontConfig), C.POINTER(Tensor), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("rvcmi_front_destroy", C.c_int, [_P]),
+    ("rvcmi_front_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    ("rvcmi_front_workspace_bytes", C.c_size_t, [_P]),
+    ("rvcmi_front_debug_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_char_p, _P, C.c_size_t,
+                                            C.POINTER(C.c_int64), _P]),
+    ("rvcmi_front_profile_enable", C.c_int, [_P, C.c_int]),
+    ("rvcmi_front_profile_read", C.c_int, [_P, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int), C.c_int]),
     ("rvcmi_ivf_create_from_file", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
     ("rvcmi_ivf_write_file", C.c_int, [_P, C.c_char_p]),
     ("rvcmi_ivf_create", C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(_P)]),

@@ -33,7 +33,7 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 // torch's CPU cumsum accumulates fp32 inputs in DOUBLE and rounds each prefix to fp32
 // (verified against torch 2.10); a wave-level scan in fp64 reproduces that to the last bit except
 // on exact rounding boundaries.  One wave (64 lanes) per utterance.
-__global__ void __launch_bounds__(64) k_phase_scan(const float* __restrict__ f0, float* __restrict__ phase,
+static __global__ void __launch_bounds__(64) k_phase_scan(const float* __restrict__ f0, float* __restrict__ phase,
                                                    int T, float sr, float upp) {
 #pragma clang fp contract(off)
     const int b = blockIdx.x;
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(64) k_phase_scan(const float* __restrict__ f0,
 }
 
 // har[b][t*upp + n-1] = tanh(lw * (0.1*sin(2*pi*(f0/sr*n + phase)) * uv + amp * noise) + lb)
-__global__ void __launch_bounds__(256) k_sine_source(const float* __restrict__ f0, const float* __restrict__ phase,
+static __global__ void __launch_bounds__(256) k_sine_source(const float* __restrict__ f0, const float* __restrict__ phase,
                                                      const float* __restrict__ noise, float* __restrict__ har,
                                                      int T, int upp, float sr, float lw, float lb, size_t total) {
 #pragma clang fp contract(off)
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_sine_source(const float* __restrict__ f
 
 // F.interpolate(mode="linear", align_corners=False) along the last axis of [rows][Lin] -> [rows][Lout]
 // (nsf.py:155-162, generators.py:76-79).
-__global__ void __launch_bounds__(256) k_interp_linear(const float* __restrict__ in, float* __restrict__ out,
+static __global__ void __launch_bounds__(256) k_interp_linear(const float* __restrict__ in, float* __restrict__ out,
                                                        int Lin, int Lout, size_t total) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) k_interp_linear(const float* __restrict__
 
 // cond(g): a 1x1 conv over a length-1 sequence = one GEMV per utterance (nsf.py:165-166).
 // One wave per output channel: the weight row is read coalesced and reduced with xor-shuffles.
-__global__ void __launch_bounds__(256) k_cond(const float* __restrict__ g, const float* __restrict__ Wc,
+static __global__ void __launch_bounds__(256) k_cond(const float* __restrict__ g, const float* __restrict__ Wc,
                                               const float* __restrict__ bc, float* __restrict__ out, int gin, int C0) {
     const int b = blockIdx.y;
     const int co = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -175,7 +175,7 @@ struct ConvArgs {
 };
 
 // One thread per (q, co); co fastest so that weight reads and stores coalesce.
-__global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
+static __global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
     const int b = blockIdx.z;
     const int ph = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
 }
 
 // x[b][t][co] += bn[co] + sum_j har[b][t*s - pad + j] * Wn[j][co]      (nsf.py:173-174)
-__global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x, const float* __restrict__ har,
+static __global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x, const float* __restrict__ har,
                                                    const float* __restrict__ Wn /*[k][C]*/, const float* __restrict__ bn,
                                                    int L, int C, int Lh, int k, int s, int pad) {
     const int b = blockIdx.z;
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x, const 
 // HBM-bound: the last stage is read exactly once with coalesced float4 loads into an LDS tile whose
 // row stride C+1 makes the per-thread row walk conflict-free.
 constexpr int POST_TT = 256;
-__global__ void __launch_bounds__(256) k_post(const float* __restrict__ xa, const float* __restrict__ xb,
+static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ xa, const float* __restrict__ xb,
                                               const float* __restrict__ xc, const float* __restrict__ Wp /*[7][C]*/,
                                               float* __restrict__ out, int L, int C, float div) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -282,14 +282,14 @@ __global__ void __launch_bounds__(256) k_post(const float* __restrict__ xa, cons
 }
 
 // y = (a + b) + c   (debug tap of the stage sum only)
-__global__ void __launch_bounds__(256) k_sum3(const float* __restrict__ a, const float* __restrict__ b,
+static __global__ void __launch_bounds__(256) k_sum3(const float* __restrict__ a, const float* __restrict__ b,
                                               const float* __restrict__ c, float* __restrict__ y, size_t n) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = (a[i] + (b ? b[i] : 0.f)) + (c ? c[i] : 0.f);
 }
 
 // channels-last fp32 [B][L][C] -> channel-first [B][C][L] (debug taps only)
-__global__ void __launch_bounds__(256) k_cl_to_cf(const float* __restrict__ in, float* __restrict__ out, int L, int C) {
+static __global__ void __launch_bounds__(256) k_cl_to_cf(const float* __restrict__ in, float* __restrict__ out, int L, int C) {
     const int b = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)L * C) return;
@@ -533,7 +533,7 @@ __device__ __forceinline__ void conv_core(f32x16 (&acc)[MI][NJ], const char* lds
 // Generic single-conv kernel: stage tile -> conv_core -> epilogue.  Grid: x = time tile,
 // y = (co block) * nphase + phase, z = batch.  Block = 4 waves laid out WCO (co) x WT (time).
 template <typename OpT, int CIN, int MI, int NJ, int WCO>
-__global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
+static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
     using TL = Tile<CIN>;
     constexpr int WT = 4 / WCO;
     constexpr int TT = WT * NJ * 32;
@@ -678,7 +678,7 @@ constexpr int RB_ROWS = 128;  // default conv1 output rows per tile = 4 MFMA col
 // Waves are laid out NW (output-channel slices of 32*MI) x NWT (time slabs of 32*NJ_ rows); OCC = waves per SIMD the
 // register budget is capped for.
 template <typename OpT, int C, int MI, int NW, int KG, int NJ_ = RB_ROWS / 32, int NWT = 1, int OCC = 2>
-__global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArgs a) {
+static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArgs a) {
     constexpr int ROWS = 32 * NJ_ * NWT;  // conv1 output rows per tile
     using TL = Tile<C>;
     using frag = typename Op<OpT>::frag;
@@ -690,12 +690,19 @@ __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArgs a) {
     constexpr int CP = 32 * MI * NW;  // padded channel count
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const RbJob& J = a.job[blockIdx.y];
-    if ((int)blockIdx.x >= J.ntiles) return;
+#ifdef RVCMI_RB_INTERLEAVE
+    // dev experiment: co-resident blocks take different jobs (kernel sizes) so their load / MFMA phases drift apart
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int bjob = lin % gridDim.y, btile = lin / gridDim.y;
+#else
+    const int bjob = blockIdx.y, btile = blockIdx.x;
+#endif
+    const RbJob& J = a.job[bjob];
+    if (btile >= J.ntiles) return;
     const int b = blockIdx.z;
     const int p2 = (J.k - 1) / 2;
     const int p1 = J.dil * (J.k - 1) / 2;
-    const int t0 = blockIdx.x * J.tt2;          // first output time of this tile
+    const int t0 = btile * J.tt2;          // first output time of this tile
     const int h0 = t0 - p2;                     // global time of h row 0
     const int x0 = h0 - p1;                     // global time of X row 0
     const int xrows = ROWS + (J.k_p - 1) * J.dil;
@@ -887,7 +894,7 @@ struct UpsArgs {
 };
 
 template <typename OpT, int CIN, int MI, int WV>
-__global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks per CU: one block stages / stores while the other multiplies
+static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks per CU: one block stages / stores while the other multiplies
     using TL = Tile<CIN>;
     using frag = typename Op<OpT>::frag;
     constexpr int STRIDE = TL::STRIDE;
@@ -1089,7 +1096,7 @@ constexpr int RBF_G = 32;   // zero guard rows around X (>= max dilated half-wid
 constexpr int RBF_G2 = 8;   // zero guard rows around H
 
 template <typename OpT, int C, int MI, int NJ, int KG, int NB, int OCC = 1, int NWV = 4>
-__global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) {
+static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) {
     constexpr int NT = 64 * NWV;  // NWV waves, each owning a slab of 32*NJ rows
     using TL = Tile<C>;
     constexpr int STRIDE = TL::STRIDE;

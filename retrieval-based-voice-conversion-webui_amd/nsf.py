@@ -11,7 +11,7 @@ Differences a caller can observe: (1) the two RNG draws the reference makes insi
 (``torch.rand(1,1,1)`` then ``torch.randn_like([B,T*upp,1])``, generators.py:164,192) are made here
 with the same calls on the same device, so a seeded run consumes the generator identically -- and
 may be overridden with ``noise=`` for bit-reproducible parity tests against the CPU path;
-(2) MFMA operands are rounded to bf16 (default) or fp16 with fp32 accumulation and an fp32
+(2) MFMA operands are rounded to fp16 (default) or bf16 with fp32 accumulation and an fp32
 residual stream; ``operand="fp32"`` selects exact-fp32 kernels.
 """
 from __future__ import annotations
@@ -58,7 +58,7 @@ def _cfg_struct(cfg: dict, operand: str) -> _lib.NsfConfig:
 class _HipGenerator(torch.nn.Module):
     """Shared implementation; see NSFGeneratorHIP / GeneratorHIP."""
 
-    def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], device="cuda:0", operand: str = "bf16",
+    def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], device="cuda:0", operand: str = "fp16",
                  max_B: int = 1, max_T: int = 256):
         super().__init__()
         self.cfg = dict(cfg)
@@ -211,7 +211,7 @@ class NSFGeneratorHIP(_HipGenerator):
         return self._run(x, f0, g, n_res, noise, tap=what)
 
     @classmethod
-    def from_reference(cls, dec: torch.nn.Module, device="cuda:0", operand: str = "bf16", **kw) -> "NSFGeneratorHIP":
+    def from_reference(cls, dec: torch.nn.Module, device="cuda:0", operand: str = "fp16", **kw) -> "NSFGeneratorHIP":
         """Build from a reference module AFTER ``remove_weight_norm()`` has folded g*v/|v|
         (rvc/synthesizer.py:27): takes ``dec.state_dict()`` as is."""
         cfg = config_from_reference(dec)
@@ -230,7 +230,7 @@ class GeneratorHIP(_HipGenerator):
         return self._run(x, None, g, n_res, None, tap=what)
 
     @classmethod
-    def from_reference(cls, dec: torch.nn.Module, device="cuda:0", operand: str = "bf16", **kw) -> "GeneratorHIP":
+    def from_reference(cls, dec: torch.nn.Module, device="cuda:0", operand: str = "fp16", **kw) -> "GeneratorHIP":
         cfg = config_from_reference(dec)
         if cfg["use_f0"]:
             raise ValueError("module has an m_source: use NSFGeneratorHIP.from_reference")

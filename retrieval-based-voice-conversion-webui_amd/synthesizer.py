@@ -14,7 +14,7 @@ import torch
 from .nsf import GeneratorHIP, NSFGeneratorHIP
 
 
-def accelerate_synthesizer(net_g: torch.nn.Module, device=None, operand: str = "bf16", max_B: int = 1, max_T: int = 256):
+def accelerate_synthesizer(net_g: torch.nn.Module, device=None, operand: str = "fp16", max_B: int = 1, max_T: int = 256):
     """Swap ``net_g.dec`` (already weight-norm-folded, rvc/synthesizer.py:27) for the HIP generator.
     ``net_g.infer`` (rvc/layers/synthesizers.py:160-203) keeps working unchanged: it type-switches on
     ``isinstance(self.dec, NSFGenerator)`` / ``Generator`` so the replacement classes are registered as
@@ -46,7 +46,7 @@ def _as_reference_subclass(new, old):
     return new
 
 
-def get_synthesizer(cpt, device=torch.device("cpu"), operand: str = "bf16"):
+def get_synthesizer(cpt, device=torch.device("cpu"), operand: str = "fp16"):
     from rvc.synthesizer import get_synthesizer as _ref_get  # the reference's own loader
 
     net_g, cpt = _ref_get(cpt, device)
@@ -55,5 +55,5 @@ def get_synthesizer(cpt, device=torch.device("cpu"), operand: str = "bf16"):
     return net_g, cpt
 
 
-def load_synthesizer(pth_path, device=torch.device("cpu"), operand: str = "bf16"):
+def load_synthesizer(pth_path, device=torch.device("cpu"), operand: str = "fp16"):
     return get_synthesizer(torch.load(pth_path, map_location=torch.device("cpu"), weights_only=True), device, operand)

@@ -1,0 +1,166 @@
+"""GPU parity of the synthesizer front (enc_p + z_p + flow^-1) and of the whole ``infer``.
+
+Fixtures come from the REAL reference modules (oracle/make_golden.py: TextEncoder, ResidualCouplingBlock and
+SynthesizerTrnMsNSFsid.infer executed on torch-CPU with seeded weights); other sizes compare against the oracle.
+Bars: MFMA operands are fp16 with fp32 accumulation, fp32 LayerNorm / softmax / gates; z has unit scale, so the
+bar on z is 5e-3 RMS (measured ~1e-3), and the north-star bar on the waveform stays 1e-3 RMS."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, rms
+from oracle import front_oracle, nsf_oracle, synth
+from oracle.front_oracle import FrontConfig
+
+pytestmark = pytest.mark.gpu
+
+Z_BAR = {"fp16": 5e-3, "bf16": 4e-2}
+_cache = {}
+
+
+def front_weights(d, in_channels=768):
+    fcfg = FrontConfig(in_channels=in_channels)
+    key = ("wf", in_channels, int(d["seed"]))
+    if key not in _cache:
+        _cache[key] = synth.make_front_weights(fcfg, int(d["seed"]))
+    wf = _cache[key]
+    sha = str(d["weights_sha256"]) if "weights_sha256" in d else str(d["front_sha256"])
+    assert synth.weights_sha256(wf) == sha, "seeded front weights differ from the fixture's (torch RNG changed?)"
+    return fcfg, wf
+
+
+def hip_front(fcfg, wf, operand, gpu, max_B=2, max_T=128):
+    import rvc_amd
+
+    return rvc_amd.FrontHIP(vars(fcfg), wf, device=gpu, operand=operand, max_B=max_B, max_T=max_T)
+
+
+def dev(d, k, gpu):
+    return torch.from_numpy(d[k]).to(gpu)
+
+
+@pytest.mark.parametrize("operand", ["fp16", "bf16"])
+@pytest.mark.parametrize("name", golden_names("front_"))
+def test_front_matches_reference_golden(name, operand, gpu):
+    d = load_golden(name)
+    fcfg, wf = front_weights(d, int(d["in_channels"]))
+    fr = hip_front(fcfg, wf, operand, gpu)
+    fh = max(int(d["flow_head"]), 0)
+    args = (dev(d, "phone", gpu), dev(d, "pitch", gpu), dev(d, "lengths", gpu), dev(d, "g", gpu))
+    nz = dev(d, "noise", gpu)
+    z = fr(*args, fh, noise=nz).cpu()
+    assert z.shape == d["z"].shape and torch.isfinite(z).all()
+    e = rms(z, d["z"])
+    assert e <= Z_BAR[operand], "%s/%s: z RMS error %.3e exceeds %.1e" % (name, operand, e, Z_BAR[operand])
+    if operand == "fp16":  # stage-by-stage (channels-last taps): localises a regression
+        for tap, bar in (("emb", 2e-3), ("attn0", 4e-3), ("layer0", 4e-3), ("layer5", 5e-3), ("z_p", 5e-3)):
+            ref = d[tap]
+            got = fr.debug_tap(tap, *args, fh, noise=nz)
+            assert got.shape == ref.shape, (tap, got.shape, ref.shape)
+            et = rms(got, ref)
+            assert et <= bar, "%s: tap %s RMS error %.3e exceeds %.1e" % (name, tap, et, bar)
+
+
+def test_padding_rows_do_not_leak(gpu):
+    """Rows beyond phone_lengths are masked exactly as x_mask does (encoders.py:145-148, attentions.py:114-115):
+    the valid part of z must not depend on what the padding rows contain."""
+    d = load_golden("front_v2_B2_T50")
+    fcfg, wf = front_weights(d)
+    fr = hip_front(fcfg, wf, "fp16", gpu)
+    phone = dev(d, "phone", gpu).clone()
+    args = lambda ph: (ph, dev(d, "pitch", gpu), dev(d, "lengths", gpu), dev(d, "g", gpu))
+    nz = dev(d, "noise", gpu)
+    z0 = fr(*args(phone), 0, noise=nz).cpu()
+    L1 = int(d["lengths"][1])
+    phone[1, L1:] = 37.0  # garbage in the padded frames of utterance 1
+    z1 = fr(*args(phone), 0, noise=nz).cpu()
+    assert torch.equal(z0[0], z1[0])
+    assert torch.equal(z0[1, :, :L1], z1[1, :, :L1])
+    assert (z1[1, :, L1:] == 0).all()
+
+
+@pytest.mark.parametrize("T,B,fh", [(1, 1, 0), (31, 1, 0), (64, 2, 0), (65, 1, 0), (200, 1, 30)])
+def test_front_against_oracle_other_sizes(T, B, fh, gpu):
+    fcfg = FrontConfig()
+    wf = synth.make_front_weights(fcfg, 77)
+    fr = hip_front(fcfg, wf, "fp16", gpu, max_B=2, max_T=256)
+    phone = synth.make_phone(B, T, 768, 77)
+    pitch = synth.make_pitch(synth.make_f0(B, T))
+    lengths = torch.tensor([T, max(1, T - 9)][:B])
+    sid = torch.tensor([1, 7][:B])
+    gen = torch.Generator().manual_seed(3)
+    noise = torch.randn(B, 192, T - fh, generator=gen)
+    with torch.no_grad():
+        z, m1, g = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, noise, fh if fh else None)
+        z = z * m1
+    got = fr(phone.to(gpu), pitch.to(gpu), lengths.to(gpu), g.to(gpu), fh, noise=noise.to(gpu)).cpu()
+    e = rms(got, z)
+    assert e <= Z_BAR["fp16"], "T=%d B=%d: z RMS error %.3e" % (T, B, e)
+
+
+class _Net:
+    """What infer_hip needs of net_g: emb_g and dec (no reference import on the GPU box)."""
+
+    def __init__(self, wf, dec):
+        self.emb_g = lambda sid: wf["emb_g.weight"].to(sid.device)[sid]
+        self.dec = dec
+
+
+@pytest.mark.parametrize("name", golden_names("infer_full_"))
+def test_whole_infer_matches_reference_golden(name, gpu):
+    """enc_p -> z_p -> flow^-1 -> NSF generator, all HIP, against the reference's net_g.infer waveform (<= 1e-3 RMS)."""
+    import rvc_amd
+
+    infer_hip = rvc_amd.infer_hip
+
+    d = load_golden(name)
+    fcfg, wf = front_weights(d)
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    wd = synth.make_dec_weights(cfg, int(d["seed"]))
+    assert synth.weights_sha256(wd) == str(d["dec_sha256"])
+    fr = hip_front(fcfg, wf, "fp16", gpu, max_B=1, max_T=128)
+    dec = rvc_amd.NSFGeneratorHIP(vars(cfg), wd, device=gpu, operand="fp16", max_B=1, max_T=128)
+    T = d["phone"].shape[1]
+    opt = lambda k: None if int(d[k]) < 0 else int(d[k])
+    out = infer_hip(_Net(wf, dec), fr, dev(d, "phone", gpu), torch.tensor([T], device=gpu), dev(d, "sid", gpu), dev(d, "pitch", gpu),
+                    dev(d, "pitchf", gpu), opt("skip_head"), opt("return_length"), opt("return_length2"),
+                    noise_zp=dev(d, "noise_zp", gpu), noise_dec=dev(d, "noise_dec", gpu)).cpu()
+    assert out.shape == d["out"].shape
+    e = rms(out, d["out"])
+    assert e <= 1e-3, "%s: waveform RMS error %.3e vs the reference infer exceeds 1e-3" % (name, e)
+
+
+def test_front_rng_stream_matches_reference_draw(gpu):
+    """Without noise= the front draws randn_like(m_p) once, [B, inter, T - flow_head], from the input's device generator."""
+    fcfg = FrontConfig()
+    wf = synth.make_front_weights(fcfg, 5)
+    fr = hip_front(fcfg, wf, "fp16", gpu, max_B=1, max_T=64)
+    T = 40
+    phone = synth.make_phone(1, T, 768, 5).to(gpu)
+    pitch = synth.make_pitch(synth.make_f0(1, T)).to(gpu)
+    g = wf["emb_g.weight"][:1].to(gpu)
+    torch.manual_seed(11)
+    a = fr(phone, pitch, None, g, 4)
+    after = torch.rand(1, device=gpu)
+    torch.manual_seed(11)
+    nz = torch.randn(1, 192, T - 4, device=gpu)
+    b = fr(phone, pitch, None, g, 4, noise=nz)
+    assert torch.equal(a, b) and torch.equal(after, torch.rand(1, device=gpu))
+
+
+def test_front_rejects_bad_input(gpu):
+    import rvc_amd
+
+    fcfg = FrontConfig()
+    wf = synth.make_front_weights(fcfg, 5)
+    fr = hip_front(fcfg, wf, "fp16", gpu, max_B=1, max_T=32)
+    with pytest.raises(ValueError):
+        fr(torch.zeros(1, 8, 100, device=gpu), None, None, None)
+    with pytest.raises(ValueError):
+        rvc_amd.FrontHIP(vars(fcfg), wf, device=gpu, operand="fp32")
+    bad = dict(wf)
+    del bad["flow.flows.2.post.bias"]
+    with pytest.raises(rvc_amd.RvcmiError):
+        rvc_amd.FrontHIP(vars(fcfg), bad, device=gpu)
+    with pytest.raises(rvc_amd.RvcmiError):
+        rvc_amd.FrontHIP(vars(FrontConfig(n_heads=4)), wf, device=gpu)
