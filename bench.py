@@ -264,6 +264,58 @@ def main():
             roof["ivf_scan_hbm"] = {"achieved": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                     "frac": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 8e12}
 
+    # ---- whole net_g.infer leg: retrieval -> x2 frames -> enc_p -> z_p -> flow^-1 -> decode, one graph ----
+    whole = None
+    if rank == 0 and not a.no_roofline and a.index_d == 768 and a.operand != "fp32":
+        from oracle.front_oracle import FrontConfig
+
+        fcfg = FrontConfig()
+        wf = synth.make_front_weights(fcfg, 1234)
+        front = rvc_amd.FrontHIP(vars(fcfg), wf, device=dev, operand=a.operand, max_B=B, max_T=T)
+        pitch_d = synth.make_pitch(f0).to(dev)
+        nz_zp = torch.randn(B, fcfg.inter_channels, T, device=dev)
+        reps = T // NQ_CLIP
+
+        def step_whole():
+            feats.copy_(phone_d)
+            index.search_blend(feats, a.index_rate, 8)
+            ph = feats.view(B, NQ_CLIP, a.index_d).repeat_interleave(reps, dim=1)  # F.interpolate(scale_factor=2), pipeline.py:146 (torch glue)
+            zz = front(ph, pitch_d[:, :ph.shape[1]], None, gd, 0, noise=nz_zp[:, :, :ph.shape[1]])
+            out_holder["w"] = gen(zz, f0d[:, :ph.shape[1]], gd, noise=nd[:, :ph.shape[1] * cfg.upp])
+
+        try:
+            for _ in range(2):
+                step_whole()
+            torch.cuda.synchronize()
+            runw = step_whole
+            if a.graph:
+                gw = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gw):
+                    step_whole()
+                runw = gw.replay
+            for _ in range(a.warmup):
+                runw()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                runw()
+            torch.cuda.synchronize()
+            dtw = (time.perf_counter() - t0) / a.steps
+            assert torch.isfinite(out_holder["w"]).all()
+            front.profile(True)
+            for _ in range(3):
+                step_whole()
+            torch.cuda.synchronize()
+            fs = front.profile_read()
+            front.profile(False)
+            Tw = reps * NQ_CLIP
+            whole = {"what": "retrieval + x2 frames + enc_p + z_p + flow^-1 + decode (the whole net_g.infer of the pipeline), one hipGraph",
+                     "ms_per_step": 1e3 * dtw, "value": B * CLIP_SECONDS * (Tw / T_CLIP) / dtw, "unit": "x real-time",
+                     "front_kernels_ms_per_step": {s_["name"]: round(s_["ms"] / 3.0, 4) for s_ in fs},
+                     "front_ms_per_step": round(sum(s_["ms"] for s_ in fs) / 3.0, 4)}
+        except Exception as e:  # noqa
+            print("[bench] whole-infer leg failed: %s" % e, file=sys.stderr)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, a.index_rate)
@@ -287,6 +339,8 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
+        if whole is not None:
+            line["whole_infer"] = whole
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))

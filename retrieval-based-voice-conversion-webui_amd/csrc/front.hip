@@ -27,8 +27,6 @@ struct FlowLayer {
     int phys_base = 0;
 };
 
-constexpr int FR_NJ = 2;  // 64-row time tiles
-
 }  // namespace
 
 struct rvcmi_front {
@@ -40,7 +38,7 @@ struct rvcmi_front {
     std::vector<FlowLayer> flows;
     DevBuf cond_w, cond_b;  // all flows' cond_layer concatenated: [n_flows * 2H * n_layers][gin]
     // workspace
-    DevBuf X, QK, VT, A, F, ZP, Ha, Hb, SK, GC;
+    DevBuf X, QK, KF, VT, A, F, ZP, Ha, Hb, SK, GC;  // QK: q [B][T][H]; KF / VT: k / v tiles in fragment order
     size_t ws_bytes = 0;
     Profiler prof;
 };
@@ -59,19 +57,23 @@ const float* wdata(const WeightMap& wm, const std::string& name, std::initialize
     return (const float*)wm.get(name, shape).data;
 }
 
-template <typename OpT, int CIN, int MI, int NW, int EPI>
-void launch_conv(rvcmi_front* h, const char* name, FrConvArgs a, const ConvLayer& L, int B, hipStream_t st) {
+// Time-tile height: 64 rows (NJ = 2) when that still gives every CU a block, else 32 rows -- at B = 1 a 10 s clip is
+// only 38 tiles of 32 frames, and one tile's MFMA work on one CU is the latency floor of a launch.
+static int pick_nj(int B, int T) { return (long)B * ((T + 63) / 64) >= 192 ? 2 : 1; }
+
+template <typename OpT, int CIN, int MI, int NW, int EPI, int NJ>
+void launch_conv_nj(rvcmi_front* h, const char* name, FrConvArgs a, const ConvLayer& L, int B, hipStream_t st) {
     a.w = L.w_pack.p;
     a.ct_stride = L.ct_stride;
     a.ntaps = L.ntaps[0];
     a.bias = L.bias.as<float>();
     a.cout = L.cout;
-    constexpr int TT = FR_NJ * 32;
+    constexpr int TT = NJ * 32;
     const int rows = TT + a.ntaps - 1 + 2;
-    const size_t smem = std::max<size_t>((size_t)rows * Tile<CIN>::STRIDE, 2 * NW * FR_NJ * 32 * sizeof(float));
+    const size_t smem = std::max<size_t>((size_t)rows * Tile<CIN>::STRIDE, 2 * NW * NJ * 32 * sizeof(float));
     const int ctiles = (L.cout + 31) / 32;
     const int gy = (ctiles + NW * MI - 1) / (NW * MI);
-    auto kern = k_fr_conv<OpT, CIN, MI, FR_NJ, NW, EPI>;
+    auto kern = k_fr_conv<OpT, CIN, MI, NJ, NW, EPI>;
     static bool attr_done = false;  // one instantiation = one static
     if (!attr_done) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -83,9 +85,14 @@ void launch_conv(rvcmi_front* h, const char* name, FrConvArgs a, const ConvLayer
     });
     HIP_CHECK(hipGetLastError());
 }
+template <typename OpT, int CIN, int MI, int NW, int EPI>
+void launch_conv(rvcmi_front* h, const char* name, const FrConvArgs& a, const ConvLayer& L, int B, hipStream_t st) {
+    if (pick_nj(B, a.T) == 1) launch_conv_nj<OpT, CIN, MI, NW, EPI, 1>(h, name, a, L, B, st);
+    else launch_conv_nj<OpT, CIN, MI, NW, EPI, 2>(h, name, a, L, B, st);
+}
 
-template <typename OpT, bool LAST>
-void launch_wn(rvcmi_front* h, FrWnArgs a, const ConvLayer& Lin, const ConvLayer& Lrs, int B, hipStream_t st) {
+template <typename OpT, bool LAST, int NJ>
+void launch_wn_nj(rvcmi_front* h, FrWnArgs a, const ConvLayer& Lin, const ConvLayer& Lrs, int B, hipStream_t st) {
     constexpr int H = 192;
     a.w_in = Lin.w_pack.p;
     a.ct_in = Lin.ct_stride;
@@ -95,19 +102,35 @@ void launch_wn(rvcmi_front* h, FrWnArgs a, const ConvLayer& Lin, const ConvLayer
     a.w_rs = Lrs.w_pack.p;
     a.ct_rs = Lrs.ct_stride;
     a.b_rs = Lrs.bias.as<float>();
-    constexpr int TT = FR_NJ * 32;
-    const size_t smem = (size_t)(TT + a.ntaps - 1 + 2 + TT + 2) * Tile<H>::STRIDE;
-    auto kern = k_fr_wn<OpT, H, FR_NJ, LAST>;
+    constexpr int TT = NJ * 32;
+    const size_t smem = (size_t)(TT + a.ntaps - 1 + 2 + TT + 2) * Tile<H>::STRIDE + 2 * H * sizeof(float);
+    auto kern = k_fr_wn<OpT, H, NJ, LAST>;
     static bool attr_done = false;
     if (!attr_done) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     const double flops = (Lin.flops_per_pos + Lrs.flops_per_pos) * (double)a.T * B;
+    static unsigned long long* stamps = nullptr;  // dev only
+    if (getenv("RVCMI_FR_STAMPS") && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 64 * 8));
+    a.stamps = getenv("RVCMI_FR_STAMPS") ? stamps : nullptr;
     h->prof.launch(LAST ? "flow_wn_last" : "flow_wn", flops, 0.0, st, [&] {
         hipLaunchKernelGGL(kern, dim3((a.T + TT - 1) / TT, B), dim3(64 * (H / 32)), smem, st, a);
     });
     HIP_CHECK(hipGetLastError());
+    if (a.stamps) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        unsigned long long t[14];
+        HIP_CHECK(hipMemcpy(t, stamps, sizeof(t), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[fr_wn%s] wall(10ns)/cycles:", LAST ? "_last" : "");
+        for (int i = 1; i < 7; ++i) fprintf(stderr, "  p%d %llu/%llu", i, t[2 * i] - t[2 * i - 2], t[2 * i + 1] - t[2 * i - 1]);
+        fprintf(stderr, "\n");
+    }
+}
+template <typename OpT, bool LAST>
+void launch_wn(rvcmi_front* h, const FrWnArgs& a, const ConvLayer& Lin, const ConvLayer& Lrs, int B, hipStream_t st) {
+    if (pick_nj(B, a.T) == 1) launch_wn_nj<OpT, LAST, 1>(h, a, Lin, Lrs, B, st);
+    else launch_wn_nj<OpT, LAST, 2>(h, a, Lin, Lrs, B, st);
 }
 
 void tap_copy(TapReq* tr, const char* what, const float* dev, int B, int T, int C, hipStream_t st) {
@@ -145,20 +168,31 @@ void front_forward_t(rvcmi_front* h, int B, int T, const float* phone, const lon
         {
             FrConvArgs a = {};
             a.in = X; a.in_bstride = (long)T * H; a.T = T; a.len = lengths;
-            a.out_op = h->QK.p; a.out_op_bstride = (long)T * 2 * H;
-            a.vt = h->VT.p; a.vt_bstride = (long)H * Tp; a.Tp = Tp; a.qdiv = sqrtf((float)(H / c.n_heads)); a.H = H;
+            a.out_op = h->QK.p; a.out_op_bstride = (long)T * H;
+            a.vt = h->VT.p; a.kf = h->KF.p; a.Tp = Tp; a.qdiv = sqrtf((float)(H / c.n_heads)); a.H = H;
             launch_conv<OpT, H, 1, 6, FR_QKV>(h, "enc_qkv", a, L.qkv, B, st);
         }
         {
             FrAttnArgs a = {};
-            a.qk = h->QK.p; a.vt = h->VT.p; a.out = h->A.p; a.relk = L.relk.p; a.relv = L.relv.as<float>(); a.len = lengths;
+            a.q = h->QK.p; a.kf = h->KF.p; a.vf = h->VT.p; a.out = h->A.p; a.relk = L.relk.p; a.relv = L.relv.as<float>(); a.len = lengths;
             a.T = T; a.Tp = Tp; a.H = H; a.ws = c.window_size;
-            a.qk_bstride = (long)T * 2 * H; a.vt_bstride = (long)H * Tp; a.out_bstride = (long)T * H;
             const double flops = 4.0 * (double)T * T * H * B;
+            static unsigned long long* stamps = nullptr;  // dev only
+            if (getenv("RVCMI_FR_STAMPS") && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 64 * 8));
+            a.stamps = getenv("RVCMI_FR_STAMPS") ? stamps : nullptr;
             h->prof.launch("enc_attn", flops, 0.0, st, [&] {
-                hipLaunchKernelGGL((k_fr_attn<OpT, 96>), dim3((T + 31) / 32, c.n_heads, B), dim3(256), 0, st, a);
+                if (c.window_size <= 10) hipLaunchKernelGGL((k_fr_attn<OpT, 96, 21>), dim3((T + 31) / 32, c.n_heads, B), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((k_fr_attn<OpT, 96, 31>), dim3((T + 31) / 32, c.n_heads, B), dim3(256), 0, st, a);
             });
             HIP_CHECK(hipGetLastError());
+            if (a.stamps) {
+                HIP_CHECK(hipStreamSynchronize(st));
+                unsigned long long t[12];
+                HIP_CHECK(hipMemcpy(t, stamps, sizeof(t), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[fr_attn] wall(10ns)/cycles:");
+                for (int k = 1; k < 5; ++k) fprintf(stderr, "  p%d %llu/%llu", k, t[2 * k] - t[2 * k - 2], t[2 * k + 1] - t[2 * k - 1]);
+                fprintf(stderr, "\n");
+            }
         }
         {
             FrConvArgs a = {};
@@ -418,7 +452,8 @@ rvcmi_front* front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* wei
         ws += bytes;
     };
     A(h->X, BT * H * 4);
-    A(h->QK, BT * 2 * H * 2);
+    A(h->QK, BT * H * 2);
+    A(h->KF, (size_t)max_B * H * h->Tp * 2);
     A(h->VT, (size_t)max_B * H * h->Tp * 2);
     A(h->A, BT * H * 2);
     A(h->F, BT * FC * 2);
@@ -428,6 +463,7 @@ rvcmi_front* front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* wei
     A(h->SK, BT * H * 4);
     A(h->GC, (size_t)max_B * gcn * c.flow_n_flows * 4 + 16);
     HIP_CHECK(hipMemset(h->VT.p, 0, h->VT.bytes));  // key padding columns must stay finite
+    HIP_CHECK(hipMemset(h->KF.p, 0, h->KF.bytes));
     h->ws_bytes = ws;
     return h.release();
 }

@@ -54,14 +54,16 @@ struct FrConvArgs {
     const long long* pitch;   // FR_EMB [B][T]
     const float* emb_pitch;   // [256][H]
     float scale;              // sqrt(H)
-    void* vt;            // FR_QKV: OpT [B][H][Tp]
-    long vt_bstride;
+    void* vt;            // FR_QKV: v tiles, OpT [B][heads][Tp/32][dk/32][2][64][8] (A-fragment order of P.V)
+    void* kf;            // FR_QKV: k tiles, OpT [B][heads][Tp/32][dk/16][64][8] (A-fragment order of K.Q^T)
     int Tp;
     float qdiv;          // sqrt(dk)
     int H;               // hidden channels (FR_QKV split point, FR_PROJ_ZP pairing)
     const float* noise;  // FR_PROJ_ZP: [B][C][T] channel-first (what randn_like(m_p) is)
     int phys_base;       // FR_COUPLE: first physical channel of the x1 half (flip folded)
 };
+
+constexpr int FR_NB = 4;  // weight ring depth of the front kernels (k-groups)
 
 __device__ __forceinline__ bool fr_valid(const FrConvArgs& a, int b, int row) {
     return a.len == nullptr || (long long)(row + a.t_off) < a.len[b];
@@ -75,27 +77,48 @@ __device__ __forceinline__ void fr_stage(char* smem, const void* in, int in_op, 
     constexpr int STRIDE = Tile<CIN>::STRIDE;
     constexpr int C8 = CIN / 8;
     const int hi = min(T, lenrow);
-    for (int idx = threadIdx.x; idx < rows * C8; idx += NT) {
-        const int r = idx / C8;
-        const int c8 = idx - r * C8;
-        const int gr = g0 + r;
-        const bool ok = gr >= 0 && gr < hi;
-        const int grc = min(max(gr, 0), T - 1);  // clamped address: unconditional loads
-        frag v;
-        if (in_op) {
-            v = *(const frag*)((const OpT*)in + boff + (size_t)grc * CIN + c8 * 8);
-        } else {
-            const float4* p = (const float4*)((const float*)in + boff + (size_t)grc * CIN + c8 * 8);
-            const float4 lo = p[0], hi4 = p[1];
-            const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    constexpr int SB = 8;  // independent chunk loads in flight per thread (a serial load->convert->store loop is latency-bound)
+    const int total = rows * C8;
+    for (int base = threadIdx.x; base < total; base += SB * NT) {
+        frag v[SB];
+        float4 lo[SB], hi4[SB];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(f[e]);
+        for (int u = 0; u < SB; ++u) {
+            const int idx = min(base + u * NT, total - 1);
+            const int r = idx / C8;
+            const int c8 = idx - r * C8;
+            const int grc = min(max(g0 + r, 0), T - 1);  // clamped address: unconditional loads
+            if (in_op) {
+                v[u] = *(const frag*)((const OpT*)in + boff + (size_t)grc * CIN + c8 * 8);
+            } else {
+                const float4* p = (const float4*)((const float*)in + boff + (size_t)grc * CIN + c8 * 8);
+                lo[u] = p[0];
+                hi4[u] = p[1];
+            }
         }
-        if (!ok) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (OpT)0.f;
+        for (int u = 0; u < SB; ++u) {
+            const int idx = base + u * NT;
+            if (idx < total) {
+                const int r = idx / C8;
+                const int c8 = idx - r * C8;
+                const int gr = g0 + r;
+                const bool ok = gr >= 0 && gr < hi;
+                frag o;
+                if (in_op) {
+                    o = v[u];
+                } else {
+                    const float f[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi4[u].x, hi4[u].y, hi4[u].z, hi4[u].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = to_op<OpT>(f[e]);
+                }
+                if (!ok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (OpT)0.f;
+                }
+                *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = o;
+            }
         }
-        *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
     }
 }
 
@@ -113,10 +136,15 @@ static __global__ void __launch_bounds__(64 * NW) k_fr_conv(FrConvArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rows = TT + a.ntaps - 1 + 2;  // + slack for the K loop's one-step-ahead reads
     const int lenrow = (a.premask && a.len) ? (int)min((long long)a.T, a.len[b] - a.t_off) : a.T;
+    // these launches are small (tens of blocks at B = 1), so a wave's speed is set by how many weight bytes it keeps in
+    // flight: a 4-deep ring (12 k-steps ahead), requested BEFORE the activation tile is staged
+    const int ct0 = ((int)blockIdx.y * NW + wave) * MI;
+    const OpT* wlane = (const OpT*)a.w + (size_t)ct0 * a.ct_stride + lane * 8;
+    typename Op<OpT>::frag Aw[FR_NB][KGROUP][MI];
+    conv_prefetch<OpT, CIN, MI, KGROUP, FR_NB>(Aw, wlane, a.ct_stride, a.ntaps);
     fr_stage<OpT, CIN, NT>(smem, a.in, a.in_op, (long)b * a.in_bstride, a.T, q0 - a.pad, rows, lenrow);
     __syncthreads();
 
-    const int ct0 = ((int)blockIdx.y * NW + wave) * MI;
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -125,50 +153,62 @@ static __global__ void __launch_bounds__(64 * NW) k_fr_conv(FrConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
     const char* lds_lane = smem + (size_t)(lane & 31) * STRIDE + (lane >> 5) * 16;
-    const OpT* wlane = (const OpT*)a.w + (size_t)ct0 * a.ct_stride + lane * 8;
-    conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.ct_stride, a.ntaps, 0, 1);
+    conv_run<OpT, CIN, MI, NJ, KGROUP, FR_NB>(acc, Aw, lds_lane, wlane, a.ct_stride, a.ntaps, 0, 1);
 
+    // ---- epilogue.  Every load is issued up front with clamped indices (hipcc turns a conditional load into an
+    // exec-masked branch with its own wait; measured here: 15k cycles for a 24-load epilogue) ----
     const int hl = lane >> 5;
+    const long long lenb = a.len ? a.len[b] : (long long)a.T + a.t_off;
+    int tt[NJ], tcl[NJ];
+    float mk[NJ];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        tt[jt] = q0 + jt * 32 + (lane & 31);
+        tcl[jt] = min(tt[jt], a.T - 1);
+        mk[jt] = (long long)(tcl[jt] + a.t_off) < lenb ? 1.f : 0.f;
+    }
     if constexpr (EPI == FR_RES_LN) {
-        // the block holds all cout (= NW*MI*32) channels of its rows: LayerNorm statistics go through LDS
+        // the block holds all cout (= NW*32) channels of its rows: LayerNorm statistics go through LDS
         static_assert(MI == 1, "LN epilogue: one tile per wave");
+        const int cb = ct0 * 32 + 4 * hl;
+        f32x4 bv[4], ga[4], be[4], rv[NJ][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bv[g] = *(const f32x4*)(a.bias + cb + 8 * g);
+            ga[g] = *(const f32x4*)(a.gamma + cb + 8 * g);
+            be[g] = *(const f32x4*)(a.beta + cb + 8 * g);
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+                rv[jt][g] = *(const f32x4*)(a.res + (size_t)b * a.out_bstride + (size_t)tcl[jt] * a.out_C + cb + 8 * g);
+        }
         __syncthreads();  // staging tile is dead
         float* red = (float*)smem;  // [2][NW][TT]
         float v[NJ][16];
-        const int cb = ct0 * 32 + 4 * hl;
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
-            const int t = q0 + jt * 32 + (lane & 31);
-            const int tc = min(t, a.T - 1);
-            const float mk = (a.postmask && !fr_valid(a, b, tc)) ? 0.f : 1.f;
-            float s = 0.f;
+            const float pm = a.postmask ? mk[jt] : 1.f;
+            float sum = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = cb + 8 * g;
-                const f32x4 bv = *(const f32x4*)(a.bias + co);
-                const f32x4 rv = *(const f32x4*)(a.res + (size_t)b * a.out_bstride + (size_t)tc * a.out_C + co);
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float y = (acc[0][jt][4 * g + e] + bv[e]) * mk;
-                    v[jt][4 * g + e] = rv[e] + y;
-                    s += v[jt][4 * g + e];
+                    v[jt][4 * g + e] = rv[jt][g][e] + (acc[0][jt][4 * g + e] + bv[g][e]) * pm;
+                    sum += v[jt][4 * g + e];
                 }
-            }
-            s += __shfl_xor(s, 32, 64);
-            if (hl == 0) red[(wave * NJ + jt) * 32 + (lane & 31)] = s;
+            sum += __shfl_xor(sum, 32, 64);
+            if (hl == 0) red[(wave * NJ + jt) * 32 + (lane & 31)] = sum;
         }
         __syncthreads();
-        float mean[NJ];
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) tot += red[(w * NJ + jt) * 32 + (lane & 31)];
-            mean[jt] = tot / (float)a.cout;
+            const float mean = tot / (float)a.cout;
             float s2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                v[jt][e] -= mean[jt];
+                v[jt][e] -= mean;
                 s2 += v[jt][e] * v[jt][e];
             }
             s2 += __shfl_xor(s2, 32, 64);
@@ -177,89 +217,133 @@ static __global__ void __launch_bounds__(64 * NW) k_fr_conv(FrConvArgs a) {
         __syncthreads();
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
-            const int t = q0 + jt * 32 + (lane & 31);
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) tot += red[NW * NJ * 32 + (w * NJ + jt) * 32 + (lane & 31)];
             const float rstd = 1.f / sqrtf(tot / (float)a.cout + 1e-5f);
-            if (t < a.T) {
+            if (tt[jt] < a.T) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co = cb + 8 * g;
-                    const f32x4 ga = *(const f32x4*)(a.gamma + co), be = *(const f32x4*)(a.beta + co);
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = v[jt][4 * g + e] * rstd * ga[e] + be[e];
-                    *(f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)t * a.out_C + co) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = v[jt][4 * g + e] * rstd * ga[g][e] + be[g][e];
+                    *(f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)tt[jt] * a.out_C + cb + 8 * g) = o;
                 }
             }
         }
     } else if constexpr (EPI == FR_PROJ_ZP) {
         static_assert(MI == 2, "paired (m, logs) tiles");
-        const int pair = ct0 / 2;
+        const int pc = (ct0 / 2) * 32 + 4 * hl;  // first channel of this lane's groups
+        f32x4 bm[4], bl[4];
+        float nz[NJ][16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bm[g] = *(const f32x4*)(a.bias + pc + 8 * g);
+            bl[g] = *(const f32x4*)(a.bias + a.H + pc + 8 * g);
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nz[jt][4 * g + e] = a.noise[((size_t)b * a.H + pc + 8 * g + e) * a.T + tcl[jt]];
+        }
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
-            const int t = q0 + jt * 32 + (lane & 31);
-            if (t >= a.T) continue;
-            const float mk = fr_valid(a, b, t) ? 1.f : 0.f;
+            if (tt[jt] >= a.T) continue;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = pair * 32 + 8 * g + 4 * hl;
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float m = (acc[0][jt][4 * g + e] + a.bias[c + e]) * mk;
-                    const float lg = (acc[1][jt][4 * g + e] + a.bias[a.H + c + e]) * mk;
-                    const float nz = a.noise[((size_t)b * a.H + c + e) * a.T + t];
-                    o[e] = (m + expf(lg) * nz * 0.66666f) * mk;
+                    const float m = (acc[0][jt][4 * g + e] + bm[g][e]) * mk[jt];
+                    const float lg = (acc[1][jt][4 * g + e] + bl[g][e]) * mk[jt];
+                    o[e] = (m + expf(lg) * nz[jt][4 * g + e] * 0.66666f) * mk[jt];
                 }
-                *(f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)t * a.out_C + c) = o;
+                *(f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)tt[jt] * a.out_C + pc + 8 * g) = o;
             }
         }
     } else {
+        f32x4 bv[MI][4];
+        int cog[MI][4];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                cog[mi][g] = (ct0 + mi) * 32 + 8 * g + 4 * hl;
+                bv[mi][g] = *(const f32x4*)(a.bias + min(cog[mi][g], a.cout - 4));
+            }
+        f32x4 ex[MI][NJ][4];  // epilogue operand fetched up front: pitch embedding row / the x1 half of the flow stream
+        if constexpr (EPI == FR_EMB || EPI == FR_COUPLE) {
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                long long pi = 0;
+                if constexpr (EPI == FR_EMB) pi = a.pitch ? a.pitch[(size_t)b * a.T + tcl[jt]] : 0;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = min(cog[mi][g], a.cout - 4);
+                        if constexpr (EPI == FR_EMB)
+                            ex[mi][jt][g] = a.pitch ? *(const f32x4*)(a.emb_pitch + (size_t)pi * a.cout + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        else
+                            ex[mi][jt][g] = *(const f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)tcl[jt] * a.out_C + a.phys_base + co);
+                    }
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
-                const int t = q0 + jt * 32 + (lane & 31);
+                const int t = tt[jt];
                 if (t >= a.T) continue;
-                const float mk = fr_valid(a, b, t) ? 1.f : 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co = (ct0 + mi) * 32 + 8 * g + 4 * hl;
+                    const int co = cog[mi][g];
                     if (co >= a.cout) continue;
                     f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
-                    v += *(const f32x4*)(a.bias + co);
+                    v += bv[mi][g];
                     if constexpr (EPI == FR_EMB) {
-                        const long long pi = a.pitch ? a.pitch[(size_t)b * a.T + t] : 0;
-                        if (a.pitch) v += *(const f32x4*)(a.emb_pitch + (size_t)pi * a.cout + co);
+                        v += ex[mi][jt][g];
                         f32x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = lrelu(v[e] * a.scale, 0.1f) * mk;
+                        for (int e = 0; e < 4; ++e) o[e] = lrelu(v[e] * a.scale, 0.1f) * mk[jt];
                         *(f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)t * a.out_C + co) = o;
                     } else if constexpr (EPI == FR_QKV) {
+                        // q -> [T][H] (pre-scaled); k and v -> per (head, 32-key tile) blocks in MFMA FRAGMENT order, so
+                        // that the attention kernel's operand loads are contiguous 1 KiB per instruction
                         using o4 = __attribute__((ext_vector_type(4))) OpT;
-                        if (co < 2 * a.H) {
+                        constexpr int DKc = 96, KSc = DKc / 16, DTc = DKc / 32;
+                        const int nh = a.H / DKc, ntl = a.Tp / 32, tile = t >> 5, kk = t & 31;
+                        if (co < a.H) {
                             o4 o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(co < a.H ? v[e] / a.qdiv : v[e]);
-                            *(o4*)((OpT*)a.out_op + (size_t)b * a.out_op_bstride + (size_t)t * (2 * a.H) + co) = o;
-                        } else {
-                            OpT* vt = (OpT*)a.vt + (size_t)b * a.vt_bstride + (size_t)(co - 2 * a.H) * a.Tp + t;
+                            for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(v[e] / a.qdiv);
+                            *(o4*)((OpT*)a.out_op + (size_t)b * a.out_op_bstride + (size_t)t * a.H + co) = o;
+                        } else if (co < 2 * a.H) {
+                            const int c = co - a.H, head = c / DKc, cc = c - head * DKc;
+                            o4 o;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) vt[(size_t)e * a.Tp] = to_op<OpT>(v[e]);
+                            for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(v[e]);
+                            const size_t off = ((((size_t)b * nh + head) * ntl + tile) * KSc + cc / 16) * 512 +
+                                               ((((cc & 15) >> 3) * 32 + kk) * 8) + (cc & 7);
+                            *(o4*)((OpT*)a.kf + off) = o;
+                        } else {
+                            const int c = co - 2 * a.H, head = c / DKc, d = c - head * DKc;
+                            const int s2 = kk >> 4, r = kk & 15, hv = (r >> 2) & 1, ev = (r & 3) + 4 * (r >> 3);
+                            OpT* vp = (OpT*)a.vt + (((((size_t)b * nh + head) * ntl + tile) * DTc + d / 32) * 2 + s2) * 512 +
+                                      (size_t)(hv * 32 + (d & 31)) * 8 + ev;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vp[e * 8] = to_op<OpT>(v[e]);
                         }
                     } else if constexpr (EPI == FR_RELU_OP) {
                         using o4 = __attribute__((ext_vector_type(4))) OpT;
                         o4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(fmaxf(v[e], 0.f) * mk);
+                        for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(fmaxf(v[e], 0.f) * mk[jt]);
                         *(o4*)((OpT*)a.out_op + (size_t)b * a.out_op_bstride + (size_t)t * a.cout + co) = o;
                     } else if constexpr (EPI == FR_F32_MASK) {
-                        *(f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)t * a.out_C + co) = v * mk;
+                        *(f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)t * a.out_C + co) = v * mk[jt];
                     } else if constexpr (EPI == FR_COUPLE) {
-                        f32x4* xp = (f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)t * a.out_C + a.phys_base + co);
-                        *xp = (*xp - v * mk) * mk;
+                        *(f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)t * a.out_C + a.phys_base + co) =
+                            (ex[mi][jt][g] - v * mk[jt]) * mk[jt];
                     }
                 }
             }
@@ -287,7 +371,12 @@ struct FrWnArgs {
     const void* w_rs;   // packed [res tile 0, skip tile 0, ...] (last layer: [skip tile 0, skip tile 1, ...])
     long ct_rs;
     const float* b_rs;  // original order
+    unsigned long long* stamps;  // dev only (RVCMI_FR_STAMPS): phase time stamps of block (1, 0)
 };
+
+// tanh / sigmoid through the hardware exp: the result is rounded to a 16-bit operand right after
+__device__ __forceinline__ float fast_sigmoid(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 2.f * fast_sigmoid(2.f * v) - 1.f; }
 
 template <typename OpT, int H, int NJ, bool LAST>
 static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {
@@ -303,13 +392,44 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hl = lane >> 5;
     const int xrows = TT + a.ntaps - 1 + 2;
     char* ACT = smem + (size_t)xrows * STRIDE;
+    float* bg = (float*)(ACT + (size_t)(TT + 2) * STRIDE);  // [2H] in_layer bias + cond slice of this utterance
     const long boff = (long)b * a.bstride;
+    const bool st = a.stamps && blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0;
+#define FR_STAMP(i) do { if (st) { a.stamps[2 * (i)] = wall_clock64(); a.stamps[2 * (i) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
+    FR_STAMP(0);
+    const OpT* wlane1 = (const OpT*)a.w_in + (size_t)(2 * wave) * a.ct_in + lane * 8;
+    typename Op<OpT>::frag Aw[FR_NB][KGROUP][2];
+    conv_prefetch<OpT, H, 2, KGROUP, FR_NB>(Aw, wlane1, a.ct_in, a.ntaps);
+    // epilogue operands requested now, used ~10 us later: x (fp32 residual), running skip sum, res_skip bias
+    constexpr int MI2 = LAST ? 1 : 2;
+    const long long lenb = a.len ? a.len[b] : (long long)a.T + a.t_off;
+    const int cb = wave * 32 + 4 * hl;
+    f32x4 xv[NJ][4], sk[NJ][4], br[MI2][4];
+    int tt[NJ];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        tt[jt] = q0 + jt * 32 + (lane & 31);
+        const size_t o = boff + (size_t)min(tt[jt], a.T - 1) * H + cb;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            xv[jt][g] = *(const f32x4*)(a.x + o + 8 * g);
+            sk[jt][g] = *(const f32x4*)(a.skip + o + 8 * g);  // garbage on the first layer, multiplied by 0 below
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) br[mi][g] = *(const f32x4*)(a.b_rs + mi * H + cb + 8 * g);
+    for (int i = threadIdx.x; i < 2 * H; i += NT) bg[i] = a.b_in[i] + (a.gc ? a.gc[(size_t)b * a.gc_bstride + i] : 0.f);
     fr_stage<OpT, H, NT>(smem, a.x, 0, boff, a.T, q0 - a.pad, xrows, a.T);
     // slack rows of the ACT tile (read one k-step ahead by the second K loop) must hold finite values
     for (int i = threadIdx.x; i < 2 * STRIDE / 4; i += NT) ((unsigned*)(ACT + (size_t)TT * STRIDE))[i] = 0u;
     __syncthreads();
+    FR_STAMP(1);
 
     const char* lds_lane = smem + (size_t)(lane & 31) * STRIDE + hl * 16;
+    const OpT* wlane = (const OpT*)a.w_rs + (size_t)(MI2 * wave) * a.ct_rs + lane * 8;
+    typename Op<OpT>::frag Aw2[FR_NB][KGROUP][MI2];
     {
         f32x16 acc[2][NJ];
 #pragma unroll
@@ -318,31 +438,26 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {
             for (int jt = 0; jt < NJ; ++jt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
-        const OpT* wlane = (const OpT*)a.w_in + (size_t)(2 * wave) * a.ct_in + lane * 8;
-        conv_core<OpT, H, 2, NJ>(acc, lds_lane, wlane, a.ct_in, a.ntaps, 0, 1);
-        const float* gc = a.gc ? a.gc + (size_t)b * a.gc_bstride : nullptr;
+        conv_run<OpT, H, 2, NJ, KGROUP, FR_NB>(acc, Aw, lds_lane, wlane1, a.ct_in, a.ntaps, 0, 1);
+        FR_STAMP(2);
+        conv_prefetch<OpT, H, MI2, KGROUP, FR_NB>(Aw2, wlane, a.ct_rs, 1);
 #pragma unroll
-        for (int jt = 0; jt < NJ; ++jt)
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bt = *(const f32x4*)(bg + cb + 8 * g), bs = *(const f32x4*)(bg + H + cb + 8 * g);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = wave * 32 + 8 * g + 4 * hl;
+            for (int jt = 0; jt < NJ; ++jt) {
                 o4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float ta = acc[0][jt][4 * g + e] + a.b_in[c + e];
-                    float sa = acc[1][jt][4 * g + e] + a.b_in[H + c + e];
-                    if (gc) {
-                        ta += gc[c + e];
-                        sa += gc[H + c + e];
-                    }
-                    o[e] = to_op<OpT>(tanhf(ta) * (1.f / (1.f + expf(-sa))));
-                }
-                *(o4*)(ACT + (size_t)(jt * 32 + (lane & 31)) * STRIDE + c * 2) = o;
+                for (int e = 0; e < 4; ++e)
+                    o[e] = to_op<OpT>(fast_tanh(acc[0][jt][4 * g + e] + bt[e]) * fast_sigmoid(acc[1][jt][4 * g + e] + bs[e]));
+                *(o4*)(ACT + (size_t)(jt * 32 + (lane & 31)) * STRIDE + (cb + 8 * g) * 2) = o;
             }
+        }
     }
+    FR_STAMP(3);
     __syncthreads();
+    FR_STAMP(4);
 
-    constexpr int MI2 = LAST ? 1 : 2;
     f32x16 acc[MI2][NJ];
 #pragma unroll
     for (int mi = 0; mi < MI2; ++mi)
@@ -351,28 +466,27 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
     const char* act_lane = ACT + (size_t)(lane & 31) * STRIDE + hl * 16;
-    const OpT* wlane = (const OpT*)a.w_rs + (size_t)(MI2 * wave) * a.ct_rs + lane * 8;
-    conv_core<OpT, H, MI2, NJ>(acc, act_lane, wlane, a.ct_rs, 1, 0, 1);
+    conv_run<OpT, H, MI2, NJ, KGROUP, FR_NB>(acc, Aw2, act_lane, wlane, a.ct_rs, 1, 0, 1);
+    FR_STAMP(5);
 #pragma unroll
     for (int jt = 0; jt < NJ; ++jt) {
-        const int t = q0 + jt * 32 + (lane & 31);
-        if (t >= a.T) continue;
-        const float mk = (a.len == nullptr || (long long)(t + a.t_off) < a.len[b]) ? 1.f : 0.f;
+        if (tt[jt] >= a.T) continue;
+        const float mk = (long long)(tt[jt] + a.t_off) < lenb ? 1.f : 0.f;
+        const size_t o = boff + (size_t)tt[jt] * H + cb;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int c = wave * 32 + 8 * g + 4 * hl;
-            const size_t o = boff + (size_t)t * H + c;
             if constexpr (!LAST) {
                 f32x4 r = {acc[0][jt][4 * g + 0], acc[0][jt][4 * g + 1], acc[0][jt][4 * g + 2], acc[0][jt][4 * g + 3]};
-                r += *(const f32x4*)(a.b_rs + c);
-                *(f32x4*)(a.x_out + o) = (*(const f32x4*)(a.x + o) + r) * mk;
+                *(f32x4*)(a.x_out + o + 8 * g) = (xv[jt][g] + (r + br[0][g])) * mk;
             }
             f32x4 s = {acc[MI2 - 1][jt][4 * g + 0], acc[MI2 - 1][jt][4 * g + 1], acc[MI2 - 1][jt][4 * g + 2], acc[MI2 - 1][jt][4 * g + 3]};
-            s += *(const f32x4*)(a.b_rs + (LAST ? 0 : H) + c);
-            if (!a.first) s += *(const f32x4*)(a.skip + o);
-            *(f32x4*)(a.skip + o) = s;
+            s += br[MI2 - 1][g];
+            if (!a.first) s += sk[jt][g];
+            *(f32x4*)(a.skip + o + 8 * g) = s;
         }
     }
+    FR_STAMP(6);
+#undef FR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -388,43 +502,53 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {
 //   O^T       += V^T (A: dk x 32 keys, read with the same slot order from the transposed V) . P
 //   rel. values: the 2ws+1 band of p is recomputed in fp32 at the end (21 dots per query) and applied to E_v.
 struct FrAttnArgs {
-    const void* qk;     // OpT [B][T][2H]: q (pre-scaled) | k
-    const void* vt;     // OpT [B][H][Tp]
+    const void* q;      // OpT [B][T][H], pre-scaled by 1/sqrt(dk)
+    const void* kf;     // OpT [B][heads][Tp/32][dk/16][64][8]
+    const void* vf;     // OpT [B][heads][Tp/32][dk/32][2][64][8]
     void* out;          // OpT [B][T][H]
     const void* relk;   // packed E_k: [dk/16][64][8] OpT (A-fragment order, rows >= 2ws+1 zero)
     const float* relv;  // [2ws+1][dk] fp32
     const long long* len;
     int T, Tp, H, ws;
-    long qk_bstride, vt_bstride, out_bstride;
+    unsigned long long* stamps;  // dev only
 };
 
-template <typename OpT, int DK>
+template <typename OpT, int DK, int NBAND>  // NBAND >= 2*ws + 1 (21 for the shipped window of 10)
 static __global__ void __launch_bounds__(256) k_fr_attn(FrAttnArgs a) {
     using frag = typename Op<OpT>::frag;
+    using o4 = __attribute__((ext_vector_type(4))) OpT;
     constexpr int KS = DK / 16;   // k-steps of the score product
     constexpr int DT = DK / 32;   // 32-row tiles of O^T
     constexpr int OS = DK + 1;    // LDS row stride of the merge buffers
+    constexpr int DG = DK / 8;    // channels per thread in the output phase (256 threads = 32 queries x 8 groups)
     static_assert(DK % 32 == 0, "head dim must be a multiple of 32");
     __shared__ float Rl[32 * 33];
     __shared__ float Ml[4 * 32], Ll[4 * 32];
     __shared__ float Ol[4 * 32 * OS];
-    __shared__ float Pb[32 * 32];
+    __shared__ float Sb[32 * 32 + 32];  // masked scores of the relative band, Sb[q][j - q + ws] (+ 32 dump slots)
     __shared__ float Mf[32], Lf[32];
+    __shared__ float Wl[4 * 32];       // merge weights exp(m_w - M) / L
+    __shared__ __attribute__((aligned(16))) float Ev[32 * DK];  // relative value embeddings (2ws+1 <= 31 rows, rest zero)
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int q0 = qt * 32;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hl = lane >> 5, ql = lane & 31;
     const int T = a.T;
     const int len = a.len ? (int)min((long long)T, a.len[b]) : T;
-    const OpT* QK = (const OpT*)a.qk + (size_t)b * a.qk_bstride;
-    const OpT* VT = (const OpT*)a.vt + (size_t)b * a.vt_bstride + (size_t)h * DK * a.Tp;
-    const int H2 = 2 * a.H;
+    const int nh = a.H / DK, ntl = a.Tp / 32;
+    const OpT* KF = (const OpT*)a.kf + ((size_t)b * nh + h) * ntl * (KS * 512) + lane * 8;
+    const OpT* VF = (const OpT*)a.vf + ((size_t)b * nh + h) * ntl * (DT * 2 * 512) + lane * 8;
+    const bool st = a.stamps && blockIdx.x == 5 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+#define FR_STAMP(i) do { if (st) { a.stamps[2 * (i)] = wall_clock64(); a.stamps[2 * (i) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
+    FR_STAMP(0);
 
     frag Bq[KS];
     {
-        const OpT* qp = QK + (size_t)min(q0 + ql, T - 1) * H2 + h * DK + 8 * hl;
+        const OpT* qp = (const OpT*)a.q + ((size_t)b * T + min(q0 + ql, T - 1)) * a.H + h * DK + 8 * hl;
 #pragma unroll
         for (int s = 0; s < KS; ++s) Bq[s] = *(const frag*)(qp + 16 * s);
     }
+    for (int i = threadIdx.x; i < 32 * DK; i += 256) Ev[i] = i < (2 * a.ws + 1) * DK ? a.relv[min(i, (2 * a.ws + 1) * DK - 1)] : 0.f;
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) Sb[i] = -INFINITY;
     if (wave == 0) {  // R[q][r] = q . E_k[r]
         f32x16 r = {0};
 #pragma unroll
@@ -433,6 +557,7 @@ static __global__ void __launch_bounds__(256) k_fr_attn(FrAttnArgs a) {
         for (int i = 0; i < 16; ++i) Rl[ql * 33 + (i & 3) + 8 * (i >> 2) + 4 * hl] = r[i];
     }
     __syncthreads();
+    FR_STAMP(1);
 
     const int q = q0 + ql;
     const bool qok = q < len;
@@ -443,59 +568,102 @@ static __global__ void __launch_bounds__(256) k_fr_attn(FrAttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) O[d][i] = 0.f;
     const int nkt = (T + 31) / 32;
-    for (int kt = wave; kt < nkt; kt += 4) {
+    // K / V fragments of the NEXT key tile are requested before the current tile is multiplied (register double buffer,
+    // clamped tile index => unconditional loads): at B = 1 only ~80 blocks exist, so per-wave latency is what counts.
+    struct KV {
+        frag k[KS];
+        frag v[DT][2];
+    };
+    auto load_tile = [&](int kt, KV& t) {
+        const int kc = min(kt, nkt - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) t.k[s] = *(const frag*)(KF + ((size_t)kc * KS + s) * 512);
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) t.v[d][s2] = *(const frag*)(VF + (((size_t)kc * DT + d) * 2 + s2) * 512);
+    };
+    const int qrel = 4 * hl - q + a.ws;  // rel(i) = j0 + c_i + qrel with the compile-time row offset c_i of element i
+    auto compute_tile = [&](int kt, const KV& t) {
         const int j0 = kt * 32;
         f32x16 S = {0};
-        {
-            const OpT* kp = QK + (size_t)min(j0 + ql, T - 1) * H2 + a.H + h * DK + 8 * hl;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) S = Op<OpT>::mfma(*(const frag*)(kp + 16 * s), Bq[s], S);
-        }
-        const bool near = (j0 >= q0 - 32 - a.ws) && (j0 <= q0 + 32 + a.ws);  // wave-uniform
+        for (int s = 0; s < KS; ++s) S = Op<OpT>::mfma(t.k[s], Bq[s], S);
+        // wave-uniform classification: interior tiles (no relative band, every key and query valid) skip all per-element
+        // index work -- on wave64 every VALU instruction costs 4 cycles, and the general path below is ~35 of them per score
+        const bool near = (j0 >= q0 - 32 - a.ws) && (j0 <= q0 + 32 + a.ws);
+        const bool plain = !near && j0 + 32 <= len && q0 + 32 <= len;
         float mx = -INFINITY;
+        if (plain) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int j = j0 + (i & 3) + 8 * (i >> 2) + 4 * hl;
-            float s = S[i];
-            if (near) {
-                const int rel = j - q + a.ws;
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, S[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ci = (i & 3) + 8 * (i >> 2);
+                const int j = j0 + ci + 4 * hl;
+                float s = S[i];
+                const int rel = j0 + ci + qrel;
+                const bool inband = near && rel >= 0 && rel <= 2 * a.ws;
                 const float rv = Rl[ql * 33 + min(max(rel, 0), 2 * a.ws)];
-                s += (rel >= 0 && rel <= 2 * a.ws) ? rv : 0.f;
+                s += inband ? rv : 0.f;
+                s = (qok && j < len) ? s : -1e4f;  // masked_fill(mask == 0, -1e4), attentions.py:115
+                s = j < T ? s : -INFINITY;         // tile padding: not a key at all
+                Sb[inband ? ql * 32 + rel : 32 * 32 + (lane & 31)] = s;  // band scores are needed again (relative values); else a dump slot
+                S[i] = s;
+                mx = fmaxf(mx, s);
             }
-            s = (qok && j < len) ? s : -1e4f;  // masked_fill(mask == 0, -1e4), attentions.py:115
-            s = j < T ? s : -INFINITY;         // tile padding: not a key at all
-            S[i] = s;
-            mx = fmaxf(mx, s);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float sc = __expf(m_run - m_new);  // 0 on the first tile (m_run = -inf)
         float ps = 0.f;
         frag Bp[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float p = __expf(S[i] - m_new);
+            const float p = __expf(S[i] - m_new);  // in [0, 1]: no fp16 clamp needed
             ps += p;
-            Bp[i >> 3][i & 7] = to_op<OpT>(p);
+            Bp[i >> 3][i & 7] = (OpT)p;
         }
-        l_run = l_run * sc + ps;
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {  // some query's running max moved: rescale
+            const float sc = __expf(m_run - m_new);             // 0 on the first tile (m_run = -inf)
+            l_run *= sc;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) O[d][i] *= sc;
+        }
+        l_run += ps;
         m_run = m_new;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) O[d][i] *= sc;
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-            const OpT* vp = VT + (size_t)(d * 32 + ql) * a.Tp + j0 + 4 * hl;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                union { uint2 u[2]; frag f; } av;
-                av.u[0] = *(const uint2*)(vp + 16 * s2);
-                av.u[1] = *(const uint2*)(vp + 16 * s2 + 8);
-                O[d] = Op<OpT>::mfma(av.f, Bp[s2], O[d]);
-            }
+            for (int s2 = 0; s2 < 2; ++s2) O[d] = Op<OpT>::mfma(t.v[d][s2], Bp[s2], O[d]);
+    };
+    {
+        // three tiles in flight (the K / V blocks come from another XCD's writes: ~2 us away); sched_barrier keeps the
+        // compiler from sinking the prefetch loads down to their first use
+        KV t0, t1, t2;
+        int kt = wave;
+        load_tile(kt, t0);
+        load_tile(kt + 4, t1);
+        while (kt < nkt) {
+            load_tile(kt + 8, t2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(kt, t0);
+            kt += 4;
+            if (kt >= nkt) break;
+            load_tile(kt + 8, t0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(kt, t1);
+            kt += 4;
+            if (kt >= nkt) break;
+            load_tile(kt + 8, t1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_tile(kt, t2);
+            kt += 4;
         }
     }
+    FR_STAMP(2);
     l_run += __shfl_xor(l_run, 32, 64);
     if (hl == 0) {
         Ml[wave * 32 + ql] = m_run;
@@ -514,42 +682,41 @@ static __global__ void __launch_bounds__(256) k_fr_attn(FrAttnArgs a) {
         for (int w = 0; w < 4; ++w) L += Ll[w * 32 + x] * __expf(Ml[w * 32 + x] - M);
         Mf[x] = M;
         Lf[x] = L;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) Wl[w * 32 + x] = __expf(Ml[w * 32 + x] - M) / L;
     }
     __syncthreads();
-    // band of p (relative values, attentions.py:127-135), recomputed in fp32 from the same operands
-    const int nband = 2 * a.ws + 1;
-    for (int idx = threadIdx.x; idx < 32 * nband; idx += 256) {
-        const int x = idx / nband, r = idx - x * nband;
-        const int qq = q0 + x, j = qq + r - a.ws;
-        float p = 0.f;
-        if (qq < T && j >= 0 && j < T) {
-            const OpT* qp = QK + (size_t)qq * H2 + h * DK;
-            const OpT* kp = QK + (size_t)j * H2 + a.H + h * DK;
-            float s = 0.f;
-            for (int d8 = 0; d8 < DK / 8; ++d8) {
-                const frag qa = *(const frag*)(qp + d8 * 8), ka = *(const frag*)(kp + d8 * 8);
+    FR_STAMP(3);
+    // output: thread = (query x, group of DG channels); the band probabilities of x stay in registers.  Every LDS read is
+    // unconditional (rows >= 2ws+1 of Ev are zero and their p is 0).
+    {
+        const int x = threadIdx.x & 31, dg = threadIdx.x >> 5;
+        const float M = Mf[x], Li = 1.f / Lf[x];
+        float pb[NBAND];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s = fmaf((float)qa[e], (float)ka[e], s);
-            }
-            s += Rl[x * 33 + r];
-            s = (qq < len && j < len) ? s : -1e4f;
-            p = __expf(s - Mf[x]) / Lf[x];
+        for (int r = 0; r < NBAND; ++r) pb[r] = __expf(Sb[x * 32 + r] - M) * Li;
+        float w4[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) w4[w] = Wl[w * 32 + x];
+        OpT* out = (OpT*)a.out + ((size_t)b * T + min(q0 + x, T - 1)) * a.H + h * DK + dg * DG;
+#pragma unroll
+        for (int c4 = 0; c4 < DG / 4; ++c4) {
+            const int d = dg * DG + c4 * 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += Ol[(w * 32 + x) * OS + d + e] * w4[w];
+#pragma unroll
+            for (int r = 0; r < NBAND; ++r) acc += *(const f32x4*)(Ev + r * DK + d) * pb[r];  // relative values, attentions.py:127-135
+            o4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(acc[e]);
+            if (q0 + x < T) *(o4*)(out + c4 * 4) = o;
         }
-        Pb[x * 32 + r] = p;
     }
-    __syncthreads();
-    OpT* out = (OpT*)a.out + (size_t)b * a.out_bstride;
-    for (int idx = threadIdx.x; idx < 32 * DK; idx += 256) {
-        const int x = idx / DK, d = idx - x * DK;
-        if (q0 + x >= T) continue;
-        const float M = Mf[x];
-        float o = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) o += Ol[(w * 32 + x) * OS + d] * __expf(Ml[w * 32 + x] - M);
-        o /= Lf[x];
-        for (int r = 0; r < nband; ++r) o = fmaf(Pb[x * 32 + r], a.relv[r * DK + d], o);
-        out[(size_t)(q0 + x) * a.H + h * DK + d] = to_op<OpT>(o);
-    }
+    FR_STAMP(4);
+#undef FR_STAMP
 }
 
 // z * x_mask, channels-last [B][T][C] -> the generator's channel-first [B][C][T]   (synthesizers.py:192)

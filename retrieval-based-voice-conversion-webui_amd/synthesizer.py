@@ -1,20 +1,25 @@
-"""``rvc.synthesizer`` surface (rvc/synthesizer.py:10-35) with the generator swapped for the HIP one.
+"""``rvc.synthesizer`` surface (rvc/synthesizer.py:10-35) with the synthesizer's compute swapped for the HIP path.
 
     get_synthesizer(cpt, device)      -> (net_g, cpt)     rvc/synthesizer.py:10
     load_synthesizer(pth_path, device) -> (net_g, cpt)    rvc/synthesizer.py:31
 
-Everything except ``net_g.dec`` (TextEncoder, flow, emb_g -- SURVEY.md 8f "next" rows) stays the
-reference's own PyTorch-ROCm modules: this module calls the reference loader, which must therefore be
-importable (it is when this package is dropped into an RVC checkout), then replaces ``net_g.dec``.
+This module calls the reference loader (which must therefore be importable -- it is when this package is dropped
+into an RVC checkout), then replaces ``net_g.dec`` with the HIP generator and, with ``front=True`` (default), routes
+``net_g.infer`` through the HIP encoder / flow as well (``rvc_amd.front``): the only torch op left inside ``infer`` is
+the ``emb_g`` row lookup.  The reference's own modules stay attached to ``net_g`` (``enc_p``, ``flow``), unused.
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 
+from .front import FrontHIP, infer_hip
 from .nsf import GeneratorHIP, NSFGeneratorHIP
 
 
-def accelerate_synthesizer(net_g: torch.nn.Module, device=None, operand: str = "fp16", max_B: int = 1, max_T: int = 256):
+def accelerate_synthesizer(net_g: torch.nn.Module, device=None, operand: str = "fp16", max_B: int = 1, max_T: int = 256,
+                           front: bool = True):
     """Swap ``net_g.dec`` (already weight-norm-folded, rvc/synthesizer.py:27) for the HIP generator.
     ``net_g.infer`` (rvc/layers/synthesizers.py:160-203) keeps working unchanged: it type-switches on
     ``isinstance(self.dec, NSFGenerator)`` / ``Generator`` so the replacement classes are registered as
@@ -29,6 +34,11 @@ def accelerate_synthesizer(net_g: torch.nn.Module, device=None, operand: str = "
     cls = NSFGeneratorHIP if use_f0 else GeneratorHIP
     new = cls.from_reference(dec, device=device, operand=operand, max_B=max_B, max_T=max_T)
     net_g.dec = _as_reference_subclass(new, dec)
+    if front and operand in ("fp16", "f16", "bf16") and hasattr(net_g, "enc_p") and hasattr(net_g, "flow"):
+        fr = FrontHIP.from_reference(net_g, device=device, operand=operand, max_B=max_B, max_T=max_T)
+        object.__setattr__(net_g, "_rvcmi_front", fr)  # not a registered submodule: net_g.half()/.to() must not touch it
+        # same signature as SynthesizerTrnMsNSFsid.infer (synthesizers.py:160-170); instance attribute shadows the method
+        object.__setattr__(net_g, "infer", functools.partial(infer_hip, net_g, fr))
     return net_g
 
 

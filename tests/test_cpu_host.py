@@ -37,11 +37,15 @@ def test_struct_layout_matches_the_header():
     assert C.sizeof(_lib.NsfConfig) == 4 * (6 + 16 + 1 + 4 + 4 + 16 + 1)
     assert C.sizeof(_lib.KernelStat) == 48 + 8 + 8 + 8 + 8
     assert C.sizeof(_lib.Tensor) == 8 + 8 + 8 + 32
+    assert C.sizeof(_lib.FrontConfig) == 4 * 15  # rvcmi_front_config: 15 ints
 
 
 def test_fails_loudly_without_a_gpu_and_on_bad_input(tmp_path):
     with pytest.raises(_lib.RvcmiError):
         rvc_amd.NSFGeneratorHIP({}, {}, device="cpu")
+    with pytest.raises(_lib.RvcmiError):
+        from oracle.front_oracle import FrontConfig
+        rvc_amd.FrontHIP(vars(FrontConfig()), {}, device="cpu")
     with pytest.raises(_lib.RvcmiError):
         rvc_amd.read_index(str(tmp_path / "missing.index"), device="cpu")
     h = C.c_void_p()
@@ -52,6 +56,7 @@ def test_fails_loudly_without_a_gpu_and_on_bad_input(tmp_path):
     rc = _lib.lib().rvcmi_ivf_create_from_file(str(bad).encode(), 0, C.byref(h))
     assert rc == -3 and b"IwFl" in _lib.lib().rvcmi_last_error()
     assert _lib.lib().rvcmi_nsf_create(None, None, 0, 0, 1, 1, C.byref(h)) == -1
+    assert _lib.lib().rvcmi_front_create(None, None, 0, 0, 1, 1, C.byref(h)) == -1
 
 
 def test_config_marshalling():
@@ -140,3 +145,25 @@ def test_reference_module_introspection_when_reference_is_present():
         assert got[k] == getattr(cfg, k), k
     sd = _plain_state_dict(net)
     assert "ups.0.weight" in sd and sd["ups.0.weight"].shape == (512, 256, 16)
+
+
+def test_front_introspection_and_infer_patch_when_reference_is_present():
+    """front_config_from_reference against the REAL reference synthesizer (skipped on the GPU box)."""
+    ref = os.environ.get("RVC_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "rvc")):
+        pytest.skip("reference checkout not mounted")
+    import sys
+
+    sys.path.insert(0, ref)
+    from rvc.layers.synthesizers import SynthesizerTrnMsNSFsid
+
+    from oracle.front_oracle import FrontConfig
+
+    cl = [1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", [3, 7, 11], [[1, 3, 5]] * 3, [10, 10, 2, 2], 512, [16, 16, 4, 4], 109, 256, 40000]
+    net = SynthesizerTrnMsNSFsid(*cl, encoder_dim=256, use_f0=True)
+    got = rvc_amd.front_config_from_reference(net)
+    want = vars(FrontConfig(in_channels=256))
+    for k, v in got.items():
+        assert want[k] == v, k
+    with pytest.raises(ValueError):
+        rvc_amd.FrontHIP.from_reference(net, device="cuda:0")  # weight norm still attached

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from conftest import ROOT, golden_config_and_weights, golden_names, load_golden
-from oracle import ivf_oracle, nsf_oracle, synth
+from oracle import front_oracle, ivf_oracle, nsf_oracle, synth
+from oracle.front_oracle import FrontConfig
 
 
 @pytest.mark.parametrize("name", golden_names("dec_"))
@@ -40,6 +41,66 @@ def test_generator_oracle_infer_boundary_golden():
         out = nsf_oracle.generator_forward(cfg, expect, torch.from_numpy(d["z"]), torch.from_numpy(d["f0"]), torch.from_numpy(d["g"]),
                                            torch.from_numpy(d["noise"]))
     assert np.abs(out.numpy() - d["out"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("name", golden_names("front_"))
+def test_front_oracle_matches_reference_golden(name):
+    """oracle/front_oracle.py == the reference's TextEncoder + prior sample + reversed ResidualCouplingBlock
+    (fixtures produced by the reference modules themselves), including every stored intermediate stage."""
+    d = load_golden(name)
+    fcfg = FrontConfig(in_channels=int(d["in_channels"]))
+    wf = synth.make_front_weights(fcfg, int(d["seed"]))
+    assert synth.weights_sha256(wf) == d["weights_sha256"]
+    fh = None if int(d["flow_head"]) < 0 else int(d["flow_head"])
+    taps = {}
+    with torch.no_grad():
+        z, m1, g = front_oracle.infer_front(fcfg, wf, torch.from_numpy(d["phone"]), torch.from_numpy(d["pitch"]), torch.from_numpy(d["lengths"]),
+                                            torch.from_numpy(d["sid"]), torch.from_numpy(d["noise"]), fh, taps)
+        z = z * m1
+    assert np.abs(g.numpy() - d["g"]).max() == 0
+    assert np.abs(z.numpy() - d["z"]).max() < 2e-5
+    for k, ok in (("emb", "emb"), ("attn0", "attn0"), ("layer0", "layer0"), ("layer5", "layer%d" % (fcfg.n_layers - 1)), ("z_p", "z_p")):
+        assert np.abs(taps[ok].transpose(1, 2).numpy() - d[k]).max() < 2e-5, k
+
+
+@pytest.mark.parametrize("name", golden_names("infer_full_"))
+def test_whole_infer_oracle_matches_reference_golden(name):
+    """front oracle + generator oracle == the reference's net_g.infer waveform (full and realtime-partial geometry)."""
+    d = load_golden(name)
+    cfg, fcfg = nsf_oracle.CONFIGS["v2_48k"], FrontConfig()
+    wd, wf = synth.make_dec_weights(cfg, int(d["seed"])), synth.make_front_weights(fcfg, int(d["seed"]))
+    assert synth.weights_sha256(wd) == str(d["dec_sha256"]) and synth.weights_sha256(wf) == str(d["front_sha256"])
+    T = d["phone"].shape[1]
+    sh, rl, rl2 = (None if int(d[k]) < 0 else int(d[k]) for k in ("skip_head", "return_length", "return_length2"))
+    fh = None if sh is None else max(sh - 24, 0)
+    with torch.no_grad():
+        z, m1, g = front_oracle.infer_front(fcfg, wf, torch.from_numpy(d["phone"]), torch.from_numpy(d["pitch"]), torch.tensor([T]),
+                                            torch.from_numpy(d["sid"]), torch.from_numpy(d["noise_zp"]), fh)
+        z = z * m1
+        pf = torch.from_numpy(d["pitchf"])
+        if sh is not None:  # synthesizers.py:172-185
+            z = z[:, :, sh - fh:sh - fh + rl]
+            pf = pf[:, sh:sh + rl]
+        out = nsf_oracle.generator_forward(cfg, wd, z, pf, g, torch.from_numpy(d["noise_dec"]), n_res=rl2)
+    assert out.shape == d["out"].shape and np.abs(out.numpy() - d["out"]).max() < 2e-5
+
+
+def test_front_oracle_masking_semantics():
+    """Padding frames never influence valid ones and come out as exact zeros (x_mask, encoders.py:145-148; the -1e4 fill of
+    attentions.py:114-115)."""
+    fcfg = FrontConfig()
+    wf = synth.make_front_weights(fcfg, 3)
+    B, T, L1 = 2, 24, 17
+    phone = synth.make_phone(B, T, 768, 3)
+    pitch = synth.make_pitch(synth.make_f0(B, T))
+    lengths, sid = torch.tensor([T, L1]), torch.tensor([0, 1])
+    noise = torch.randn(B, 192, T, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        z0, m1, _ = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, noise)
+        ph2 = phone.clone()
+        ph2[1, L1:] = 37.0
+        z1, _, _ = front_oracle.infer_front(fcfg, wf, ph2, pitch, lengths, sid, noise)
+    assert torch.equal((z0 * m1)[1, :, :L1], (z1 * m1)[1, :, :L1]) and ((z1 * m1)[1, :, L1:] == 0).all()
 
 
 def test_sine_source_phase_is_continuous_and_unvoiced_is_noise_only():
