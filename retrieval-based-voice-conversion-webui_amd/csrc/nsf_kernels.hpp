@@ -360,6 +360,39 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
     constexpr int STRIDE = Tile<CIN>::STRIDE;
     constexpr int C8 = CIN / 8;
     const int tid = threadIdx.x;
+    if (a.in_mode == IN_F32_CF) {
+        // channel-first input (the caller's [B][C][T], nsf.py:164): consecutive lanes walk TIME so that every load
+        // instruction is one contiguous run per channel; 8 channels x SBC chunks in flight per thread (the row-major
+        // mapping below made this 8 uncoalesced serial loads per chunk: 49 us for conv_pre at T = 1198)
+        constexpr int SBC = 4;
+        const float* ip = (const float*)a.in + (size_t)b * a.in_bstride;
+        const int total = rows * C8;
+        for (int base = tid; base < total; base += SBC * 256) {
+            float f[SBC][8];
+#pragma unroll
+            for (int u = 0; u < SBC; ++u) {
+                const int idx = min(base + u * 256, total - 1);
+                const int c8 = idx / rows, r = idx - c8 * rows;
+                const int grc = min(max(g0 + r, 0), a.Lin - 1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[u][e] = ip[(size_t)(c8 * 8 + e) * a.Lin + grc];
+            }
+#pragma unroll
+            for (int u = 0; u < SBC; ++u) {
+                const int idx = base + u * 256;
+                if (idx < total) {
+                    const int c8 = idx / rows, r = idx - c8 * rows;
+                    const int gr = g0 + r;
+                    const bool ok = gr >= 0 && gr < a.Lin;
+                    frag v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ok ? to_op<OpT>(f[u][e]) : (OpT)0.f;
+                    *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
+                }
+            }
+        }
+        return;
+    }
     for (int idx = tid; idx < rows * C8; idx += 256) {
         const int r = idx / C8;
         const int c8 = idx - r * C8;
@@ -570,6 +603,26 @@ static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
 
     // ---- epilogue -------------------------------------------------------------------------
     const int out_add = a.nphase > 1 ? ph : a.out_add;
+    // bias (+ the per-utterance cond vector) of this lane's channels: fetched ONCE, as one batch, before the store loops
+    // (a conditional load inside them becomes a branch with its own wait: 64 serialised L2 round trips = ~30 us on conv_pre)
+    f32x4 bvec[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bvec[mi][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bvec[mi][g] = *(const f32x4*)(a.bias + min((ct0 + mi) * 32 + 4 * (lane >> 5) + 8 * g, a.cout - 4));
+    }
+    if (a.cb && a.out_mode != OUT_ACT) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bvec[mi][g] += *(const f32x4*)(a.cb + (size_t)b * a.cout + min((ct0 + mi) * 32 + 4 * (lane >> 5) + 8 * g, a.cout - 4));
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int cobase = (ct0 + mi) * 32 + 4 * (lane >> 5);
@@ -583,10 +636,7 @@ static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
                 const int co = cobase + 8 * g;
                 if (co >= a.cout) continue;  // cout is a multiple of 4 whenever it is < the padded tile
                 f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
-                if (a.bias) {
-                    const f32x4 bv = *(const f32x4*)(a.bias + co);
-                    v += bv;
-                }
+                v += bvec[mi][g];
                 if (a.out_mode == OUT_ACT) {
                     using o4 = __attribute__((ext_vector_type(4))) OpT;
                     o4 o;
@@ -594,7 +644,6 @@ static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
                     for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(lrelu(v[e], a.slope_out));
                     *(o4*)((OpT*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co) = o;
                 } else {
-                    if (a.cb) v += *(const f32x4*)(a.cb + (size_t)b * a.cout + co);
                     if (a.res) v += *(const f32x4*)(a.res + (size_t)b * a.res_bstride + orow * a.out_C + co);
                     f32x4* o = (f32x4*)((float*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co);
                     if (a.accumulate) v += *o;
