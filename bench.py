@@ -43,6 +43,8 @@ def parse():
     p.add_argument("--index-d", type=int, default=768)
     p.add_argument("--index-rate", type=float, default=0.75)
     p.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    p.add_argument("--whole", action="store_true",
+                   help="time the whole net_g.infer (retrieval + enc_p + flow^-1 + decode) as THE step instead of the BASELINE hot path")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--stream", action="store_true",
@@ -187,10 +189,25 @@ def main():
     feats = torch.empty_like(phone_d)
     out_holder = {}
 
+    front = None
+    if a.whole:
+        from oracle.front_oracle import FrontConfig
+
+        fcfg0 = FrontConfig()
+        front = rvc_amd.FrontHIP(vars(fcfg0), synth.make_front_weights(fcfg0, 1234), device=dev, operand=a.operand, max_B=B, max_T=T)
+        pitch0 = synth.make_pitch(f0).to(dev)
+        nz0 = torch.randn(B, fcfg0.inter_channels, T, device=dev)
+
     def step():
         feats.copy_(phone_d)
         index.search_blend(feats, a.index_rate, 8)
-        out_holder["o"] = gen(zd, f0d, gd, noise=nd)
+        if front is None:
+            out_holder["o"] = gen(zd, f0d, gd, noise=nd)
+        else:
+            Tw = (T // NQ_CLIP) * NQ_CLIP
+            ph = feats.view(B, NQ_CLIP, a.index_d).repeat_interleave(T // NQ_CLIP, dim=1)
+            zz = front(ph, pitch0[:, :Tw], None, gd, 0, noise=nz0[:, :, :Tw])
+            out_holder["o"] = gen(zz, f0d[:, :Tw], gd, noise=nd[:, :Tw * cfg.upp])
 
     for _ in range(2):
         step()
@@ -233,12 +250,17 @@ def main():
     if rank == 0 and not a.no_roofline:
         gen.profile(True)
         index.profile(True)
+        if front is not None:
+            front.profile(True)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
         gs, ivs = gen.profile_read(), index.profile_read()
         gen.profile(False)
         index.profile(False)
+        if front is not None:
+            ivs = ivs + front.profile_read()
+            front.profile(False)
         dom = max(gs, key=lambda s: s["ms"])
         peak = PEAK[a.operand]
         ach = dom["flops"] / (dom["ms"] * 1e-3)
@@ -266,7 +288,7 @@ def main():
 
     # ---- whole net_g.infer leg: retrieval -> x2 frames -> enc_p -> z_p -> flow^-1 -> decode, one graph ----
     whole = None
-    if rank == 0 and not a.no_roofline and a.index_d == 768 and a.operand != "fp32":
+    if rank == 0 and not a.no_roofline and not a.whole and a.index_d == 768 and a.operand != "fp32":
         from oracle.front_oracle import FrontConfig
 
         fcfg = FrontConfig()
@@ -324,7 +346,8 @@ def main():
         clips = B * world * a.steps
         value = clips * CLIP_SECONDS * (T / T_CLIP) / dt
         line = {
-            "metric": "real-time factor (audio-sec/wall-sec), 48 kHz v2, 10 s clips, retrieval + NSF-HiFi-GAN decode",
+            "metric": "real-time factor (audio-sec/wall-sec), 48 kHz v2, 10 s clips, retrieval + NSF-HiFi-GAN decode" +
+                      (" + enc_p + flow (whole net_g.infer)" if a.whole else ""),
             "value": value, "unit": "x real-time (audio-sec/wall-sec), whole job",
             "per_gpu": value / world,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
