@@ -243,6 +243,14 @@ int rvcmi_ivf_search(rvcmi_ivf* h, int64_t nq, const float* q_dev, int k, float*
 int rvcmi_ivf_search_blend(rvcmi_ivf* h, int64_t nq, float* feats_dev, float index_rate, int k,
                            int skip_if_short, void* stream);
 
+/* rvcmi_ivf_search_blend followed by what Pipeline.vc does next (pipeline.py:140-159), in one pass over the rows:
+ *   F.interpolate(scale_factor=2) (nearest: out frame t <- row t/2), truncation to p_len <= 2*nq, and -- when
+ *   pitchf_dev is not NULL (the `protect < 0.5` branch) -- feats*pitchff + feats0*(1-pitchff) with
+ *   pitchff = pitchf[t] < 1 ? protect : 1.  feats_dev [nq,d] is NOT modified; out_dev is [p_len,d].            */
+int rvcmi_ivf_search_blend_expand(rvcmi_ivf* h, int64_t nq, const float* feats_dev, float index_rate, int k,
+                                  int skip_if_short, const float* pitchf_dev, float protect, int64_t p_len,
+                                  float* out_dev, void* stream);
+
 /* index.reconstruct_n(i0, n) -> out_host [n,d] rows in id order (pipeline.py:215).             */
 int rvcmi_ivf_reconstruct_n(const rvcmi_ivf* h, int64_t i0, int64_t n, float* out_host);
 
@@ -255,6 +263,29 @@ int rvcmi_ivf_create_from_blob(void* dev_ptr, size_t bytes, int device, int take
 /* Per-phase HIP-event timing for bench.py (coarse / scan / blend), same contract as the nsf one. */
 int rvcmi_ivf_profile_enable(rvcmi_ivf* h, int enable);
 int rvcmi_ivf_profile_read(rvcmi_ivf* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset);
+
+/* ------------------------------------------------------------------------------------------- */
+/* Device-resident glue: stateless, everything on the caller's stream */
+/* ------------------------------------------------------------------------------------------- */
+
+/* The x2 interpolation + protect mix of pipeline.py:140-159 when NO index is used (index_rate == 0):
+ * out[t] = feats[t/reps] (* pf + feats[t/reps] * (1 - pf) when pitchf_dev != NULL).                */
+int rvcmi_glue_expand_protect(const float* feats_dev, int64_t nq, int d, int reps, const float* pitchf_dev,
+                              float protect, int64_t p_len, float* out_dev, void* stream);
+
+/* RMVPE salience [n,nbins=360] -> what Generator.calculate(..., "rmvpe") returns (rvc/f0/gen.py:43-123):
+ *   _to_local_average_cents + _decode (rvc/f0/rmvpe.py:119-164), _resize_f0 to p_len and _interpolate_f0
+ *   (rvc/f0/f0.py:31-78), post_process (rvc/f0/gen.py:10-41): key shift 2^(f0_up_key/12), mel binning to 1..255.
+ * fp64 throughout, like numpy.  scratch_dev: n doubles.  pitch_dev [p_len] int64, pitchf_dev [p_len] fp32.
+ * n + p_len <= 20480 frames (one block holds the sequential pass).                                  */
+int rvcmi_glue_rmvpe_f0(const float* salience_dev, int n, int nbins, float thred, int p_len, int f0_up_key,
+                        double* scratch_dev, int64_t* pitch_dev, float* pitchf_dev, void* stream);
+/* post_process only (f0 in Hz from any other estimator, fp64 [n]).                                 */
+int rvcmi_glue_f0_post(const double* f0_dev, int n, int f0_up_key, int64_t* pitch_dev, float* pitchf_dev,
+                       void* stream);
+
+/* pipeline.py:355-359: audio *= 32768 / max(1, abs(audio).max()/0.99), in place.  scratch_dev: 256 floats. */
+int rvcmi_glue_scale_int16_range(float* audio_dev, int64_t n, float* scratch_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ oracle/synth.py and verify the sha256 recorded here.
 """
 from __future__ import annotations
 
+import math
 import os
 import sys
 
@@ -217,7 +218,81 @@ def infer_full_case(name: str, T: int, skip_head=None, return_length=None, retur
         name, o.pow(2).mean().sqrt().item(), err, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
 
 
+def glue_case(name: str = "glue_f0"):
+    """The f0 chain of the REFERENCE itself -- RMVPE._to_local_average_cents/_decode (rvc/f0/rmvpe.py:119-164),
+    F0Predictor._resize_f0/_interpolate_f0 (rvc/f0/f0.py:31-78), post_process (rvc/f0/gen.py:10-41, numba stubbed to a
+    pass-through) -- on seeded salience maps with voiced/unvoiced runs, edge layouts included.  The oracle restatement is
+    checked against them, inputs and outputs are stored."""
+    import types
+
+    sys.path.insert(0, REF)
+    nb = types.ModuleType("numba")
+    nb.jit = lambda *a, **k: (lambda f: f)
+    sys.modules.setdefault("numba", nb)
+    from math import log
+
+    from rvc.f0.f0 import F0Predictor
+    from rvc.f0.gen import post_process
+
+    src = open(os.path.join(REF, "rvc", "f0", "rmvpe.py")).read()
+    a, b = src.index("    def _to_local_average_cents"), src.index("    def _mel2hidden")
+    c = src.index("    def _decode")
+    ns = {"np": np}
+    exec("class R:\n" + src[a:b] + src[c:], ns)  # the two methods verbatim, without the model-loading constructor
+    R = ns["R"]
+    rm = R()
+    rm.cents_mapping = np.pad(20 * np.arange(360) + 1997.3794084376191, (4, 4))  # rmvpe.py:62-63
+    from oracle import glue_oracle
+
+    out = {}
+    rng = np.random.default_rng(2024)
+    cases = {
+        "mixed": (300, 310, 0), "up": (150, 300, 7), "down": (257, 129, -5), "lead_unvoiced": (64, 64, 12),
+        "tail_unvoiced": (80, 90, 0), "last_voiced_only_end": (40, 40, 3), "all_unvoiced": (33, 40, 0), "single": (1, 3, 0),
+    }
+    fp = F0Predictor()
+    for cname, (n, p_len, key) in cases.items():
+        sal = (rng.random((n, 360), dtype=np.float32) * 0.02).astype(np.float32)
+        voiced = np.ones(n, bool)
+        if cname == "mixed":
+            voiced[(np.arange(n) % 50) < 12] = False
+        elif cname == "lead_unvoiced":
+            voiced[:20] = False
+        elif cname == "tail_unvoiced":
+            voiced[-25:] = False
+        elif cname == "last_voiced_only_end":
+            voiced[10:-1] = False
+        elif cname == "all_unvoiced":
+            voiced[:] = False
+        elif cname in ("up", "down"):
+            voiced[(np.arange(n) % 37) < 9] = False
+        centre = (120 + 60 * np.sin(np.arange(n) / 17.0)).astype(int)
+        centre[::29] = np.array([0, 1, 358, 359, 3, 356])[np.arange(len(centre[::29])) % 6]  # window clipped at both table ends
+        for i in range(n):
+            if voiced[i]:
+                k0 = centre[i]
+                for w_ in range(-6, 7):
+                    if 0 <= k0 + w_ < 360:
+                        sal[i, k0 + w_] += np.float32(0.9 * math.exp(-0.5 * (w_ / 2.0) ** 2))
+        f0a = rm._decode(sal.copy(), thred=0.03)
+        f0r = fp._interpolate_f0(fp._resize_f0(f0a, p_len))[0]
+        coarse, f0k = post_process(100, f0r.copy(), key, 1, 1127 * log(1 + 50 / 700), 1127 * log(1 + 1100 / 700), None)
+        pitch, pitchf = coarse[:p_len].astype(np.int64), f0k[:p_len].astype(np.float32)
+        o_dec = glue_oracle.rmvpe_decode(sal, 0.03)
+        o_pitch, o_pitchf = glue_oracle.rmvpe_f0(sal, p_len, key, 0.03)
+        assert np.array_equal(o_dec, f0a), cname
+        assert np.array_equal(o_pitch, pitch) and np.array_equal(o_pitchf, pitchf), cname
+        out[cname + "::salience"] = sal
+        out[cname + "::meta"] = np.array([n, p_len, key])
+        out[cname + "::f0_decoded"] = f0a
+        out[cname + "::pitch"] = pitch
+        out[cname + "::pitchf"] = pitchf
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print("%-28s %d cases, oracle == reference bit-exact  (%d KB)" % (name, len(cases), os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
 def main_front():
+    glue_case()
     front_case("front_v2_B2_T50", 2, 50, [50, 43])
     front_case("front_v2_B1_T100_head6", 1, 100, [100], flow_head=6)     # > one 64-row tile, realtime flow_head
     front_case("front_v1_B1_T40", 1, 40, [40], in_channels=256)           # v1: 256-d features

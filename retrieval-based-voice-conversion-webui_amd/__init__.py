@@ -9,10 +9,11 @@ from .ivf import IVFFlatHIP, read_index, write_index
 from .front import FrontHIP, front_config_from_reference, infer_hip
 from .nsf import GeneratorHIP, NSFGeneratorHIP, config_from_reference
 from .pipeline import retrieve_blend
+from . import glue
 from .synthesizer import accelerate_synthesizer, get_synthesizer, load_synthesizer
 from . import dist
 
 __all__ = [
     "RvcmiError", "build", "IVFFlatHIP", "read_index", "write_index", "GeneratorHIP", "NSFGeneratorHIP",
-    "config_from_reference", "FrontHIP", "front_config_from_reference", "infer_hip", "retrieve_blend", "accelerate_synthesizer", "get_synthesizer", "load_synthesizer", "dist",
+    "config_from_reference", "FrontHIP", "front_config_from_reference", "infer_hip", "retrieve_blend", "accelerate_synthesizer", "get_synthesizer", "load_synthesizer", "dist", "glue",
 ]

@@ -14,7 +14,7 @@ from typing import List
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librvcmi.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["nsf.hip", "ivf.hip", "front.hip"]
+SOURCES = ["nsf.hip", "ivf.hip", "front.hip", "glue.hip"]
 
 RVCMI_MAX_UPS, RVCMI_MAX_RB, RVCMI_MAX_DIL = 8, 4, 4
 OPERANDS = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2}
@@ -88,11 +88,16 @@ SYMBOLS = [
     ("rvcmi_ivf_reserve", C.c_int, [_P, C.c_int64]),
     ("rvcmi_ivf_search", C.c_int, [_P, C.c_int64, _P, C.c_int, _P, _P, _P]),
     ("rvcmi_ivf_search_blend", C.c_int, [_P, C.c_int64, _P, C.c_float, C.c_int, C.c_int, _P]),
+    ("rvcmi_ivf_search_blend_expand", C.c_int, [_P, C.c_int64, _P, C.c_float, C.c_int, C.c_int, _P, C.c_float, C.c_int64, _P, _P]),
     ("rvcmi_ivf_reconstruct_n", C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     ("rvcmi_ivf_blob", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     ("rvcmi_ivf_create_from_blob", C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.POINTER(_P)]),
     ("rvcmi_ivf_profile_enable", C.c_int, [_P, C.c_int]),
     ("rvcmi_ivf_profile_read", C.c_int, [_P, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int), C.c_int]),
+    ("rvcmi_glue_expand_protect", C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, C.c_float, C.c_int64, _P, _P]),
+    ("rvcmi_glue_rmvpe_f0", C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P, _P]),
+    ("rvcmi_glue_f0_post", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
+    ("rvcmi_glue_scale_int16_range", C.c_int, [_P, C.c_int64, _P, _P]),
 ]
 
 

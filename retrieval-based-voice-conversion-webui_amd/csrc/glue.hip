@@ -1,0 +1,74 @@
+// C entry points of the device-resident glue; kernels in glue_kernels.hpp.
+#include <cmath>
+
+#include "common.hpp"
+#include "glue_kernels.hpp"
+
+using namespace rvcmi;
+
+extern "C" {
+
+int rvcmi_glue_expand_protect(const float* feats, int64_t nq, int d, int reps, const float* pitchf, float protect, int64_t p_len,
+                              float* out, void* stream) {
+    return guarded([&] {
+        if (!feats || !out || nq < 0 || d < 1 || reps < 1 || p_len < 0 || p_len > nq * reps)
+            RVCMI_FAIL(RVCMI_ERR_INVALID, "expand_protect: bad argument (nq %lld d %d reps %d p_len %lld)", (long long)nq, d, reps, (long long)p_len);
+        if (!nq || !p_len) return;
+        hipLaunchKernelGGL(k_blend_expand, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, feats, nullptr, nullptr, nullptr, d, 0,
+                           (int64_t)0, 0.f, 0.f, nullptr, 0, pitchf, protect, p_len, reps, out);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int rvcmi_glue_rmvpe_f0(const float* salience, int n, int nbins, float thred, int p_len, int f0_up_key, double* scratch,
+                        int64_t* pitch, float* pitchf, void* stream) {
+    return guarded([&] {
+        if (!salience || !scratch || !pitch || !pitchf || n < 1 || nbins < 1 || p_len < 1)
+            RVCMI_FAIL(RVCMI_ERR_INVALID, "rmvpe_f0: bad argument");
+        const size_t smem = (size_t)(n + p_len) * sizeof(double);
+        if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_NOMEM, "rmvpe_f0: %d + %d frames exceed the single-block f0 pass (20480)", n, p_len);
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL(k_rmvpe_decode, dim3((n + 3) / 4), dim3(256), 0, st, salience, n, nbins, thred, scratch);
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f0_post), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        // the host evaluates the scalars exactly as the reference does (python floats / math.log, rvc/f0/gen.py:18, 70-73)
+        const double key_mul = std::pow(2.0, (double)f0_up_key / 12.0);
+        const double mel_min = 1127.0 * std::log(1.0 + 50.0 / 700.0), mel_max = 1127.0 * std::log(1.0 + 1100.0 / 700.0);
+        hipLaunchKernelGGL(k_f0_post, dim3(1), dim3(256), smem, st, scratch, n, p_len, 1, 1, key_mul, mel_min, mel_max, pitch, pitchf);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int rvcmi_glue_f0_post(const double* f0, int n, int f0_up_key, int64_t* pitch, float* pitchf, void* stream) {
+    return guarded([&] {
+        if (!f0 || !pitch || !pitchf || n < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "f0_post: bad argument");
+        const size_t smem = (size_t)(2 * n) * sizeof(double);
+        if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_NOMEM, "f0_post: %d frames exceed the single-block f0 pass (10240)", n);
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f0_post), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        const double key_mul = std::pow(2.0, (double)f0_up_key / 12.0);
+        const double mel_min = 1127.0 * std::log(1.0 + 50.0 / 700.0), mel_max = 1127.0 * std::log(1.0 + 1100.0 / 700.0);
+        hipLaunchKernelGGL(k_f0_post, dim3(1), dim3(256), smem, (hipStream_t)stream, f0, n, n, 0, 0, key_mul, mel_min, mel_max, pitch, pitchf);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int rvcmi_glue_scale_int16_range(float* audio, int64_t n, float* scratch256, void* stream) {
+    return guarded([&] {
+        if (!audio || !scratch256 || n < 0) RVCMI_FAIL(RVCMI_ERR_INVALID, "scale_int16_range: bad argument");
+        if (!n) return;
+        const int nb = (int)std::min<int64_t>(256, (n + 255) / 256);
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL(k_absmax_partial, dim3(nb), dim3(256), 0, st, audio, n, scratch256);
+        hipLaunchKernelGGL(k_scale_int16_range, dim3(nb), dim3(256), 0, st, audio, n, scratch256, nb);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+}  // extern "C"

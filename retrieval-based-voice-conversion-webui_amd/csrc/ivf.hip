@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "glue_kernels.hpp"
 
 namespace rvcmi {
 
@@ -913,6 +914,25 @@ int rvcmi_ivf_search_blend(rvcmi_ivf* h, int64_t nq, float* feats, float index_r
         h->prof.launch("ivf_blend", 2.0 * nq * k * d, (double)nq * d * 4 * (2 + k), st, [&] {
             hipLaunchKernelGGL(k_blend, dim3((unsigned)nq), dim3(256), 0, st, feats, h->Dtmp.as<float>(), h->P.as<int64_t>(),
                                h->vecs(), d, k, h->hdr.pos_last, rate, omr, h->flag.as<int>(), skip_if_short);
+        });
+        HIP_CHECK(hipGetLastError());
+    });
+}
+int rvcmi_ivf_search_blend_expand(rvcmi_ivf* h, int64_t nq, const float* feats, float index_rate, int k, int skip_if_short,
+                                  const float* pitchf, float protect, int64_t p_len, float* out, void* stream) {
+    return guarded([&] {
+        if (!h || (nq && (!feats || !out))) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        if (p_len < 0 || p_len > 2 * nq) RVCMI_FAIL(RVCMI_ERR_INVALID, "p_len %lld outside [0, 2*nq]", (long long)p_len);
+        if (nq == 0 || p_len == 0) return;
+        hipStream_t st = (hipStream_t)stream;
+        reserve(h, nq);
+        search(h, nq, feats, k, h->Dtmp.as<float>(), h->Itmp.as<int64_t>(), st);
+        const int d = h->hdr.d;
+        const float rate = index_rate, omr = (float)(1.0 - (double)index_rate);
+        h->prof.launch("ivf_blend_x2", 2.0 * nq * k * d, (double)nq * d * 4 * (1 + k) + (double)p_len * d * 4, st, [&] {
+            hipLaunchKernelGGL(k_blend_expand, dim3((unsigned)nq), dim3(256), 0, st, feats, h->Dtmp.as<float>(), h->P.as<int64_t>(),
+                               h->vecs(), d, k, h->hdr.pos_last, rate, omr, h->flag.as<int>(), skip_if_short, pitchf, protect,
+                               p_len, 2, out);
         });
         HIP_CHECK(hipGetLastError());
     });

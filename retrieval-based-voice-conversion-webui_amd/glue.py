@@ -1,0 +1,102 @@
+"""Device-resident versions of the host-side glue of ``Pipeline.vc`` / ``Pipeline.pipeline`` (SURVEY.md section 8f
+row 2), so that nothing between the PyTorch-ROCm feature extractors and ``net_g.infer`` has to visit the host:
+
+    retrieve_blend_expand(feats, index, index_rate, pitchf, protect, p_len)   pipeline.py:118-159
+    rmvpe_f0(salience, p_len, f0_up_key, thred)                               rvc/f0/rmvpe.py:115-164, f0.py:31-78, gen.py:10-41
+    f0_post(f0, f0_up_key)                                                    rvc/f0/gen.py:10-41
+    scale_int16_range(audio)                                                  pipeline.py:355-359
+
+All take and return CUDA (ROCm) tensors and enqueue on the current stream; a CPU tensor raises (no fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _dev(t: torch.Tensor, what: str) -> torch.device:
+    if t.device.type != "cuda":
+        raise _lib.RvcmiError("%s must live on the GPU (got %s); the glue has no CPU fallback" % (what, t.device))
+    return t.device
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def retrieve_blend_expand(feats: torch.Tensor, index, index_rate: float, pitchf: Optional[torch.Tensor] = None,
+                          protect: float = 0.5, p_len: Optional[int] = None, realtime_guard: bool = False) -> torch.Tensor:
+    """``feats`` [1, nq, d] HuBERT features -> [1, p_len, d]: retrieval blend (when ``index`` is given and
+    ``index_rate != 0``), x2 nearest interpolation, truncation to ``p_len`` and the protect mix
+    (``pitchf`` [1, >= p_len], applied when ``protect < 0.5`` as in pipeline.py:153)."""
+    dev = _dev(feats, "feats")
+    if feats.dim() != 3 or feats.shape[0] != 1:
+        raise ValueError("feats must be [1, nq, d]")
+    nq, d = int(feats.shape[1]), int(feats.shape[2])
+    p_len = 2 * nq if p_len is None else min(int(p_len), 2 * nq)
+    f = feats[0].to(torch.float32).contiguous()
+    pf = None
+    if pitchf is not None and protect < 0.5:
+        pf = pitchf.reshape(-1)[:p_len].to(dev, torch.float32).contiguous()
+        if pf.numel() < p_len:
+            raise ValueError("pitchf has %d frames, p_len is %d" % (pf.numel(), p_len))
+    out = torch.empty(p_len, d, device=dev, dtype=torch.float32)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        if index is not None and index_rate != 0:
+            if d != index.d:
+                raise ValueError("index mistatch")  # the reference's message (pipeline.py:128)
+            index.reserve(nq)
+            _lib.check(L.rvcmi_ivf_search_blend_expand(index._h, nq, _ptr(f), float(index_rate), 8, 1 if realtime_guard else 0,
+                                                       _ptr(pf), float(protect), p_len, _ptr(out), _stream(dev)))
+        else:
+            _lib.check(L.rvcmi_glue_expand_protect(_ptr(f), nq, d, 2, _ptr(pf), float(protect), p_len, _ptr(out), _stream(dev)))
+    return out.unsqueeze(0).to(feats.dtype)
+
+
+def rmvpe_f0(salience: torch.Tensor, p_len: int, f0_up_key: int = 0, thred: float = 0.03) -> Tuple[torch.Tensor, torch.Tensor]:
+    """RMVPE salience [n, 360] -> (pitch int64 [1, p_len], pitchf float32 [1, p_len]) as ``Generator.calculate`` +
+    pipeline.py:270-277 produce them."""
+    dev = _dev(salience, "salience")
+    if salience.dim() != 2:
+        raise ValueError("salience must be [n, bins]")
+    s = salience.to(torch.float32).contiguous()
+    n, nb = int(s.shape[0]), int(s.shape[1])
+    scratch = torch.empty(n, device=dev, dtype=torch.float64)
+    pitch = torch.empty(int(p_len), device=dev, dtype=torch.int64)
+    pitchf = torch.empty(int(p_len), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().rvcmi_glue_rmvpe_f0(_ptr(s), n, nb, float(thred), int(p_len), int(f0_up_key), _ptr(scratch), _ptr(pitch),
+                                                  _ptr(pitchf), _stream(dev)))
+    return pitch.unsqueeze(0), pitchf.unsqueeze(0)
+
+
+def f0_post(f0: torch.Tensor, f0_up_key: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """f0 in Hz [n] (any estimator) -> (pitch int64 [1, n], pitchf float32 [1, n]): rvc/f0/gen.py post_process."""
+    dev = _dev(f0, "f0")
+    x = f0.reshape(-1).to(torch.float64).contiguous()
+    n = int(x.numel())
+    pitch = torch.empty(n, device=dev, dtype=torch.int64)
+    pitchf = torch.empty(n, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().rvcmi_glue_f0_post(_ptr(x), n, int(f0_up_key), _ptr(pitch), _ptr(pitchf), _stream(dev)))
+    return pitch.unsqueeze(0), pitchf.unsqueeze(0)
+
+
+def scale_int16_range(audio: torch.Tensor) -> torch.Tensor:
+    """In place: ``audio *= 32768 / max(1, |audio|.max() / 0.99)`` (pipeline.py:355-359); returns ``audio``."""
+    dev = _dev(audio, "audio")
+    if audio.dtype != torch.float32 or not audio.is_contiguous():
+        raise ValueError("audio must be a contiguous float32 tensor")
+    scratch = torch.empty(256, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().rvcmi_glue_scale_int16_range(_ptr(audio), audio.numel(), _ptr(scratch), _stream(dev)))
+    return audio

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import ROOT, golden_config_and_weights, golden_names, load_golden
-from oracle import front_oracle, ivf_oracle, nsf_oracle, synth
+from oracle import front_oracle, glue_oracle, ivf_oracle, nsf_oracle, synth
 from oracle.front_oracle import FrontConfig
 
 
@@ -101,6 +101,28 @@ def test_front_oracle_masking_semantics():
         ph2[1, L1:] = 37.0
         z1, _, _ = front_oracle.infer_front(fcfg, wf, ph2, pitch, lengths, sid, noise)
     assert torch.equal((z0 * m1)[1, :, :L1], (z1 * m1)[1, :, :L1]) and ((z1 * m1)[1, :, L1:] == 0).all()
+
+
+def test_glue_oracle_matches_reference_golden():
+    """oracle/glue_oracle.py == RMVPE._decode + F0Predictor._resize_f0/_interpolate_f0 + post_process of the reference
+    (fixture produced by those functions themselves): bit-exact, all edge layouts."""
+    d = load_golden("glue_f0")
+    for c in sorted({k.split("::")[0] for k in d}):
+        n, p_len, key = (int(v) for v in d[c + "::meta"])
+        assert np.array_equal(glue_oracle.rmvpe_decode(d[c + "::salience"], 0.03), d[c + "::f0_decoded"]), c
+        pitch, pitchf = glue_oracle.rmvpe_f0(d[c + "::salience"], p_len, key, 0.03)
+        assert np.array_equal(pitch, d[c + "::pitch"]) and np.array_equal(pitchf, d[c + "::pitchf"]), c
+
+
+def test_glue_interpolate_f0_quirks():
+    """The reference's gap filling (f0.py:31-66): leading gaps copy the next voiced value, inner gaps ramp with step (next - prev) / gap_length
+    (so the last filled frame already equals the next voiced value), a trailing
+    gap repeats the last voiced value, and a gap that ends on the LAST frame overwrites it."""
+    f = glue_oracle.interpolate_f0(np.array([0, 0, 100.0, 0, 0, 130.0, 0, 0]))
+    assert np.allclose(f, [100, 100, 100, 115, 130, 130, 130, 130])
+    f = glue_oracle.interpolate_f0(np.array([100.0, 0, 0, 200.0]))
+    assert np.allclose(f, [100, 100, 100, 100])
+    assert np.array_equal(glue_oracle.interpolate_f0(np.zeros(5)), np.zeros(5))
 
 
 def test_sine_source_phase_is_continuous_and_unvoiced_is_noise_only():
