@@ -198,7 +198,7 @@ def main():
         pitch0 = synth.make_pitch(f0).to(dev)
         nz0 = torch.randn(B, fcfg0.inter_channels, T, device=dev)
 
-    def whole(front_, pitch_, nz_):
+    def run_whole(front_, pitch_, nz_):
         # Pipeline.vc (pipeline.py:118-175) from the HuBERT features on: search + blend + x2 frames + protect mix in ONE pass
         # (rvcmi_ivf_search_blend_expand, WebUI default protect 0.33), then enc_p -> z_p -> flow^-1 -> generator
         Tw = 2 * NQ_CLIP
@@ -213,7 +213,7 @@ def main():
             index.search_blend(feats, a.index_rate, 8)
             out_holder["o"] = gen(zd, f0d, gd, noise=nd)
         else:
-            out_holder["o"] = whole(front, pitch0, nz0)
+            out_holder["o"] = run_whole(front, pitch0, nz0)
 
     for _ in range(2):
         step()
@@ -305,7 +305,7 @@ def main():
         reps = 2
 
         def step_whole():
-            out_holder["w"] = whole(front, pitch_d, nz_zp)
+            out_holder["w"] = run_whole(front, pitch_d, nz_zp)
 
         try:
             for _ in range(2):
