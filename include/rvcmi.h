@@ -287,6 +287,14 @@ int rvcmi_glue_f0_post(const double* f0_dev, int n, int f0_up_key, int64_t* pitc
 /* pipeline.py:355-359: audio *= 32768 / max(1, abs(audio).max()/0.99), in place.  scratch_dev: 256 floats. */
 int rvcmi_glue_scale_int16_range(float* audio_dev, int64_t n, float* scratch_dev, void* stream);
 
+/* SOLA chunk stitching of the realtime path (gui.py:1057-1090): normalised cross-correlation
+ * of infer_wav[: Lb + Ls] with sola_buffer [Lb] over offsets 0..Ls, argmax (first maximum), cut, cross-fade with the
+ * sin^2 windows, out_block_dev [block_frame] <- result, sola_buffer_dev <- the next tail (in place).
+ * offset_out_dev (optional) receives the chosen offset.  Needs Ls + block_frame + Lb <= n.            */
+int rvcmi_glue_sola(const float* infer_wav_dev, int64_t n, float* sola_buffer_dev, int Lb, int Ls,
+                    const float* fade_in_dev, const float* fade_out_dev, int block_frame, float* out_block_dev,
+                    int* offset_out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

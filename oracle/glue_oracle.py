@@ -7,6 +7,7 @@
 * ``interpolate_f0``      rvc/f0/f0.py:31-66
 * ``post_process``        rvc/f0/gen.py:10-41, constants :70-73,131-132
 * ``scale_int16_range``   infer/modules/vc/pipeline.py:355-359
+* ``sola``                gui.py:1057-1090 (the non-phase-vocoder branch)
 
 ``oracle/make_golden.py`` pins the f0 functions to the reference's own implementations (``F0Predictor``, ``RMVPE``
 methods, ``post_process`` with numba stubbed out) on seeded inputs and stores the results in ``tests/golden/glue_f0.npz``.
@@ -122,3 +123,19 @@ def scale_int16_range(audio: np.ndarray) -> np.ndarray:
         max_int16 /= audio_max
     np.multiply(audio, max_int16, audio)
     return audio
+
+
+def sola(infer_wav: torch.Tensor, sola_buffer: torch.Tensor, fade_in: torch.Tensor, fade_out: torch.Tensor, block_frame: int,
+         search_frame: int):
+    """gui.py:1057-1090 verbatim in torch-CPU (use_pv False).  Returns (out block, new sola_buffer, offset)."""
+    Lb = sola_buffer.numel()
+    infer_wav = infer_wav.clone()
+    conv_input = infer_wav[None, None, : Lb + search_frame]
+    cor_nom = F.conv1d(conv_input, sola_buffer[None, None, :])
+    cor_den = torch.sqrt(F.conv1d(conv_input ** 2, torch.ones(1, 1, Lb)) + 1e-8)
+    sola_offset = int(torch.argmax(cor_nom[0, 0] / cor_den[0, 0]))
+    infer_wav = infer_wav[sola_offset:]
+    infer_wav[:Lb] *= fade_in
+    infer_wav[:Lb] += sola_buffer * fade_out
+    new_buf = infer_wav[block_frame: block_frame + Lb].clone()
+    return infer_wav[:block_frame].clone(), new_buf, sola_offset

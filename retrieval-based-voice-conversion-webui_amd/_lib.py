@@ -98,6 +98,7 @@ SYMBOLS = [
     ("rvcmi_glue_rmvpe_f0", C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("rvcmi_glue_f0_post", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     ("rvcmi_glue_scale_int16_range", C.c_int, [_P, C.c_int64, _P, _P]),
+    ("rvcmi_glue_sola", C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
 ]
 
 

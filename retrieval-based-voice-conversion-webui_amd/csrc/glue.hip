@@ -71,4 +71,25 @@ int rvcmi_glue_scale_int16_range(float* audio, int64_t n, float* scratch256, voi
     });
 }
 
+int rvcmi_glue_sola(const float* infer_wav, int64_t n, float* sola_buffer, int Lb, int Ls, const float* fade_in,
+                    const float* fade_out, int block_frame, float* out_block, int* offset_out, void* stream) {
+    return guarded([&] {
+        if (!infer_wav || !sola_buffer || !fade_in || !fade_out || !out_block || Lb < 1 || Ls < 0 || block_frame < 1)
+            RVCMI_FAIL(RVCMI_ERR_INVALID, "sola: bad argument");
+        if ((int64_t)Ls + block_frame + Lb > n)
+            RVCMI_FAIL(RVCMI_ERR_INVALID, "sola: chunk of %lld samples is shorter than search %d + block %d + buffer %d", (long long)n, Ls,
+                       block_frame, Lb);
+        const size_t smem = (size_t)(2 * Lb + Ls) * sizeof(float);
+        if (smem > 150 * 1024) RVCMI_FAIL(RVCMI_ERR_NOMEM, "sola: buffer + search window too large");
+        static bool attr = false;
+        if (!attr) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sola), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));  // + 2 KB static
+            attr = true;
+        }
+        hipLaunchKernelGGL(k_sola, dim3(1), dim3(256), smem, (hipStream_t)stream, infer_wav, sola_buffer, Lb, Ls, fade_in, fade_out,
+                           block_frame, out_block, offset_out);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 }  // extern "C"

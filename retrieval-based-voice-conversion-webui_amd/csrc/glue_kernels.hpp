@@ -243,4 +243,61 @@ static __global__ void __launch_bounds__(256) k_scale_int16_range(float* __restr
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = __fmul_rn(x[i], sc);
 }
 
+// SOLA (gui.py:1057-1090, "SOLA algorithm from DDSP-SVC"): find the offset in [0, Ls] at which the new chunk best continues
+// the previous chunk's tail (normalised cross-correlation), cut there, cross-fade Lb samples, keep the next tail.
+//   cor_nom[o] = sum_i x[o+i] * buf[i],  cor_den[o] = sqrt(sum_i x[o+i]^2 + 1e-8),  offset = argmax(cor_nom / cor_den)
+//   y = x[offset:];  y[:Lb] = y[:Lb] * fade_in + buf * fade_out;  buf <- y[block : block + Lb];  out <- y[:block]
+// The two sums are accumulated in fp64 and rounded once (the reference's F.conv1d leaves the fp32 summation order to the
+// backend); everything after the argmax is the reference's fp32 expression, unfused.  One block.
+static __global__ void __launch_bounds__(256) k_sola(const float* __restrict__ x, float* __restrict__ buf, int Lb, int Ls,
+                                                     const float* __restrict__ fade_in, const float* __restrict__ fade_out,
+                                                     int block, float* __restrict__ out, int* __restrict__ offset_out) {
+#pragma clang fp contract(off)
+    extern __shared__ float sl[];
+    float* xs = sl;             // [Lb + Ls]
+    float* bs = sl + Lb + Ls;   // [Lb]
+    __shared__ float rv[256];
+    __shared__ int ri[256];
+    for (int i = threadIdx.x; i < Lb + Ls; i += 256) xs[i] = x[i];
+    for (int i = threadIdx.x; i < Lb; i += 256) bs[i] = buf[i];
+    __syncthreads();
+    float best = -INFINITY;
+    int bo = 0;
+    for (int o = threadIdx.x; o <= Ls; o += 256) {
+        double nom = 0.0, en = 0.0;
+        for (int i = 0; i < Lb; ++i) {
+            const double v = (double)xs[o + i];
+            nom += v * (double)bs[i];
+            en += v * v;
+        }
+        const float r = __fdiv_rn((float)nom, sqrtf(__fadd_rn((float)en, 1e-8f)));
+        if (r > best) {
+            best = r;
+            bo = o;
+        }
+    }
+    rv[threadIdx.x] = best;
+    ri[threadIdx.x] = bo;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            const float ov = rv[threadIdx.x + s];
+            const int oi = ri[threadIdx.x + s];
+            if (ov > rv[threadIdx.x] || (ov == rv[threadIdx.x] && oi < ri[threadIdx.x])) {  // torch.argmax: first maximum
+                rv[threadIdx.x] = ov;
+                ri[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int off = ri[0];
+    if (threadIdx.x == 0 && offset_out) *offset_out = off;
+    auto y = [&](int p) {  // the shifted, cross-faded chunk at position p
+        const float v = x[off + p];
+        return p < Lb ? __fadd_rn(__fmul_rn(v, fade_in[p]), __fmul_rn(bs[p], fade_out[p])) : v;
+    };
+    for (int i = threadIdx.x; i < block; i += 256) out[i] = y(i);
+    for (int i = threadIdx.x; i < Lb; i += 256) buf[i] = y(block + i);  // old tail is in LDS: safe to overwrite
+}
+
 }  // namespace rvcmi

@@ -100,3 +100,20 @@ def scale_int16_range(audio: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().rvcmi_glue_scale_int16_range(_ptr(audio), audio.numel(), _ptr(scratch), _stream(dev)))
     return audio
+
+
+def sola(infer_wav: torch.Tensor, sola_buffer: torch.Tensor, fade_in: torch.Tensor, fade_out: torch.Tensor, block_frame: int,
+         search_frame: int, return_offset: bool = False):
+    """The SOLA stitch of gui.py:1057-1090 in one launch: returns the ``block_frame`` output samples and updates
+    ``sola_buffer`` in place (``return_offset=True`` also returns the chosen offset as a 1-element int32 tensor)."""
+    dev = _dev(infer_wav, "infer_wav")
+    for t, nm in ((infer_wav, "infer_wav"), (sola_buffer, "sola_buffer"), (fade_in, "fade_in"), (fade_out, "fade_out")):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+            raise ValueError("%s must be a contiguous float32 tensor on %s" % (nm, dev))
+    Lb = int(sola_buffer.numel())
+    out = torch.empty(int(block_frame), device=dev, dtype=torch.float32)
+    off = torch.empty(1, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().rvcmi_glue_sola(_ptr(infer_wav), infer_wav.numel(), _ptr(sola_buffer), Lb, int(search_frame), _ptr(fade_in),
+                                              _ptr(fade_out), int(block_frame), _ptr(out), _ptr(off), _stream(dev)))
+    return (out, off) if return_offset else out

@@ -89,3 +89,23 @@ def test_glue_rejects_cpu_tensors():
         rvc_amd.glue.f0_post(torch.zeros(4, dtype=torch.float64))
     with pytest.raises(rvc_amd.RvcmiError):
         rvc_amd.glue.retrieve_blend_expand(torch.zeros(1, 4, 8), None, 0.0)
+
+
+@pytest.mark.parametrize("true_off", [0, 137, 400])
+def test_sola_matches_gui_expression(true_off, gpu):
+    """gui.py geometry at 40 kHz: zc 400, block 26 zc, cross-fade buffer 4 zc, search 1 zc, chunk 31 zc."""
+    import rvc_amd
+
+    zc, blk, Lb, Ls = 400, 26 * 400, 4 * 400, 400
+    gen = torch.Generator().manual_seed(true_off)
+    t = torch.arange(31 * zc, dtype=torch.float32)
+    wav = 0.4 * torch.sin(2 * np.pi * 220.0 * t / 40000) + 0.2 * torch.sin(2 * np.pi * 523.0 * t / 40000) + 0.02 * torch.randn(31 * zc, generator=gen)
+    buf = wav[true_off: true_off + Lb].clone() * 0.9 + 0.01 * torch.randn(Lb, generator=gen)  # the previous tail: best match at true_off
+    fade_in = torch.sin(0.5 * np.pi * torch.linspace(0.0, 1.0, Lb)) ** 2  # gui.py:841-855
+    fade_out = 1 - fade_in
+    ref_out, ref_buf, ref_off = glue_oracle.sola(wav, buf, fade_in, fade_out, blk, Ls)
+    assert ref_off == true_off
+    dbuf = buf.to(gpu).clone()
+    out, off = rvc_amd.glue.sola(wav.to(gpu), dbuf, fade_in.to(gpu), fade_out.to(gpu), blk, Ls, return_offset=True)
+    assert int(off.item()) == ref_off
+    assert torch.equal(out.cpu(), ref_out) and torch.equal(dbuf.cpu(), ref_buf)
