@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -135,9 +136,48 @@ def stream_mode(a):
         if i >= 20:
             lat.append(1e3 * (time.perf_counter() - t0))
     lat.sort()
-    print(json.dumps({"metric": "realtime chunk latency p50 (retrieval + NSF decode), v1/40k, 256 ms block", "value": lat[len(lat) // 2],
-                      "unit": "ms", "p90": lat[int(0.9 * len(lat))], "higher_is_better": False, "n_gpus": 1, "dtype": a.operand,
-                      "data": "synthetic", "config": {"workload": "BASELINE configs[4] (hot path only): T=31 frames -> 12400 samples, 16 queries, eager launches"}}))
+    line = {"metric": "realtime chunk latency p50 (retrieval + NSF decode), v1/40k, 256 ms block", "value": lat[len(lat) // 2],
+            "unit": "ms", "p90": lat[int(0.9 * len(lat))], "higher_is_better": False, "n_gpus": 1, "dtype": a.operand,
+            "data": "synthetic", "config": {"workload": "BASELINE configs[4] (hot path only): T=31 frames -> 12400 samples, 16 queries, eager launches"}}
+    if a.operand != "fp32" and a.index_d == 768:
+        # the whole RVC.infer of the realtime loop after HuBERT / f0 (infer/lib/rtrvc.py:163-251, gui.py:1057-1090):
+        # 141 feature rows, retrieval on the last 16 (guarded), x2 -> 282 frames, protect mix, infer(skip_head=250,
+        # return_length=31) = enc_p on 282 frames, flow on the last 56, decoder on 31, then the SOLA stitch.
+        from oracle.front_oracle import FrontConfig
+
+        fcfg = FrontConfig()
+        front = rvc_amd.FrontHIP(vars(fcfg), synth.make_front_weights(fcfg, 1234), device=dev, operand=a.operand, max_B=1, max_T=288)
+        NF, P_LEN, SKIP, RET = 141, 282, 250, 31
+        hub = synth.make_phone(1, NF, 768)[0].to(dev).contiguous()
+        pitchf_all = synth.make_f0(1, P_LEN).to(dev)
+        pitch_all = synth.make_pitch(pitchf_all.cpu()).to(dev)
+        zc, Lb, Ls = cfg.sr // 100, 4 * (cfg.sr // 100), cfg.sr // 100
+        blk = RET * zc - Lb - Ls
+        sola_buf = torch.zeros(Lb, device=dev)
+        fade_in = torch.sin(0.5 * math.pi * torch.linspace(0.0, 1.0, Lb, device=dev)) ** 2
+        fade_out = 1 - fade_in
+        sid_g = gd
+        net = type("N", (), {})()
+        net.emb_g = lambda sid: sid_g.reshape(1, -1)
+        net.dec = gen
+        lat2 = []
+        for i in range(220):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            f = hub.clone()
+            index.search_blend(f[SKIP // 2:], a.index_rate, 8, skip_if_short=True)          # rtrvc.py:167-186
+            ph = rvc_amd.glue.retrieve_blend_expand(f.unsqueeze(0), None, 0.0, pitchf_all, 0.33, P_LEN)   # :221-233 (x2, protect; blend done above)
+            wav = rvc_amd.infer_hip(net, front, ph, None, torch.zeros(1, dtype=torch.long, device=dev), pitch_all, pitchf_all,
+                                    SKIP, RET, RET)[0, 0]                                 # :236-247
+            out = rvc_amd.glue.sola(wav.contiguous(), sola_buf, fade_in, fade_out, blk, Ls)  # gui.py:1057-1090
+            torch.cuda.synchronize()
+            if i >= 20:
+                lat2.append(1e3 * (time.perf_counter() - t0))
+        lat2.sort()
+        assert torch.isfinite(out).all()
+        line["whole_chunk"] = {"what": "retrieval (16 rows, guarded) + x2 + protect + enc_p(282) + flow(56) + decode(31) + SOLA, eager",
+                               "p50_ms": lat2[len(lat2) // 2], "p90_ms": lat2[int(0.9 * len(lat2))]}
+    print(json.dumps(line))
 
 
 def main():
