@@ -210,6 +210,16 @@ typedef struct rvcmi_ivf rvcmi_ivf;
 
 /* faiss.read_index(path)  (pipeline.py:214).  Parses the IwFl/IxF2/ilar on-disk layout.       */
 int rvcmi_ivf_create_from_file(const char* path, int device, rvcmi_ivf** out);
+/* index.train(big_npy) + index.add(big_npy)  (web.py:554-563), on the GPU:
+ *   k-means for the nlist centroids (niter Lloyd iterations from nlist seeded training vectors; every assignment
+ *   is the exact fp64 nearest centroid, computed by the search path's own coarse kernels; empty lists are re-seeded
+ *   by splitting the largest one), then every vector goes to the list of its nearest centroid, ids = row numbers
+ *   in add order.  x_host [n,d] fp32 HOST (what np.load gives).  nprobe = 1 (web.py:552).  objective_out
+ *   (optional, niter+1 doubles) receives the sum of squared distances at every assignment step.
+ *   faiss' own k-means (its RNG, sub-sampling and split heuristics) is not reproduced: retrieval semantics do not
+ *   depend on how the centroids were found, and the reference pins nothing here.                      */
+int rvcmi_ivf_build(int d, int64_t n, const float* x_host, int64_t nlist, int niter, uint64_t seed, int device,
+                    double* objective_out, rvcmi_ivf** out);
 /* faiss.write_index(index, path)  (web.py:571) -- so indices round-trip with stock RVC.       */
 int rvcmi_ivf_write_file(const rvcmi_ivf* h, const char* path);
 

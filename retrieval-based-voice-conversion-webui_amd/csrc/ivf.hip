@@ -510,6 +510,45 @@ __global__ void __launch_bounds__(256) k_blend(float* __restrict__ feats, const 
     }
 }
 
+// ---- index build (web.py:544-563: index.train = k-means for the nlist centroids, index.add = nearest-centroid lists) ----
+// Lloyd update: centroid l <- mean of its members, members in ascending id order, fp64 accumulation (deterministic).
+// One block per list, threads over the dimension.
+__global__ void __launch_bounds__(256) k_list_mean(const float* __restrict__ x, const int64_t* __restrict__ order,
+                                                   const int64_t* __restrict__ off, int d, float* __restrict__ cent) {
+    const int64_t l = blockIdx.x;
+    const int64_t beg = off[l], end = off[l + 1];
+    if (end == beg) return;  // empty list: the host re-seeds it
+    for (int e = threadIdx.x; e < d; e += 256) {
+        double acc = 0.0;
+        for (int64_t i = beg; i < end; ++i) acc += (double)x[order[i] * d + e];
+        cent[l * d + e] = (float)(acc / (double)(end - beg));
+    }
+}
+// squared distance (fp64) of every point to its assigned centroid: the k-means objective, one wave per point
+__global__ void __launch_bounds__(256) k_assigned_dist(const float* __restrict__ x, const float* __restrict__ cent,
+                                                       const int64_t* __restrict__ assign, int64_t n, int d, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float* xp = x + i * d;
+    const float* cp = cent + assign[i] * d;
+    double acc = 0.0;
+    for (int e = lane; e < d; e += 64) {
+        const double t = (double)xp[e] - (double)cp[e];
+        acc += t * t;
+    }
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[i] = acc;
+}
+// vecs[p] = x[order[p]]: the list-major copy of the vectors
+__global__ void __launch_bounds__(256) k_gather_rows(const float* __restrict__ x, const int64_t* __restrict__ order, int64_t n, int d,
+                                                     float* __restrict__ out) {
+    const int64_t p = blockIdx.x;
+    const float4* src = (const float4*)(x + order[p] * d);
+    float4* dst = (float4*)(out + p * d);
+    for (int e = threadIdx.x; e < d / 4; e += 256) dst[e] = src[e];
+}
+
 }  // namespace rvcmi
 
 using namespace rvcmi;
@@ -867,6 +906,122 @@ int rvcmi_ivf_write_file(const rvcmi_ivf* h, const char* path) {
         if (!h || !path) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
         HIP_CHECK(hipSetDevice(h->device));
         write_faiss(h, path);
+    });
+}
+int rvcmi_ivf_build(int d, int64_t n, const float* x_host, int64_t nlist, int niter, uint64_t seed, int device,
+                    double* objective_out, rvcmi_ivf** out) {
+    return guarded([&] {
+        if (!x_host || !out) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        validate(d, n, nlist, 1);
+        if (n < nlist) RVCMI_FAIL(RVCMI_ERR_INVALID, "need at least nlist=%lld training vectors, got %lld", (long long)nlist, (long long)n);
+        if (niter < 0 || niter > 1000) RVCMI_FAIL(RVCMI_ERR_INVALID, "niter out of range");
+        HIP_CHECK(hipSetDevice(device));
+        hipStream_t st = nullptr;
+        DevBuf X, Cd, Cn, Sc, As, Ord, Off, Dist;
+        X.alloc((size_t)n * d * 4);
+        HIP_CHECK(hipMemcpy(X.p, x_host, (size_t)n * d * 4, hipMemcpyHostToDevice));
+        Cd.alloc((size_t)nlist * d * 4);
+        Cn.alloc((size_t)nlist * 4);
+        As.alloc((size_t)n * 8);
+        Ord.alloc((size_t)n * 8);
+        Off.alloc((size_t)(nlist + 1) * 8);
+        Dist.alloc((size_t)n * 8);
+        const int64_t chunk = std::max<int64_t>(64, std::min<int64_t>(n, ((int64_t)512 << 20) / (4 * nlist)));
+        Sc.alloc((size_t)chunk * nlist * 4);
+        // init: nlist distinct training vectors (seeded partial Fisher-Yates), like faiss' random subset initialisation
+        std::vector<float> cent((size_t)nlist * d);
+        {
+            std::vector<int64_t> perm(n);
+            for (int64_t i = 0; i < n; ++i) perm[i] = i;
+            uint64_t sd = seed * 6364136223846793005ULL + 1442695040888963407ULL;
+            for (int64_t i = 0; i < nlist; ++i) {
+                sd ^= sd >> 12; sd ^= sd << 25; sd ^= sd >> 27;  // xorshift64*
+                const uint64_t r = (sd * 2685821657736338717ULL) % (uint64_t)(n - i);
+                std::swap(perm[i], perm[i + (int64_t)r]);
+                memcpy(&cent[(size_t)i * d], x_host + (size_t)perm[i] * d, (size_t)d * 4);
+            }
+        }
+        std::vector<int64_t> assign(n), order(n), off(nlist + 1);
+        std::vector<float> cn(nlist);
+        std::vector<double> dist(n);
+        for (int it = 0; it <= niter; ++it) {
+            double cmax2 = 0.0;
+            for (int64_t c = 0; c < nlist; ++c) {
+                double n2 = 0.0;
+                for (int e = 0; e < d; ++e) n2 += (double)cent[c * d + e] * (double)cent[c * d + e];
+                cn[c] = (float)n2;
+                cmax2 = std::max(cmax2, n2);
+            }
+            HIP_CHECK(hipMemcpyAsync(Cd.p, cent.data(), cent.size() * 4, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(Cn.p, cn.data(), cn.size() * 4, hipMemcpyHostToDevice, st));
+            // exact (fp64-verified) nearest centroid of every training vector: the search path's own coarse kernels
+            for (int64_t qs = 0; qs < n; qs += chunk) {
+                const int64_t nqc = std::min<int64_t>(chunk, n - qs);
+                const float* q = X.as<float>() + qs * d;
+                if (((nlist + 127) / 128) * ((nqc + 63) / 64) >= 512) {
+                    dim3 grid((unsigned)((nlist + 127) / 128), (unsigned)((nqc + 63) / 64));
+                    hipLaunchKernelGGL((k_coarse_gemm<2, 4>), grid, dim3(256), 0, st, q, Cd.as<float>(), Cn.as<float>(), nqc, nlist, d, Sc.as<float>());
+                } else {
+                    dim3 grid((unsigned)((nlist + 31) / 32), (unsigned)((nqc + 31) / 32));
+                    hipLaunchKernelGGL((k_coarse_gemm<1, 1>), grid, dim3(64), 0, st, q, Cd.as<float>(), Cn.as<float>(), nqc, nlist, d, Sc.as<float>());
+                }
+                hipLaunchKernelGGL(k_coarse_pick, dim3((unsigned)((nqc + 3) / 4)), dim3(256), 0, st, q, Cd.as<float>(), Sc.as<float>(), nqc,
+                                   nlist, d, std::sqrt(cmax2), As.as<int64_t>() + qs);
+            }
+            HIP_CHECK(hipGetLastError());
+            if (objective_out) {
+                hipLaunchKernelGGL(k_assigned_dist, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, X.as<float>(), Cd.as<float>(),
+                                   As.as<int64_t>(), n, d, Dist.as<double>());
+                HIP_CHECK(hipMemcpyAsync(dist.data(), Dist.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            }
+            HIP_CHECK(hipMemcpyAsync(assign.data(), As.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (objective_out) {
+                double o = 0.0;
+                for (int64_t i = 0; i < n; ++i) o += dist[i];
+                objective_out[it] = o;
+            }
+            // lists: stable counting sort by centroid => ids ascending inside a list (what sequential index.add produces)
+            std::fill(off.begin(), off.end(), 0);
+            for (int64_t i = 0; i < n; ++i) off[assign[i] + 1]++;
+            for (int64_t l = 0; l < nlist; ++l) off[l + 1] += off[l];
+            {
+                std::vector<int64_t> cur(off.begin(), off.end() - 1);
+                for (int64_t i = 0; i < n; ++i) order[cur[assign[i]]++] = i;
+            }
+            HIP_CHECK(hipMemcpyAsync(Ord.p, order.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(Off.p, off.data(), (size_t)(nlist + 1) * 8, hipMemcpyHostToDevice, st));
+            if (it == niter) break;
+            hipLaunchKernelGGL(k_list_mean, dim3((unsigned)nlist), dim3(256), 0, st, X.as<float>(), Ord.as<int64_t>(), Off.as<int64_t>(), d,
+                               Cd.as<float>());
+            HIP_CHECK(hipMemcpyAsync(cent.data(), Cd.p, cent.size() * 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            // empty lists: split the currently largest one (faiss' split_clusters idea, deterministic choice): copy its
+            // centroid and nudge the two copies apart by 1/1024 in alternating coordinates
+            std::vector<int64_t> sz(nlist);
+            for (int64_t l = 0; l < nlist; ++l) sz[l] = off[l + 1] - off[l];
+            for (int64_t l = 0; l < nlist; ++l) {
+                if (sz[l]) continue;
+                const int64_t big = std::max_element(sz.begin(), sz.end()) - sz.begin();
+                for (int e = 0; e < d; ++e) {
+                    const float v = cent[big * d + e];
+                    const float eps = 1.f / 1024.f;
+                    cent[l * d + e] = (e & 1) ? v * (1.f - eps) : v * (1.f + eps);
+                    cent[big * d + e] = (e & 1) ? v * (1.f + eps) : v * (1.f - eps);
+                }
+                sz[l] = sz[big] / 2;
+                sz[big] -= sz[l];
+            }
+        }
+        // index.add: list-major copy of the vectors, then the packed blob (same layout the reader produces)
+        DevBuf V;
+        V.alloc((size_t)std::max<int64_t>(n, 1) * d * 4);
+        hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)n), dim3(256), 0, st, X.as<float>(), Ord.as<int64_t>(), n, d, V.as<float>());
+        HIP_CHECK(hipGetLastError());
+        std::vector<float> vecs((size_t)n * d);
+        HIP_CHECK(hipMemcpy(vecs.data(), V.p, vecs.size() * 4, hipMemcpyDeviceToHost));
+        auto blob = build_blob(d, n, nlist, 1, cent.data(), off.data(), order.data(), vecs.data());
+        *out = from_host_blob(blob, device);
     });
 }
 int rvcmi_ivf_create(int d, int64_t n, int64_t nlist, int nprobe, const float* centroids, const int64_t* list_offsets,

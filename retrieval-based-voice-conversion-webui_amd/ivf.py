@@ -52,6 +52,26 @@ class IVFFlatHIP:
         return cls(h, dev)
 
     @classmethod
+    def train(cls, big_npy: np.ndarray, nlist: int = None, niter: int = 10, seed: int = 1234, device="cuda:0",
+              return_objective: bool = False):
+        """``index = faiss.index_factory(d, "IVF%s,Flat" % n_ivf); index.train(big_npy); index.add(big_npy)`` (web.py:544-563)
+        on the GPU.  ``nlist`` defaults to the reference's ``min(int(16 * sqrt(N)), N // 39)``; ``nprobe`` is 1 (web.py:552).
+        ids are the row numbers of ``big_npy`` (sequential ``add``)."""
+        dev = _cuda(device)
+        x = np.ascontiguousarray(big_npy, dtype=np.float32)
+        if x.ndim != 2:
+            raise ValueError("big_npy must be [N, d]")
+        n, d = x.shape
+        if nlist is None:
+            nlist = max(1, min(int(16 * np.sqrt(n)), n // 39))
+        obj = np.zeros(int(niter) + 1, dtype=np.float64)
+        h = C.c_void_p(None)
+        _lib.check(_lib.lib().rvcmi_ivf_build(d, n, x.ctypes.data_as(C.c_void_p), int(nlist), int(niter), int(seed), _idx(dev),
+                                              obj.ctypes.data_as(C.c_void_p) if return_objective else C.c_void_p(None), C.byref(h)))
+        idx = cls(h, dev)
+        return (idx, obj) if return_objective else idx
+
+    @classmethod
     def from_blob(cls, blob: torch.Tensor) -> "IVFFlatHIP":
         """Adopt a device blob (uint8 CUDA tensor), e.g. one received by an RCCL broadcast."""
         if blob.dtype != torch.uint8 or blob.device.type != "cuda" or not blob.is_contiguous():
@@ -183,3 +203,11 @@ def _hip_memcpy_d2d(dst: int, src: int, n: int) -> int:
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipMemcpy.restype = C.c_int
     return hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), n, 3)  # hipMemcpyDeviceToDevice
+
+
+def train_index(big_npy: np.ndarray, path: str = None, nlist: int = None, niter: int = 10, seed: int = 1234, device="cuda:0") -> IVFFlatHIP:
+    """The index recipe of web.py:544-571 (``train`` + ``add`` + optional ``write_index``) on the GPU."""
+    idx = IVFFlatHIP.train(big_npy, nlist=nlist, niter=niter, seed=seed, device=device)
+    if path is not None:
+        write_index(idx, path)
+    return idx

@@ -209,3 +209,49 @@ def test_stress_size_ranking_properties(gpu):
         order = np.lexsort((ids[off[l]:off[l + 1]], dd))[:8]
         assert np.array_equal(I[i], ids[off[l]:off[l + 1]][order])
         assert np.array_equal(D[i], dd[order].astype(np.float32))
+
+
+def test_index_build_kmeans_lists_and_roundtrip(gpu, tmp_path):
+    """web.py:544-571 on the GPU: k-means objective never increases, every vector sits in the list of its exact (fp64) nearest
+    centroid with ids ascending inside a list, every centroid is the mean of its list after convergence steps, a vector
+    queried against the built index finds itself, and the written file reads back identically."""
+    import rvc_amd
+
+    rng = np.random.default_rng(3)
+    blobs = rng.standard_normal((40, 256)).astype(np.float32) * 3.0
+    x = (blobs[rng.integers(0, 40, 6000)] + rng.standard_normal((6000, 256)).astype(np.float32)).astype(np.float32)
+    index, obj = rvc_amd.IVFFlatHIP.train(x, niter=8, seed=7, device=gpu, return_objective=True)
+    assert index.ntotal == 6000 and index.d == 256 and index.nprobe == 1
+    assert index.nlist == synth.ivf_nlist(6000)
+    assert np.all(np.diff(obj) <= 1e-6 * obj[:-1]), "k-means objective increased: %s" % obj
+    assert obj[-1] < 0.8 * obj[0]
+    path = str(tmp_path / "built.index")
+    rvc_amd.write_index(index, path)
+    d = ivf_oracle.read_index(path)
+    off, ids, vecs, cent = d["list_offsets"], d["ids"], d["vecs"], d["centroids"]
+    assert sorted(ids.tolist()) == list(range(6000))
+    assert np.array_equal(vecs, x[ids])
+    want = synth.assign_nearest(x, cent)  # exact fp64 argmin, ties -> lowest id
+    got = np.repeat(np.arange(index.nlist), np.diff(off))
+    assert np.array_equal(want[ids], got)
+    for l in range(index.nlist):
+        seg = ids[off[l]:off[l + 1]]
+        assert np.all(np.diff(seg) > 0)
+    D, I = index.search(x[:500], 1)
+    assert np.array_equal(I[:, 0], np.arange(500)) and np.all(D[:, 0] == 0)
+    again = rvc_amd.read_index(path, device=gpu)
+    D2, I2 = again.search(x[100:164], 8)
+    D1, I1 = index.search(x[100:164], 8)
+    assert np.array_equal(I1, I2) and np.array_equal(D1, D2)
+
+
+def test_index_build_handles_empty_lists_and_is_deterministic(gpu):
+    import rvc_amd
+
+    rng = np.random.default_rng(4)
+    x = np.repeat(rng.standard_normal((30, 64)).astype(np.float32), 20, axis=0)  # 600 rows, only 30 distinct: most seeds collide
+    a = rvc_amd.IVFFlatHIP.train(x, nlist=15, niter=5, seed=1, device=gpu)
+    b = rvc_amd.IVFFlatHIP.train(x, nlist=15, niter=5, seed=1, device=gpu)
+    assert torch.equal(a.blob(), b.blob())
+    D, I = a.search(x[::20], 8)
+    assert np.all(D[:, 0] == 0)
