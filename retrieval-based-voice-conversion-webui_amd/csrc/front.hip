@@ -178,7 +178,7 @@ void front_forward_t(rvcmi_front* h, int B, int T, const float* phone, const lon
             a.T = T; a.Tp = Tp; a.H = H; a.ws = c.window_size;
             const double flops = 4.0 * (double)T * T * H * B;
             static unsigned long long* stamps = nullptr;  // dev only
-            if (getenv("RVCMI_FR_STAMPS") && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 64 * 8));
+            if (getenv("RVCMI_FR_STAMPS") && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 256 * 8));
             a.stamps = getenv("RVCMI_FR_STAMPS") ? stamps : nullptr;
             h->prof.launch("enc_attn", flops, 0.0, st, [&] {
                 if (c.window_size <= 10) hipLaunchKernelGGL((k_fr_attn<OpT, 96, 21>), dim3((T + 31) / 32, c.n_heads, B), dim3(256), 0, st, a);

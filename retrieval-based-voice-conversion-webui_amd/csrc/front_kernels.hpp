@@ -547,7 +547,18 @@ static __global__ void __launch_bounds__(256) k_fr_attn(FrAttnArgs a) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) Bq[s] = *(const frag*)(qp + 16 * s);
     }
-    for (int i = threadIdx.x; i < 32 * DK; i += 256) Ev[i] = i < (2 * a.ws + 1) * DK ? a.relv[min(i, (2 * a.ws + 1) * DK - 1)] : 0.f;
+    // relative value table: requested now (unconditional, clamped), parked in registers, written to LDS after the key loop
+    constexpr int EVN = 32 * DK / 256;
+    float evr[EVN];
+    {
+        const int nev = (2 * a.ws + 1) * DK;
+#pragma unroll
+        for (int u = 0; u < EVN; ++u) {
+            const int i = threadIdx.x + u * 256;
+            const float v = a.relv[min(i, nev - 1)];
+            evr[u] = i < nev ? v : 0.f;
+        }
+    }
     for (int i = threadIdx.x; i < 32 * 32; i += 256) Sb[i] = -INFINITY;
     if (wave == 0) {  // R[q][r] = q . E_k[r]
         f32x16 r = {0};
@@ -592,7 +603,8 @@ static __global__ void __launch_bounds__(256) k_fr_attn(FrAttnArgs a) {
         // wave-uniform classification: interior tiles (no relative band, every key and query valid) skip all per-element
         // index work -- on wave64 every VALU instruction costs 4 cycles, and the general path below is ~35 of them per score
         const bool near = (j0 >= q0 - 32 - a.ws) && (j0 <= q0 + 32 + a.ws);
-        const bool plain = !near && j0 + 32 <= len && q0 + 32 <= len;
+        // (query rows >= T of the last tile are never stored, so they do not force the general path when len == T)
+        const bool plain = !near && j0 + 32 <= len && (q0 + 32 <= len || len == T);
         float mx = -INFINITY;
         if (plain) {
 #pragma unroll
@@ -664,6 +676,8 @@ static __global__ void __launch_bounds__(256) k_fr_attn(FrAttnArgs a) {
         }
     }
     FR_STAMP(2);
+#pragma unroll
+    for (int u = 0; u < EVN; ++u) Ev[threadIdx.x + u * 256] = evr[u];
     l_run += __shfl_xor(l_run, 32, 64);
     if (hl == 0) {
         Ml[wave * 32 + ql] = m_run;
