@@ -341,7 +341,7 @@ __device__ __forceinline__ OpT to_op(float v) {
 }
 template <>
 __device__ __forceinline__ _Float16 to_op<_Float16>(float v) {
-    return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+    return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);  // one v_med3_f32 instead of max + min
 }
 
 template <int CIN>

@@ -167,3 +167,41 @@ def test_front_introspection_and_infer_patch_when_reference_is_present():
         assert want[k] == v, k
     with pytest.raises(ValueError):
         rvc_amd.FrontHIP.from_reference(net, device="cuda:0")  # weight norm still attached
+
+
+@pytest.mark.parametrize("name", ["infer_full_v2_48k_T40", "infer_full_v2_48k_rt"])
+def test_infer_hip_orchestration_against_reference_golden_on_cpu(name):
+    """rvc_amd.infer_hip (the replacement of SynthesizerTrnMsNSFsid.infer, synthesizers.py:160-203) driven with oracle-backed
+    stand-ins for the HIP front / generator must reproduce the REFERENCE's net_g.infer waveform: this pins its slicing
+    (flow_head = max(skip_head - 24, 0), dec_head, pitchf window, return_length2 -> n_res) without a GPU."""
+    from conftest import load_golden
+    from oracle import front_oracle, nsf_oracle, synth
+    from oracle.front_oracle import FrontConfig
+
+    d = load_golden(name)
+    cfg, fcfg = nsf_oracle.CONFIGS["v2_48k"], FrontConfig()
+    wd, wf = synth.make_dec_weights(cfg, int(d["seed"])), synth.make_front_weights(fcfg, int(d["seed"]))
+
+    class Front:
+        cfg = {"use_f0": True}
+
+        def __call__(self, phone, pitch, lengths, g, flow_head=0, *, noise=None):
+            sid = torch.tensor([int(d["sid"][0])])
+            z, m1, _ = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, noise, flow_head if flow_head else None)
+            return z * m1
+
+    class Net:
+        emb_g = staticmethod(lambda sid: wf["emb_g.weight"][sid])
+
+        @staticmethod
+        def dec(z, pitchf, g=None, n_res=None, noise=None):
+            return nsf_oracle.generator_forward(cfg, wd, z, pitchf, g, noise, n_res=n_res)
+
+    T = d["phone"].shape[1]
+    opt = lambda k: None if int(d[k]) < 0 else int(d[k])
+    with torch.no_grad():
+        out = rvc_amd.infer_hip(Net(), Front(), torch.from_numpy(d["phone"]), torch.tensor([T]), torch.from_numpy(d["sid"]),
+                                torch.from_numpy(d["pitch"]), torch.from_numpy(d["pitchf"]), opt("skip_head"), opt("return_length"),
+                                opt("return_length2"), noise_zp=torch.from_numpy(d["noise_zp"]), noise_dec=torch.from_numpy(d["noise_dec"]))
+    assert out.shape == d["out"].shape
+    assert np.abs(out.numpy() - d["out"]).max() < 2e-5
