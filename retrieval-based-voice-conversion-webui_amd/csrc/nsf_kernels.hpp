@@ -779,7 +779,10 @@ static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArg
 
     // ---- 1. stage lrelu(x) -> OpT tile.  SB independent 32-byte loads in flight per thread (the accumulators are
     //         not live yet); clamped addresses keep every load unconditional (no exec-masked block per load).
-    constexpr int SB = 8;
+#ifndef RB_SB
+#define RB_SB 12  // 188-row tiles are 23.5 chunks per thread: two batches of 12 (three of 8 cost one more HBM round trip)
+#endif
+    constexpr int SB = RB_SB;
     const int total = xrows * C8;
     for (int base = threadIdx.x; base < total; base += SB * NT) {
         float4 lo[SB], hi[SB];
