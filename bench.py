@@ -9,6 +9,11 @@ A "step" = one pass of the hot path over one batch of B clips per rank: 599 HuBE
 clip through search(k=8)+blend against the index, then the generator on T=1198 frames (what a 10 s
 clip costs inside the pipeline with x_pad=1).  Inputs are resident in HBM before
 the timed region.  Rank 0 prints ONE JSON line.
+
+What is imported from ``oracle/`` and why: ``oracle.synth`` / the config dataclasses only GENERATE the seeded synthetic
+weights, features, f0 and index (no checkpoints or datasets exist offline); nothing under ``oracle/`` executes inside a
+timed region except in the ``cpu_baseline`` leg, which times the CPU restatement itself.  Every timed step calls the
+HIP library through ``rvc_amd`` only.
 """
 from __future__ import annotations
 
