@@ -415,6 +415,7 @@ def main():
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
     if use_dist:
+        dist.barrier()  # the other ranks wait for rank 0's untimed roofline / whole-infer legs before tearing RCCL down
         dist.destroy_process_group()
 
 
