@@ -404,23 +404,25 @@ static void set_lds_rb() {
 }
 
 template <typename OpT, int CIN, int MI, int WV>
-static void launch_ups_inst(const UpsArgs& a, int B, hipStream_t st) {
-    constexpr int TQ = 32 * 4 * (4 / WV);
+static void launch_ups_inst(const UpsArgs& a, int nj, int B, hipStream_t st) {
+    const int TQ = 32 * nj * (4 / WV);
     const size_t smem = (size_t)a.tile_rows * Tile<CIN>::STRIDE + (a.nz_k1 ? (size_t)(TQ * a.u * a.ns + 16) * 2 : 0);
     if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "upsampler LDS tile too large (%zu B)", smem);
     const int per_block = WV * a.vpw;
     dim3 grid((a.Lin + TQ - 1) / TQ, (a.nvt + per_block - 1) / per_block, B);
-    hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV>), grid, dim3(256), smem, st, a);
+    if (nj == 4) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 4>), grid, dim3(256), smem, st, a);
+    else if (nj == 2) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 2>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 1>), grid, dim3(256), smem, st, a);
 }
 #define RVCMI_UPS_CASES(X, OpT) \
     X(OpT, 512, 2) X(OpT, 256, 2) X(OpT, 128, 2) X(OpT, 64, 1) X(OpT, 32, 1)
 template <typename OpT>
-static void launch_ups_t(const UpsArgs& a, int wv, int B, hipStream_t st) {
+static void launch_ups_t(const UpsArgs& a, int wv, int nj, int B, hipStream_t st) {
 #define X(OpT_, CIN_, MI_)                                                        \
     if (a.cin == CIN_) {                                                          \
-        if (wv == 4) return launch_ups_inst<OpT_, CIN_, MI_, 4>(a, B, st);        \
-        if (wv == 2) return launch_ups_inst<OpT_, CIN_, MI_, 2>(a, B, st);        \
-        return launch_ups_inst<OpT_, CIN_, MI_, 1>(a, B, st);                     \
+        if (wv == 4) return launch_ups_inst<OpT_, CIN_, MI_, 4>(a, nj, B, st);    \
+        if (wv == 2) return launch_ups_inst<OpT_, CIN_, MI_, 2>(a, nj, B, st);    \
+        return launch_ups_inst<OpT_, CIN_, MI_, 1>(a, nj, B, st);                 \
     }
     RVCMI_UPS_CASES(X, OpT)
 #undef X
@@ -428,14 +430,14 @@ static void launch_ups_t(const UpsArgs& a, int wv, int B, hipStream_t st) {
 }
 template <typename OpT>
 static void set_lds_ups() {
-#define X(OpT_, CIN_, MI_)                                                                                              \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ups<OpT_, CIN_, MI_, 4>),                             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                             \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ups<OpT_, CIN_, MI_, 2>),                             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                             \
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ups<OpT_, CIN_, MI_, 1>),                             \
+#define Y(OpT_, CIN_, MI_, WV_, NJ_)                                                                                    \
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ups<OpT_, CIN_, MI_, WV_, NJ_>),                      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define X(OpT_, CIN_, MI_)                                                                                              \
+    Y(OpT_, CIN_, MI_, 4, 4) Y(OpT_, CIN_, MI_, 4, 2) Y(OpT_, CIN_, MI_, 4, 1) Y(OpT_, CIN_, MI_, 2, 4) Y(OpT_, CIN_, MI_, 2, 2)   \
+    Y(OpT_, CIN_, MI_, 2, 1) Y(OpT_, CIN_, MI_, 1, 4) Y(OpT_, CIN_, MI_, 1, 2) Y(OpT_, CIN_, MI_, 1, 1)
     RVCMI_UPS_CASES(X, OpT)
+#undef Y
 #undef X
 }
 
@@ -754,7 +756,18 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             ua.cog = (C + 32 * MIu - 1) / (32 * MIu);
             ua.nvt = s.u * ua.cog;
             const int wv = ua.nvt >= 4 ? 4 : (ua.nvt >= 2 ? 2 : 1);
-            const int TQ = 128 * (4 / wv);
+            // time-tile height: blocks have equal duration, so a launch of ~1.1 x (resident blocks) runs two rounds for one
+            // round of work; pick the largest tile that still gives >= 4 rounds of blocks (2 resident blocks per CU)
+            // (measured at B = 1, same box, us: C_in 512: 52 / 36 / 37 for NJ 4 / 2 / 1; 256: 94 / 95 / 85; 128: 131 / 118 / 110;
+            //  64 -> 32 channels: 98 / 102 / 150 -- with one 32-channel tile per wave, short tiles starve the MFMA of columns)
+            int nj = 4;
+            const long blocks4 = (long)((Lin + 128 * (4 / wv) - 1) / (128 * (4 / wv))) * B;
+            if (blocks4 < 2048 && s.cin >= 128) nj = s.cin >= 512 ? 2 : 1;
+            if (const char* e = getenv("RVCMI_UPS_NJ")) {
+                const int v = atoi(e);
+                if (v == 1 || v == 2 || v == 4) nj = v;
+            }
+            const int TQ = 32 * nj * (4 / wv);
             ua.tile_rows = TQ + (hi - lo);
             const long qtiles = (Lin + TQ - 1) / TQ;
             int vpw = (ua.nvt + wv - 1) / wv;  // everything in one block ...
@@ -764,8 +777,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             const double flops = U.flops_per_pos * (double)Lin * B + 2.0 * s.nk * (double)L * C * B;
             const double bytes = (double)B * Lin * Cprev * 4 * (y[1] ? (y[2] ? 3 : 2) : 1) + (double)B * L * C * 4;
             h->prof.launch(nm, flops, bytes, st, [&] {
-                if (op == RVCMI_OPERAND_BF16) launch_ups_t<__bf16>(ua, wv, B, st);
-                else launch_ups_t<_Float16>(ua, wv, B, st);
+                if (op == RVCMI_OPERAND_BF16) launch_ups_t<__bf16>(ua, wv, nj, B, st);
+                else launch_ups_t<_Float16>(ua, wv, nj, B, st);
             });
             HIP_CHECK(hipGetLastError());
         }

@@ -242,7 +242,7 @@ static __global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x,
 // out[b][t] = tanh(sum_{j,ci} lrelu(x[t-3+j][ci], 0.01) * Wp[j][ci]),  x = ((xa + xb) + xc) / div   (nsf.py:186-189)
 // HBM-bound: the last stage is read exactly once with coalesced float4 loads into an LDS tile whose
 // row stride C+1 makes the per-thread row walk conflict-free.
-constexpr int POST_TT = 256;
+constexpr int POST_TT = 256;  // = blockDim: one output sample per thread (a 128-row tile measured no faster)
 static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ xa, const float* __restrict__ xb,
                                               const float* __restrict__ xc, const float* __restrict__ Wp /*[7][C]*/,
                                               float* __restrict__ out, int L, int C, float div) {
@@ -945,13 +945,12 @@ struct UpsArgs {
     int dbg;  // timing ablations only: 1 skip staging loads, 2 skip MFMA, 4 skip noise conv, 16 skip store
 };
 
-template <typename OpT, int CIN, int MI, int WV>
+template <typename OpT, int CIN, int MI, int WV, int NJ = 4>
 static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks per CU: one block stages / stores while the other multiplies
     using TL = Tile<CIN>;
     using frag = typename Op<OpT>::frag;
     constexpr int STRIDE = TL::STRIDE;
     constexpr int C8 = CIN / 8;
-    constexpr int NJ = 4;
     constexpr int WT = 4 / WV;
     constexpr int TQ = 32 * NJ * WT;
     constexpr int SB = 8;  // independent chunk loads (x up to 3 inputs) in flight per thread; the accumulators are not live yet
