@@ -392,45 +392,53 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
 // Specialised scan for d = 64*V (V = 12 for the 768-d v2 index, 4 for the 256-d v1 index): the query chunk of each
 // lane lives in registers, every load of TWO rows is in flight before anything is consumed (one memory round trip per
 // pair of rows instead of three per row), row indices are clamped so no load sits behind a branch.
-template <int V>
+// Specialised scan: d = LPR * 4 * VL, LPR lanes per row (16 or 32), G = 256 / LPR row groups, RU rows in flight per group.
+// d = 768 uses 32 lanes per row: with 16 (48 floats of query + 96 of rows + fp64 temporaries per lane) the kernel needed
+// 345 registers, ran one block per CU and turned the clip's 599 query blocks into three serial rounds of HBM-latency-bound
+// work; at 32 lanes per row every block of the launch is resident at once.
+template <int VL, int LPR, int RU>
 __global__ void __launch_bounds__(256) k_scan_v(const float* __restrict__ q, const int64_t* __restrict__ assign, int nprobe,
-                                                const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
-                                                const float* __restrict__ vecs, int64_t nq, int k, float* __restrict__ D,
-                                                int64_t* __restrict__ I, int64_t* __restrict__ P, int* __restrict__ any_short) {
-    constexpr int d = 64 * V;
-    constexpr int RU = 2;
+                                                   const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
+                                                   const float* __restrict__ vecs, int64_t nq, int k, float* __restrict__ D,
+                                                   int64_t* __restrict__ I, int64_t* __restrict__ P, int* __restrict__ any_short) {
+    constexpr int d = LPR * 4 * VL;
+    constexpr int G = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     TopK* merge = (TopK*)smem_raw;
     const int64_t qi = blockIdx.x;
-    const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
-    float4 qv[V];
+    const int grp = threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    float4 qv[VL];
 #pragma unroll
-    for (int i = 0; i < V; ++i) qv[i] = *(const float4*)(q + qi * d + (sub + 16 * i) * 4);
-    TopK t;
+    for (int i = 0; i < VL; ++i) qv[i] = *(const float4*)(q + qi * d + (sub + LPR * i) * 4);
+    // the group's running top-8 lives in LDS and is maintained by the group's first lane: keeping it in registers (48 per
+    // lane, all lanes) plus the unrolled compare-swap network cost ~100 VGPRs; a list has only 2-3 rows per group
+    TopK& t = merge[grp];
+    if (sub == 0) {
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) { t.d[s] = INFINITY; t.id[s] = INT64_MAX; t.pos[s] = -1; }
+        for (int s = 0; s < KMAX; ++s) { t.d[s] = INFINITY; t.id[s] = INT64_MAX; t.pos[s] = -1; }
+    }
     for (int p = 0; p < nprobe; ++p) {
         const int64_t l = assign[qi * nprobe + p];
         if (l < 0) continue;
         const int64_t beg = list_off[l], end = list_off[l + 1];
         if (end <= beg) continue;
-        for (int64_t r0 = beg + grp; r0 < end; r0 += SCAN_GROUPS * RU) {
-            float4 v[RU][V];
+        for (int64_t r0 = beg + grp; r0 < end; r0 += G * RU) {
+            float4 v[RU][VL];
             int64_t rr[RU], idv[RU];
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
-                rr[u] = r0 + u * SCAN_GROUPS;
+                rr[u] = r0 + u * G;
                 const int64_t rc = rr[u] < end ? rr[u] : end - 1;  // clamped: loads stay unconditional
                 const float4* row = (const float4*)(vecs + rc * d);
 #pragma unroll
-                for (int i = 0; i < V; ++i) v[u][i] = row[sub + 16 * i];
+                for (int i = 0; i < VL; ++i) v[u][i] = row[sub + LPR * i];
                 idv[u] = ids[rc];
             }
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 double acc = 0.0;
 #pragma unroll
-                for (int i = 0; i < V; ++i) {
+                for (int i = 0; i < VL; ++i) {
                     const double t0 = (double)qv[i].x - (double)v[u][i].x, t1 = (double)qv[i].y - (double)v[u][i].y;
                     const double t2 = (double)qv[i].z - (double)v[u][i].z, t3 = (double)qv[i].w - (double)v[u][i].w;
                     acc = fma(t0, t0, acc);
@@ -438,20 +446,30 @@ __global__ void __launch_bounds__(256) k_scan_v(const float* __restrict__ q, con
                     acc = fma(t2, t2, acc);
                     acc = fma(t3, t3, acc);
                 }
-                for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-                if (rr[u] < end) topk_insert(t, acc, idv[u], rr[u]);
+                for (int off = LPR / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                if (sub == 0 && rr[u] < end && before(acc, idv[u], t.d[KMAX - 1], t.id[KMAX - 1])) {
+                    int s = KMAX - 1;  // insertion into the sorted LDS list
+                    while (s > 0 && before(acc, idv[u], t.d[s - 1], t.id[s - 1])) {
+                        t.d[s] = t.d[s - 1];
+                        t.id[s] = t.id[s - 1];
+                        t.pos[s] = t.pos[s - 1];
+                        --s;
+                    }
+                    t.d[s] = acc;
+                    t.id[s] = idv[u];
+                    t.pos[s] = rr[u];
+                }
             }
         }
     }
-    if (sub == 0) merge[grp] = t;
     __syncthreads();
-    if (threadIdx.x < SCAN_GROUPS * KMAX) {
+    if (threadIdx.x < G * KMAX) {
         const int me = threadIdx.x;
         const int mg = me / KMAX, ms = me % KMAX;
         const double md = merge[mg].d[ms];
         const int64_t mid = merge[mg].id[ms];
         int rank = 0;
-        for (int o = 0; o < SCAN_GROUPS * KMAX; ++o) {
+        for (int o = 0; o < G * KMAX; ++o) {
             const double od = merge[o / KMAX].d[o % KMAX];
             const int64_t oid = merge[o / KMAX].id[o % KMAX];
             rank += (od < md || (od == md && (oid < mid || (oid == mid && o < me)))) ? 1 : 0;
@@ -875,12 +893,12 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
     h->prof.launch("ivf_scan", 3.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
         const size_t sm2 = SCAN_GROUPS * sizeof(TopK);
         if (d == 768 && !getenv("RVCMI_IVF_GENERIC")) {
-            hipLaunchKernelGGL(k_scan_v<12>, dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
+            hipLaunchKernelGGL((k_scan_v<6, 32, 2>), dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
                                h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>());
             return;
         }
         if (d == 256 && !getenv("RVCMI_IVF_GENERIC")) {
-            hipLaunchKernelGGL(k_scan_v<4>, dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
+            hipLaunchKernelGGL((k_scan_v<4, 16, 2>), dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
                                h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>());
             return;
         }
