@@ -247,15 +247,15 @@ def glue_case(name: str = "glue_f0"):
     out = {}
     rng = np.random.default_rng(2024)
     cases = {
-        "mixed": (300, 310, 0), "up": (150, 300, 7), "down": (257, 129, -5), "lead_unvoiced": (64, 64, 12),
-        "tail_unvoiced": (80, 90, 0), "last_voiced_only_end": (40, 40, 3), "all_unvoiced": (33, 40, 0), "single": (1, 3, 0),
+        "mixed": (120, 130, 0), "up": (75, 150, 7), "down": (129, 65, -5), "lead_unvoiced": (48, 48, 12),
+        "tail_unvoiced": (60, 66, 0), "last_voiced_only_end": (40, 40, 3), "all_unvoiced": (33, 40, 0), "single": (1, 3, 0),
     }
     fp = F0Predictor()
     for cname, (n, p_len, key) in cases.items():
         sal = (rng.random((n, 360), dtype=np.float32) * 0.02).astype(np.float32)
         voiced = np.ones(n, bool)
         if cname == "mixed":
-            voiced[(np.arange(n) % 50) < 12] = False
+            voiced[(np.arange(n) % 40) < 11] = False
         elif cname == "lead_unvoiced":
             voiced[:20] = False
         elif cname == "tail_unvoiced":
