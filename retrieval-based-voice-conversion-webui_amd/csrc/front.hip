@@ -38,7 +38,7 @@ struct rvcmi_front {
     std::vector<FlowLayer> flows;
     DevBuf cond_w, cond_b;  // all flows' cond_layer concatenated: [n_flows * 2H * n_layers][gin]
     // workspace
-    DevBuf X, QK, KF, VT, A, F, ZP, Ha, Hb, SK, GC;  // QK: q [B][T][H]; KF / VT: k / v tiles in fragment order
+    DevBuf X, X2, QK, KF, VT, A, F, ZP, Ha, Hb, SK, GC;  // QK: q [B][T][H]; KF / VT: k / v tiles in fragment order
     size_t ws_bytes = 0;
     Profiler prof;
 };
@@ -59,7 +59,13 @@ const float* wdata(const WeightMap& wm, const std::string& name, std::initialize
 
 // Time-tile height: 64 rows (NJ = 2) when that still gives every CU a block, else 32 rows -- at B = 1 a 10 s clip is
 // only 38 tiles of 32 frames, and one tile's MFMA work on one CU is the latency floor of a launch.
-static int pick_nj(int B, int T) { return (long)B * ((T + 63) / 64) >= 192 ? 2 : 1; }
+static int pick_nj(int B, int T) {
+    if (const char* e = getenv("RVCMI_FR_NJ")) {  // tests force the large-batch tile height on small inputs
+        const int v = atoi(e);
+        if (v == 1 || v == 2) return v;
+    }
+    return (long)B * ((T + 63) / 64) >= 192 ? 2 : 1;
+}
 
 template <typename OpT, int CIN, int MI, int NW, int EPI, int NJ>
 void launch_conv_nj(rvcmi_front* h, const char* name, FrConvArgs a, const ConvLayer& L, int B, hipStream_t st) {
@@ -133,6 +139,37 @@ void launch_wn(rvcmi_front* h, const FrWnArgs& a, const ConvLayer& Lin, const Co
     else launch_wn_nj<OpT, LAST, 2>(h, a, Lin, Lrs, B, st);
 }
 
+template <typename OpT, int NJ1>
+void launch_ffn_nj(rvcmi_front* h, FrFfnArgs a, const ConvLayer& L1, const ConvLayer& L2, int B, hipStream_t st) {
+    constexpr int H = 192, F = 768;
+    a.w1 = L1.w_pack.p;
+    a.ct1 = L1.ct_stride;
+    a.b1 = L1.bias.as<float>();
+    a.w2 = L2.w_pack.p;
+    a.ct2 = L2.ct_stride;
+    a.b2 = L2.bias.as<float>();
+    a.ntaps = L1.ntaps[0];
+    constexpr int HR = 32 * NJ1;
+    const int TV = HR - (a.ntaps - 1);
+    const size_t smem = (size_t)(HR + a.ntaps - 1 + 2) * Tile<H>::STRIDE + (size_t)(HR + a.ntaps - 1 + 2) * Tile<F>::STRIDE;
+    auto kern = k_fr_ffn<OpT, H, F, NJ1>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const double flops = (L1.flops_per_pos + L2.flops_per_pos) * (double)a.T * B;
+    h->prof.launch("enc_ffn_ln", flops, 0.0, st, [&] {
+        hipLaunchKernelGGL(kern, dim3((a.T + TV - 1) / TV, B), dim3(64 * (H / 32)), smem, st, a);
+    });
+    HIP_CHECK(hipGetLastError());
+}
+template <typename OpT>
+void launch_ffn(rvcmi_front* h, const FrFfnArgs& a, const ConvLayer& L1, const ConvLayer& L2, int B, hipStream_t st) {
+    if (pick_nj(B, a.T) == 1) launch_ffn_nj<OpT, 1>(h, a, L1, L2, B, st);
+    else launch_ffn_nj<OpT, 2>(h, a, L1, L2, B, st);
+}
+
 void tap_copy(TapReq* tr, const char* what, const float* dev, int B, int T, int C, hipStream_t st) {
     if (!tr || tr->done || tr->what != what) return;
     const size_t n = (size_t)B * T * C;
@@ -153,6 +190,7 @@ void front_forward_t(rvcmi_front* h, int B, int T, const float* phone, const lon
     const int T2 = T - fh;
     const int Tp = h->Tp;
     float* X = h->X.as<float>();
+    float* X2 = h->X2.as<float>();  // the fused FFN writes the other buffer (its tiles read a halo of X)
     // ---- TextEncoder (encoders.py:134-159) ----
     {
         FrConvArgs a = {};
@@ -203,19 +241,30 @@ void front_forward_t(rvcmi_front* h, int B, int T, const float* phone, const lon
             if (i == 0) tap_copy(tr, "attn0", X, B, T, H, st);
             if (tr && tr->done) return;
         }
-        {
-            FrConvArgs a = {};
-            a.in = X; a.in_bstride = (long)T * H; a.T = T; a.len = lengths; a.premask = 1; a.pad = (c.kernel_size - 1) / 2;
-            a.out_op = h->F.p; a.out_op_bstride = (long)T * c.filter_channels;
-            launch_conv<OpT, H, 1, 6, FR_RELU_OP>(h, "enc_ffn1", a, L.f1, B, st);
+        if (c.kernel_size <= 5 && !getenv("RVCMI_FR_NO_FFN_FUSION")) {
+            // FFN + residual + LayerNorm in one launch; reads X (with a halo) and writes the other stream buffer
+            FrFfnArgs a = {};
+            a.x = X; a.xo = X2; a.bstride = (long)T * H; a.T = T; a.len = lengths;
+            a.gamma = L.g2.as<float>(); a.beta = L.b2.as<float>();
+            launch_ffn<OpT>(h, a, L.f1, L.f2, B, st);
+            std::swap(X, X2);
+        } else {
+            {
+                FrConvArgs a = {};
+                a.in = X; a.in_bstride = (long)T * H; a.T = T; a.len = lengths; a.premask = 1; a.pad = (c.kernel_size - 1) / 2;
+                a.out_op = h->F.p; a.out_op_bstride = (long)T * c.filter_channels;
+                launch_conv<OpT, H, 1, 6, FR_RELU_OP>(h, "enc_ffn1", a, L.f1, B, st);
+            }
+            {
+                FrConvArgs a = {};
+                a.in = h->F.p; a.in_op = 1; a.in_bstride = (long)T * c.filter_channels; a.T = T; a.len = lengths;
+                a.pad = (c.kernel_size - 1) / 2; a.postmask = 1;
+                a.out = X; a.out_bstride = (long)T * H; a.out_C = H; a.res = X;
+                a.gamma = L.g2.as<float>(); a.beta = L.b2.as<float>();
+                launch_conv<OpT, 768, 1, 6, FR_RES_LN>(h, "enc_ffn2_ln", a, L.f2, B, st);
+            }
         }
         {
-            FrConvArgs a = {};
-            a.in = h->F.p; a.in_op = 1; a.in_bstride = (long)T * c.filter_channels; a.T = T; a.len = lengths;
-            a.pad = (c.kernel_size - 1) / 2; a.postmask = 1;
-            a.out = X; a.out_bstride = (long)T * H; a.out_C = H; a.res = X;
-            a.gamma = L.g2.as<float>(); a.beta = L.b2.as<float>();
-            launch_conv<OpT, 768, 1, 6, FR_RES_LN>(h, "enc_ffn2_ln", a, L.f2, B, st);
             char nm[32];
             snprintf(nm, sizeof(nm), "layer%d", i);
             tap_copy(tr, nm, X, B, T, H, st);
@@ -452,6 +501,7 @@ rvcmi_front* front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* wei
         ws += bytes;
     };
     A(h->X, BT * H * 4);
+    A(h->X2, BT * H * 4);
     A(h->QK, BT * H * 2);
     A(h->KF, (size_t)max_B * H * h->Tp * 2);
     A(h->VT, (size_t)max_B * H * h->Tp * 2);

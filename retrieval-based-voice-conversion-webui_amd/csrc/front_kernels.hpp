@@ -733,6 +733,180 @@ static __global__ void __launch_bounds__(256) k_fr_attn(FrAttnArgs a) {
 #undef FR_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------
+// FFN (attentions.py:262-272) + residual + LayerNorm (encoders.py:78-80) in ONE launch:
+//   conv_1 (k taps, H -> F) -> relu -> * mask -> LDS (fp16, F channels x 32*NJ1 rows) -> conv_2 (k taps, F -> H) -> * mask
+//   -> + x -> LayerNorm.  The hidden activation never leaves the CU.  Tiles are "overlap-save" in time: a block computes
+//   32*NJ1 hidden rows and from them 32*NJ1 - (k-1) output rows (6 % redundant conv_1 work at NJ1 = 1, k = 3).
+// Reads x with a halo and writes another buffer (xo): in place would race with the neighbouring tiles' halo reads.
+// ------------------------------------------------------------------------------------------------
+struct FrFfnArgs {
+    const float* x;     // [B][T][H] fp32
+    float* xo;          // [B][T][H] fp32 (different buffer)
+    long bstride;
+    int T;
+    const long long* len;
+    const void* w1;     // packed conv_1
+    long ct1;
+    const float* b1;
+    const void* w2;     // packed conv_2
+    long ct2;
+    const float* b2;
+    int ntaps;          // kernel size (odd)
+    const float* gamma;
+    const float* beta;
+};
+
+template <typename OpT, int H, int F, int NJ1>
+static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_ffn(FrFfnArgs a) {
+    using TLH = Tile<H>;
+    using TLF = Tile<F>;
+    using o4 = __attribute__((ext_vector_type(4))) OpT;
+    constexpr int NW = H / 32;
+    constexpr int NT = 64 * NW;
+    constexpr int HR = 32 * NJ1;                 // hidden rows per block
+    constexpr int FT = F / 32 / NW;              // hidden-channel tiles per wave (4)
+    static_assert(F % (32 * NW) == 0 && FT % 2 == 0, "hidden channels must split into pairs of tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y;
+    const int pad = (a.ntaps - 1) / 2;
+    const int TV = HR - 2 * pad;                 // valid output rows per block
+    const int q0 = blockIdx.x * TV;              // first output row
+    const int h0 = q0 - pad;                     // global row of hidden row 0
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hl = lane >> 5;
+    const int xrows = HR + a.ntaps - 1 + 2;
+    char* XS = smem;                                          // x operand tile, rows h0 - pad ...
+    char* HS = smem + (size_t)xrows * TLH::STRIDE;            // hidden tile [HR + ntaps - 1 + 2][F]
+    const long boff = (long)b * a.bstride;
+    const long long lenb = a.len ? a.len[b] : (long long)a.T;
+    const int lenrow = (int)(lenb < (long long)a.T ? lenb : (long long)a.T);
+
+    // conv_1 weights of this wave's first tile pair, then the x tile (x * x_mask: rows >= len are zero)
+    const OpT* w1lane = (const OpT*)a.w1 + (size_t)(wave * FT) * a.ct1 + lane * 8;
+    typename Op<OpT>::frag Aw[FR_NB][KGROUP][2];
+    conv_prefetch<OpT, H, 2, KGROUP, FR_NB>(Aw, w1lane, a.ct1, a.ntaps);
+    // epilogue operands of the LayerNorm, requested early
+    const int cb = wave * 32 + 4 * hl;
+    int tt[NJ1], tcl[NJ1];
+    f32x4 rv[NJ1][4], bv2[4], ga[4], be[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bv2[g] = *(const f32x4*)(a.b2 + cb + 8 * g);
+        ga[g] = *(const f32x4*)(a.gamma + cb + 8 * g);
+        be[g] = *(const f32x4*)(a.beta + cb + 8 * g);
+    }
+#pragma unroll
+    for (int jt = 0; jt < NJ1; ++jt) {
+        tt[jt] = q0 + jt * 32 + (lane & 31);
+        tcl[jt] = min(tt[jt], a.T - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rv[jt][g] = *(const f32x4*)(a.x + boff + (size_t)tcl[jt] * H + cb + 8 * g);
+    }
+    fr_stage<OpT, H, NT>(XS, a.x, 0, boff, a.T, h0 - pad, xrows, lenrow);
+    // rows of the hidden tile past HR (read by conv_2's look-ahead and by the discarded last output rows) must be finite
+    for (int i = threadIdx.x; i < (a.ntaps - 1 + 2) * (TLF::STRIDE / 4); i += NT) ((unsigned*)(HS + (size_t)HR * TLF::STRIDE))[i] = 0u;
+    __syncthreads();
+
+    // ---- conv_1 + relu + mask -> hidden tile, two output-channel tiles at a time ----
+    const char* x_lane = XS + (size_t)(lane & 31) * TLH::STRIDE + hl * 16;
+#pragma unroll 1
+    for (int pass = 0; pass < FT / 2; ++pass) {
+        const int ct = wave * FT + 2 * pass;
+        const OpT* wl = (const OpT*)a.w1 + (size_t)ct * a.ct1 + lane * 8;
+        if (pass > 0) conv_prefetch<OpT, H, 2, KGROUP, FR_NB>(Aw, wl, a.ct1, a.ntaps);
+        f32x16 acc[2][NJ1];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int jt = 0; jt < NJ1; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
+        conv_run<OpT, H, 2, NJ1, KGROUP, FR_NB>(acc, Aw, x_lane, wl, a.ct1, a.ntaps, 0, 1);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = (ct + mi) * 32 + 8 * g + 4 * hl;
+                const f32x4 bb = *(const f32x4*)(a.b1 + c);
+#pragma unroll
+                for (int jt = 0; jt < NJ1; ++jt) {
+                    const int hr = jt * 32 + (lane & 31);
+                    const int t = h0 + hr;
+                    const float mk = (t >= 0 && t < lenrow) ? 1.f : 0.f;  // zero padding of conv_2 and x_mask in one
+                    o4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(fmaxf(acc[mi][jt][4 * g + e] + bb[e], 0.f) * mk);
+                    *(o4*)(HS + (size_t)hr * TLF::STRIDE + c * 2) = o;
+                }
+            }
+    }
+    // ---- conv_2 over the hidden tile ----
+    const OpT* w2lane = (const OpT*)a.w2 + (size_t)wave * a.ct2 + lane * 8;
+    typename Op<OpT>::frag Aw2[FR_NB][KGROUP][1];
+    conv_prefetch<OpT, F, 1, KGROUP, FR_NB>(Aw2, w2lane, a.ct2, a.ntaps);
+    __syncthreads();
+    f32x16 acc2[1][NJ1];
+#pragma unroll
+    for (int jt = 0; jt < NJ1; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[0][jt][e] = 0.f;
+    const char* h_lane = HS + (size_t)(lane & 31) * TLF::STRIDE + hl * 16;
+    conv_run<OpT, F, 1, NJ1, KGROUP, FR_NB>(acc2, Aw2, h_lane, w2lane, a.ct2, a.ntaps, 0, 1);
+
+    // ---- (* mask) + x -> LayerNorm over the H channels (statistics through LDS, two passes) ----
+    __syncthreads();  // x tile is dead
+    float* red = (float*)XS;  // [2][NW][HR]
+    float v[NJ1][16];
+#pragma unroll
+    for (int jt = 0; jt < NJ1; ++jt) {
+        const float pm = (long long)tcl[jt] < lenb ? 1.f : 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[jt][4 * g + e] = rv[jt][g][e] + (acc2[0][jt][4 * g + e] + bv2[g][e]) * pm;
+                sum += v[jt][4 * g + e];
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        if (hl == 0) red[(wave * NJ1 + jt) * 32 + (lane & 31)] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < NJ1; ++jt) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[(w * NJ1 + jt) * 32 + (lane & 31)];
+        const float mean = tot / (float)H;
+        float s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            v[jt][e] -= mean;
+            s2 += v[jt][e] * v[jt][e];
+        }
+        s2 += __shfl_xor(s2, 32, 64);
+        if (hl == 0) red[NW * NJ1 * 32 + (wave * NJ1 + jt) * 32 + (lane & 31)] = s2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jt = 0; jt < NJ1; ++jt) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += red[NW * NJ1 * 32 + (w * NJ1 + jt) * 32 + (lane & 31)];
+        const float rstd = 1.f / sqrtf(tot / (float)H + 1e-5f);
+        const int j = jt * 32 + (lane & 31);
+        if (j < TV && tt[jt] < a.T) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = v[jt][4 * g + e] * rstd * ga[g][e] + be[g][e];
+                *(f32x4*)(a.xo + boff + (size_t)tt[jt] * H + cb + 8 * g) = o;
+            }
+        }
+    }
+}
+
 // z * x_mask, channels-last [B][T][C] -> the generator's channel-first [B][C][T]   (synthesizers.py:192)
 static __global__ void __launch_bounds__(256) k_fr_out(const float* __restrict__ x, float* __restrict__ out, int T, int C, int t_off,
                                                 const long long* __restrict__ len) {

@@ -164,3 +164,20 @@ def test_front_rejects_bad_input(gpu):
         rvc_amd.FrontHIP(vars(fcfg), bad, device=gpu)
     with pytest.raises(rvc_amd.RvcmiError):
         rvc_amd.FrontHIP(vars(FrontConfig(n_heads=4)), wf, device=gpu)
+
+
+@pytest.mark.parametrize("fused_ffn", [True, False])
+def test_front_large_batch_tile_height_and_unfused_ffn(fused_ffn, gpu, monkeypatch):
+    """Large batches run 64-row time tiles (pick_nj) and the FFN can run as two launches: force both code paths on a
+    small golden input (they are otherwise only reached at B*T/64 >= 192)."""
+    monkeypatch.setenv("RVCMI_FR_NJ", "2")
+    if not fused_ffn:
+        monkeypatch.setenv("RVCMI_FR_NO_FFN_FUSION", "1")
+    for name in ("front_v2_B2_T50", "front_v2_B1_T100_head6"):
+        d = load_golden(name)
+        fcfg, wf = front_weights(d, int(d["in_channels"]))
+        fr = hip_front(fcfg, wf, "fp16", gpu)
+        fh = max(int(d["flow_head"]), 0)
+        z = fr(dev(d, "phone", gpu), dev(d, "pitch", gpu), dev(d, "lengths", gpu), dev(d, "g", gpu), fh, noise=dev(d, "noise", gpu)).cpu()
+        e = rms(z, d["z"])
+        assert e <= Z_BAR["fp16"], "%s (NJ=2, fused_ffn=%s): z RMS error %.3e" % (name, fused_ffn, e)
