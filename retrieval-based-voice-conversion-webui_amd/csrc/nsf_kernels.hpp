@@ -255,19 +255,45 @@ static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ x
     for (int i = threadIdx.x; i < 7 * C; i += 256) w[i] = Wp[i];
     const int C4 = C >> 2;
     const size_t boff = (size_t)b * L * C;
-    for (int idx = threadIdx.x; idx < (POST_TT + 6) * C4; idx += 256) {
-        const int r = idx / C4, c4 = idx - r * C4;
-        const int t = t0 - 3 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < L) {
-            v = *(const float4*)(xa + boff + (size_t)t * C + c4 * 4);
-            if (xb) { const float4 o = *(const float4*)(xb + boff + (size_t)t * C + c4 * 4); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            if (xc) { const float4 o = *(const float4*)(xc + boff + (size_t)t * C + c4 * 4); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            if (div != 1.f) { v.x = v.x / div; v.y = v.y / div; v.z = v.z / div; v.w = v.w / div; }
-            v.x = lrelu(v.x, 0.01f); v.y = lrelu(v.y, 0.01f); v.z = lrelu(v.z, 0.01f); v.w = lrelu(v.w, 0.01f);
+    // batched, unconditional (clamped) loads: the former per-chunk `if (in range) { load; if (xb) load; if (xc) load }` loop was
+    // ~8 serial HBM round trips per thread
+    constexpr int SB = 5;
+    const int total = (POST_TT + 6) * C4;
+    for (int base = threadIdx.x; base < total; base += SB * 256) {
+        float4 va[SB], vb[SB], vc[SB];
+        size_t off[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int idx = min(base + u * 256, total - 1);
+            const int r = idx / C4, c4 = idx - r * C4;
+            const int tc = min(max(t0 - 3 + r, 0), L - 1);
+            off[u] = boff + (size_t)tc * C + c4 * 4;
+            va[u] = *(const float4*)(xa + off[u]);
         }
-        float* d = tile + r * S + c4 * 4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if (xb) {
+#pragma unroll
+            for (int u = 0; u < SB; ++u) vb[u] = *(const float4*)(xb + off[u]);
+        }
+        if (xc) {
+#pragma unroll
+            for (int u = 0; u < SB; ++u) vc[u] = *(const float4*)(xc + off[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int idx = base + u * 256;
+            if (idx < total) {
+                const int r = idx / C4, c4 = idx - r * C4;
+                const int t = t0 - 3 + r;
+                float4 v = va[u];
+                if (xb) { v.x += vb[u].x; v.y += vb[u].y; v.z += vb[u].z; v.w += vb[u].w; }
+                if (xc) { v.x += vc[u].x; v.y += vc[u].y; v.z += vc[u].z; v.w += vc[u].w; }
+                if (div != 1.f) { v.x = v.x / div; v.y = v.y / div; v.z = v.z / div; v.w = v.w / div; }
+                v.x = lrelu(v.x, 0.01f); v.y = lrelu(v.y, 0.01f); v.z = lrelu(v.z, 0.01f); v.w = lrelu(v.w, 0.01f);
+                if (t < 0 || t >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                float* d = tile + r * S + c4 * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
     }
     __syncthreads();
     const int t = t0 + threadIdx.x;
