@@ -181,3 +181,39 @@ def test_front_large_batch_tile_height_and_unfused_ffn(fused_ffn, gpu, monkeypat
         z = fr(dev(d, "phone", gpu), dev(d, "pitch", gpu), dev(d, "lengths", gpu), dev(d, "g", gpu), fh, noise=dev(d, "noise", gpu)).cpu()
         e = rms(z, d["z"])
         assert e <= Z_BAR["fp16"], "%s (NJ=2, fused_ffn=%s): z RMS error %.3e" % (name, fused_ffn, e)
+
+
+def test_front_full_clip_size_vs_oracle_and_windowed_waveform(gpu):
+    """BASELINE size (T = 1198 frames = one 10 s clip): the front against its oracle over the whole clip (the attention is
+    global, so no windowing is possible for it), then the whole infer's waveform against the oracle generator on a
+    380-frame window fed with the HIP front's own z (the decoder is local; its CPU oracle needs ~1 s per 380 frames)."""
+    import rvc_amd
+
+    T = 1198
+    fcfg = FrontConfig()
+    wf = synth.make_front_weights(fcfg, 1234)
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    wd = synth.make_dec_weights(cfg, 1234)
+    phone = synth.make_phone(1, T, 768, 1234)
+    pitchf = synth.make_f0(1, T)
+    pitch = synth.make_pitch(pitchf)
+    lengths, sid = torch.tensor([T]), torch.tensor([0])
+    nz = torch.randn(1, 192, T, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        zr, m1, g = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, nz)
+    fr = hip_front(fcfg, wf, "fp16", gpu, max_B=1, max_T=T)
+    z = fr(phone.to(gpu), pitch.to(gpu), lengths.to(gpu), g.to(gpu), 0, noise=nz.to(gpu))
+    e = rms(z.cpu(), zr * m1)
+    assert e <= Z_BAR["fp16"], "full-size front: z RMS error %.3e" % e
+    dec = rvc_amd.NSFGeneratorHIP(vars(cfg), wd, device=gpu, operand="fp16", max_B=1, max_T=T)
+    noise = nsf_oracle.reference_noise(1, T, cfg.upp, 114514)
+    f0u = torch.zeros_like(pitchf)  # unvoiced: no phase history, so a window of the clip is exactly comparable
+    out = dec(z, f0u.to(gpu), g.to(gpu), noise=noise.to(gpu)).cpu()
+    a, b, m = 500, 800, 40
+    with torch.no_grad():
+        ref = nsf_oracle.generator_forward(cfg, wd, (zr * m1)[:, :, a - m:b + m], f0u[:, a - m:b + m], g,
+                                           noise[:, (a - m) * cfg.upp:(b + m) * cfg.upp])
+    x = out[0, 0, a * cfg.upp:b * cfg.upp]
+    y = ref[0, 0, m * cfg.upp:(m + b - a) * cfg.upp]
+    ew = rms(x, y)
+    assert ew <= 1e-3, "full-size whole infer (window %d..%d): waveform RMS error %.3e" % (a, b, ew)
