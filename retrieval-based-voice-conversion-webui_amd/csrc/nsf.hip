@@ -606,7 +606,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
     const float* har = nullptr;
     if (c.use_f0) {
         h->prof.launch("phase_scan", 0, (double)B * T * 8, st, [&] {
-            hipLaunchKernelGGL(k_phase_scan, dim3(B), dim3(64), 0, st, f0, h->phase.as<float>(), T, (float)c.sr, (float)upp);
+            hipLaunchKernelGGL(k_phase_scan, dim3(B), dim3(256), 0, st, f0, h->phase.as<float>(), T, (float)c.sr, (float)upp);
         });
         const size_t total = (size_t)B * T * upp;
         h->prof.launch("sine_source", 0, (double)total * (noise ? 8 : 4), st, [&] {

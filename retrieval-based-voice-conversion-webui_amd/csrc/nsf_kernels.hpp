@@ -32,17 +32,19 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 // phase[b][t] = fmod(float(sum_{tau<t} w_tau), 1), w_tau = fmod(f0/sr*upp + 0.5, 1) - 0.5.
 // torch's CPU cumsum accumulates fp32 inputs in DOUBLE and rounds each prefix to fp32
 // (verified against torch 2.10); a wave-level scan in fp64 reproduces that to the last bit except
-// on exact rounding boundaries.  One wave (64 lanes) per utterance.
-static __global__ void __launch_bounds__(64) k_phase_scan(const float* __restrict__ f0, float* __restrict__ phase,
+// on exact rounding boundaries.  One block of 256 threads per utterance (the frames' slow fmod / divide chain is spread
+// over 4 waves: 15 -> ~5 us for a 10 s clip; the block-level scan goes through LDS).
+static __global__ void __launch_bounds__(256) k_phase_scan(const float* __restrict__ f0, float* __restrict__ phase,
                                                    int T, float sr, float upp) {
 #pragma clang fp contract(off)
+    __shared__ double wsum[4];
     const int b = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* f = f0 + (size_t)b * T;
     float* ph = phase + (size_t)b * T;
     const int n = T - 1;  // increments come from frames 0..T-2
-    const int per = (n + 63) / 64;
-    const int beg = lane * per;
+    const int per = (n + 255) / 256;
+    const int beg = min(n, tid * per);
     const int end = min(n, beg + per);
     double local = 0.0;
     for (int t = beg; t < end; ++t) {
@@ -50,14 +52,17 @@ static __global__ void __launch_bounds__(64) k_phase_scan(const float* __restric
         float w = __fsub_rn(fmodf(__fadd_rn(rad, 0.5f), 1.0f), 0.5f);
         local += (double)w;
     }
-    // inclusive wave scan of the per-lane sums
+    // inclusive wave scan of the per-thread sums, then the waves' totals through LDS
     double incl = local;
     for (int off = 1; off < 64; off <<= 1) {
         double o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
-    double run = incl - local;  // exclusive prefix
-    if (lane == 0) ph[0] = 0.f;
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    double run = incl - local;  // exclusive prefix inside the wave
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    if (tid == 0) ph[0] = 0.f;
     for (int t = beg; t < end; ++t) {
         float rad = __fmul_rn(__fdiv_rn(f[t], sr), upp);
         float w = __fsub_rn(fmodf(__fadd_rn(rad, 0.5f), 1.0f), 0.5f);
