@@ -314,8 +314,9 @@ static void launch_by_cin(const ConvArgs& a, int B, hipStream_t st) {
 }
 
 template <typename OpT>
-static void launch_conv_mfma(const ConvArgs& a, int B, hipStream_t st) {
+static void launch_conv_mfma(const ConvArgs& a, int nj, int B, hipStream_t st) {
     const Geom g = conv_geom(a.cout);
+    if (g.MI == 2 && g.WCO == 4 && nj == 1) return launch_by_cin<OpT, 2, 1, 4>(a, B, st);
     if (g.MI == 2 && g.WCO == 4) return launch_by_cin<OpT, 2, 4, 4>(a, B, st);
     if (g.MI == 2 && g.WCO == 2) return launch_by_cin<OpT, 2, 4, 2>(a, B, st);
     if (g.MI == 2 && g.WCO == 1) return launch_by_cin<OpT, 2, 4, 1>(a, B, st);
@@ -326,6 +327,7 @@ template <typename OpT>
 static void set_lds_all() {
 #define X(OpT_, CIN_, MI_, NJ_, WCO_) set_lds_inst<OpT_, CIN_, MI_, NJ_, WCO_>();
     RVCMI_FOR_EACH_CIN(X, OpT, 2, 4, 4)
+    RVCMI_FOR_EACH_CIN(X, OpT, 2, 1, 4)
     RVCMI_FOR_EACH_CIN(X, OpT, 2, 4, 2)
     RVCMI_FOR_EACH_CIN(X, OpT, 2, 4, 1)
     RVCMI_FOR_EACH_CIN(X, OpT, 1, 4, 1)
@@ -532,7 +534,14 @@ static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const 
         dim3 grid((unsigned)((n + 255) / 256), L.nphase, B);
         h->prof.launch(name, flops, bytes, st, [&] { hipLaunchKernelGGL(k_conv_f32, grid, dim3(256), 0, st, a); });
     } else {
-        const Geom g = conv_geom(L.cout);
+        Geom g = conv_geom(L.cout);
+        // a launch of a few dozen 128-row tiles (conv_pre of one clip: 20 blocks) is latency-bound on one tile's K loop:
+        // 32-row tiles give 4x the blocks and a quarter of the per-block work
+        int nj = 4;
+        if (g.MI == 2 && g.WCO == 4 && (long)B * ((a.Lq + g.TT - 1) / g.TT) * ((L.cout + 255) / 256) * L.nphase < 128) {
+            nj = 1;
+            g.TT = 32;
+        }
         a.w = L.w_pack.p;
         a.w_ct_stride = L.ct_stride;
         a.ntaps = L.ntaps_p;
@@ -540,8 +549,8 @@ static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const 
         a.roff = L.dstep < 0 ? span : 0;
         a.tile_rows = g.TT + span;
         h->prof.launch(name, flops, bytes, st, [&] {
-            if (op == RVCMI_OPERAND_BF16) launch_conv_mfma<__bf16>(a, B, st);
-            else launch_conv_mfma<_Float16>(a, B, st);
+            if (op == RVCMI_OPERAND_BF16) launch_conv_mfma<__bf16>(a, nj, B, st);
+            else launch_conv_mfma<_Float16>(a, nj, B, st);
         });
     }
     HIP_CHECK(hipGetLastError());
