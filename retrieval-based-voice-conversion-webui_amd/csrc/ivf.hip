@@ -190,6 +190,69 @@ __global__ void __launch_bounds__(64 * NWC) k_coarse_gemm(const float* __restric
     }
 }
 
+// Small problems (nlist 256 x 599 queries = 152 tiles): one 32 x 32 tile per block, the K dimension split over 4 waves
+// (wave w takes chunks w, w+4, ...), each with its own staging area and a register prefetch of its next chunk; the four
+// partial accumulators are added in a fixed order through LDS.  The single-wave version walked 24 chunks serially and was
+// bound by 24 load latencies (34 us); a tree of partial sums stays inside the error bound k_coarse_pick assumes.
+__global__ void __launch_bounds__(256) k_coarse_gemm_ks(const float* __restrict__ q, const float* __restrict__ cent,
+                                                        const float* __restrict__ cn, int64_t nq, int64_t nlist, int d,
+                                                        float* __restrict__ S) {
+    __shared__ float St[4][64 * CG_S];   // per wave: 32 query rows then 32 centroid rows
+    __shared__ float Red[3][64 * 16];
+    const int64_t q0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* st = St[wave];
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float4 pre[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = lane + it * 64;
+            const int row = idx >> 3, c4 = idx & 7;
+            const int kk = min(k0 + c4 * 4, d - 4);
+            const float* src = row < 32 ? q + min(q0 + row, nq - 1) * d : cent + min(c0 + (row - 32), nlist - 1) * d;
+            const float4 v = *(const float4*)(src + kk);
+            const bool ok = k0 + c4 * 4 < d;
+            pre[it] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+    };
+    const int kstep = 4 * CG_K;
+    if (wave * CG_K < d) fetch(wave * CG_K);
+    for (int k0 = wave * CG_K; k0 < d; k0 += kstep) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = lane + it * 64;
+            const int row = idx >> 3, c4 = idx & 7;
+            float* dst = st + row * CG_S + c4 * 4;
+            dst[0] = pre[it].x; dst[1] = pre[it].y; dst[2] = pre[it].z; dst[3] = pre[it].w;
+        }
+        if (k0 + kstep < d) fetch(k0 + kstep);  // in flight while this chunk is multiplied (wave-private LDS: no barrier)
+        const float* qa = st + (lane & 31) * CG_S + (lane >> 5);
+        const float* cb = st + (32 + (lane & 31)) * CG_S + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < CG_K / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * ks], cb[2 * ks], acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Red[wave - 1][e * 64 + lane] = acc[e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int64_t c = c0 + (lane & 31);
+        if (c < nlist) {
+            const float cnc = cn[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float dot = ((acc[r] + Red[0][r * 64 + lane]) + Red[1][r * 64 + lane]) + Red[2][r * 64 + lane];
+                const int64_t qr = q0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (qr < nq) S[qr * nlist + c] = cnc - 2.f * dot;
+            }
+        }
+    }
+}
+
 // k_coarse_pick: one wave per query.  m = min_c S[q][c]; every centroid with S <= m + margin is a candidate
 // (margin = 2 * rigorous rounding bound, so the exact winner is always among them -- usually alone); candidates are
 // re-evaluated cooperatively in fp64 as sum((q-c)^2) and the exact (distance, id) minimum wins.
@@ -866,7 +929,7 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
                                        b.nlist, d, h->cscore.as<float>());
                 } else {
                     dim3 grid((unsigned)((b.nlist + 31) / 32), (unsigned)((nqc + 31) / 32));
-                    hipLaunchKernelGGL((k_coarse_gemm<1, 1>), grid, dim3(64), 0, st, q + qs * d, h->centroids(), h->cnorm(), nqc,
+                    hipLaunchKernelGGL(k_coarse_gemm_ks, grid, dim3(256), 0, st, q + qs * d, h->centroids(), h->cnorm(), nqc,
                                        b.nlist, d, h->cscore.as<float>());
                 }
                 hipLaunchKernelGGL(k_coarse_pick, dim3((unsigned)((nqc + 3) / 4)), dim3(256), 0, st, q + qs * d, h->centroids(),
