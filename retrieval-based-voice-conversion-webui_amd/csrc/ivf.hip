@@ -463,8 +463,11 @@ template <int VL, int LPR, int RU>
 __global__ void __launch_bounds__(256) k_scan_v(const float* __restrict__ q, const int64_t* __restrict__ assign, int nprobe,
                                                    const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
                                                    const float* __restrict__ vecs, int64_t nq, int k, float* __restrict__ D,
-                                                   int64_t* __restrict__ I, int64_t* __restrict__ P, int* __restrict__ any_short) {
+                                                   int64_t* __restrict__ I, int64_t* __restrict__ P, int* __restrict__ any_short,
+                                                   float* __restrict__ bfeats, float rate, float omr, int64_t pos_last) {
     constexpr int d = LPR * 4 * VL;
+    __shared__ float bd[KMAX];      // fused blend (bfeats != nullptr): the query's k results, by rank
+    __shared__ long long bp[KMAX];
     constexpr int G = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     TopK* merge = (TopK*)smem_raw;
@@ -542,12 +545,47 @@ __global__ void __launch_bounds__(256) k_scan_v(const float* __restrict__ q, con
                 D[qi * k + rank] = FLT_MAX;
                 I[qi * k + rank] = -1;
                 P[qi * k + rank] = -1;
+                bd[rank] = FLT_MAX;
+                bp[rank] = -1;
                 atomicOr(any_short, 1);
             } else {
                 D[qi * k + rank] = (float)md;
                 I[qi * k + rank] = mid;
                 P[qi * k + rank] = merge[mg].pos[ms];
+                bd[rank] = (float)md;
+                bp[rank] = merge[mg].pos[ms];
             }
+        }
+    }
+    if (bfeats) {
+        // pipeline.py:129-138 for this query's row, exactly as k_blend evaluates it (numpy's operation order); the rows were
+        // just read by the scan, so the gather hits L2.  Only used without the realtime guard (which is a per-call decision).
+#pragma clang fp contract(off)
+        __syncthreads();
+        float w[KMAX];
+        for (int s = 0; s < k; ++s) {
+            const float inv = __fdiv_rn(1.0f, bd[s]);
+            w[s] = __fmul_rn(inv, inv);
+        }
+        float sum;
+        if (k == 8) {
+            sum = __fadd_rn(__fadd_rn(__fadd_rn(w[0], w[1]), __fadd_rn(w[2], w[3])),
+                            __fadd_rn(__fadd_rn(w[4], w[5]), __fadd_rn(w[6], w[7])));
+        } else {
+            sum = w[0];
+            for (int s = 1; s < k; ++s) sum = __fadd_rn(sum, w[s]);
+        }
+        for (int s = 0; s < k; ++s) w[s] = __fdiv_rn(w[s], sum);
+        for (int e = threadIdx.x; e < d; e += 256) {
+            float acc = 0.f;
+            for (int s = 0; s < k; ++s) {
+                long long p = bp[s];
+                if (p < 0) p = pos_last;
+                const float prod = __fmul_rn(vecs[p * d + e], w[s]);
+                acc = s == 0 ? prod : __fadd_rn(acc, prod);
+            }
+            const float f = bfeats[qi * d + e];
+            bfeats[qi * d + e] = __fadd_rn(__fmul_rn(acc, rate), __fmul_rn(omr, f));
         }
     }
 }
@@ -906,10 +944,16 @@ static void reserve(rvcmi_ivf* h, int64_t nq) {
     h->cap_nprobe = np;
 }
 
-static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, int64_t* I, hipStream_t st) {
+struct BlendFuse {
+    float* feats;
+    float rate, omr;
+};
+// returns true when the blend of `bf` was done inside the scan kernel
+static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, int64_t* I, hipStream_t st,
+                   const BlendFuse* bf = nullptr) {
     if (!h || nq < 0 || (nq && (!q || !D || !I))) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
     if (k < 1 || k > KMAX) RVCMI_FAIL(RVCMI_ERR_INVALID, "k=%d outside [1,%d]", k, KMAX);
-    if (nq == 0) return;
+    if (nq == 0) return false;
     reserve(h, nq);
     const BlobHeader& b = h->hdr;
     const int d = b.d;
@@ -951,18 +995,23 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
                                h->assign.as<int64_t>());
         });
     }
+    bool fused = false;
     const double rows = b.nlist ? (double)b.ntotal / (double)b.nlist * np : 0;
     const size_t smem = align_up((size_t)d * 4, 16) + SCAN_GROUPS * sizeof(TopK);
     h->prof.launch("ivf_scan", 3.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
         const size_t sm2 = SCAN_GROUPS * sizeof(TopK);
         if (d == 768 && !getenv("RVCMI_IVF_GENERIC")) {
             hipLaunchKernelGGL((k_scan_v<6, 32, 2>), dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
-                               h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>());
+                               h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(), bf ? bf->feats : nullptr,
+                               bf ? bf->rate : 0.f, bf ? bf->omr : 0.f, h->hdr.pos_last);
+            fused = bf != nullptr;
             return;
         }
         if (d == 256 && !getenv("RVCMI_IVF_GENERIC")) {
             hipLaunchKernelGGL((k_scan_v<4, 16, 2>), dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
-                               h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>());
+                               h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(), bf ? bf->feats : nullptr,
+                               bf ? bf->rate : 0.f, bf ? bf->omr : 0.f, h->hdr.pos_last);
+            fused = bf != nullptr;
             return;
         }
         hipLaunchKernelGGL(k_scan, dim3((unsigned)nq), dim3(256), smem, st, q, h->assign.as<int64_t>(), np,
@@ -970,6 +1019,7 @@ static void search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
                            getenv("RVCMI_IVF_DBG") ? atoi(getenv("RVCMI_IVF_DBG")) : 0);
     });
     HIP_CHECK(hipGetLastError());
+    return fused;
 }
 
 }  // namespace rvcmi
@@ -1143,10 +1193,12 @@ int rvcmi_ivf_search_blend(rvcmi_ivf* h, int64_t nq, float* feats, float index_r
         if (nq == 0) return;
         hipStream_t st = (hipStream_t)stream;
         reserve(h, nq);
-        search(h, nq, feats, k, h->Dtmp.as<float>(), h->Itmp.as<int64_t>(), st);
         const int d = h->hdr.d;
         // torch evaluates `npy * index_rate + (1 - index_rate) * feats` with the python scalars cast to fp32
         const float rate = index_rate, omr = (float)(1.0 - (double)index_rate);
+        const BlendFuse bf = {feats, rate, omr};
+        // without the realtime guard the blend of a row needs nothing but that row's own results: done by the scan block
+        if (search(h, nq, feats, k, h->Dtmp.as<float>(), h->Itmp.as<int64_t>(), st, skip_if_short ? nullptr : &bf)) return;
         h->prof.launch("ivf_blend", 2.0 * nq * k * d, (double)nq * d * 4 * (2 + k), st, [&] {
             hipLaunchKernelGGL(k_blend, dim3((unsigned)nq), dim3(256), 0, st, feats, h->Dtmp.as<float>(), h->P.as<int64_t>(),
                                h->vecs(), d, k, h->hdr.pos_last, rate, omr, h->flag.as<int>(), skip_if_short);
