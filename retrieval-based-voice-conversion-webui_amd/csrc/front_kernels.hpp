@@ -398,8 +398,9 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {
 #define FR_STAMP(i) do { if (st) { a.stamps[2 * (i)] = wall_clock64(); a.stamps[2 * (i) + 1] = __builtin_amdgcn_s_memtime(); } } while (0)
     FR_STAMP(0);
     const OpT* wlane1 = (const OpT*)a.w_in + (size_t)(2 * wave) * a.ct_in + lane * 8;
-    typename Op<OpT>::frag Aw[FR_NB][KGROUP][2];
-    conv_prefetch<OpT, H, 2, KGROUP, FR_NB>(Aw, wlane1, a.ct_in, a.ntaps);
+    constexpr int NBW = NJ == 1 ? FR_NB : 2;  // 64-row tiles (large batches) hold twice the accumulators: a 2-deep ring avoids spills
+    typename Op<OpT>::frag Aw[NBW][KGROUP][2];
+    conv_prefetch<OpT, H, 2, KGROUP, NBW>(Aw, wlane1, a.ct_in, a.ntaps);
     // epilogue operands requested now, used ~10 us later: x (fp32 residual), running skip sum, res_skip bias
     constexpr int MI2 = LAST ? 1 : 2;
     const long long lenb = a.len ? a.len[b] : (long long)a.T + a.t_off;
@@ -429,7 +430,7 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {
 
     const char* lds_lane = smem + (size_t)(lane & 31) * STRIDE + hl * 16;
     const OpT* wlane = (const OpT*)a.w_rs + (size_t)(MI2 * wave) * a.ct_rs + lane * 8;
-    typename Op<OpT>::frag Aw2[FR_NB][KGROUP][MI2];
+    typename Op<OpT>::frag Aw2[NBW][KGROUP][MI2];
     {
         f32x16 acc[2][NJ];
 #pragma unroll
@@ -438,9 +439,9 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {
             for (int jt = 0; jt < NJ; ++jt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
-        conv_run<OpT, H, 2, NJ, KGROUP, FR_NB>(acc, Aw, lds_lane, wlane1, a.ct_in, a.ntaps, 0, 1);
+        conv_run<OpT, H, 2, NJ, KGROUP, NBW>(acc, Aw, lds_lane, wlane1, a.ct_in, a.ntaps, 0, 1);
         FR_STAMP(2);
-        conv_prefetch<OpT, H, MI2, KGROUP, FR_NB>(Aw2, wlane, a.ct_rs, 1);
+        conv_prefetch<OpT, H, MI2, KGROUP, NBW>(Aw2, wlane, a.ct_rs, 1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 bt = *(const f32x4*)(bg + cb + 8 * g), bs = *(const f32x4*)(bg + H + cb + 8 * g);
@@ -466,7 +467,7 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
     const char* act_lane = ACT + (size_t)(lane & 31) * STRIDE + hl * 16;
-    conv_run<OpT, H, MI2, NJ, KGROUP, FR_NB>(acc, Aw2, act_lane, wlane, a.ct_rs, 1, 0, 1);
+    conv_run<OpT, H, MI2, NJ, KGROUP, NBW>(acc, Aw2, act_lane, wlane, a.ct_rs, 1, 0, 1);
     FR_STAMP(5);
 #pragma unroll
     for (int jt = 0; jt < NJ; ++jt) {
@@ -783,8 +784,9 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_ffn(FrFfnArgs a) {
 
     // conv_1 weights of this wave's first tile pair, then the x tile (x * x_mask: rows >= len are zero)
     const OpT* w1lane = (const OpT*)a.w1 + (size_t)(wave * FT) * a.ct1 + lane * 8;
-    typename Op<OpT>::frag Aw[FR_NB][KGROUP][2];
-    conv_prefetch<OpT, H, 2, KGROUP, FR_NB>(Aw, w1lane, a.ct1, a.ntaps);
+    constexpr int NBF = NJ1 == 1 ? FR_NB : 2;  // see k_fr_wn
+    typename Op<OpT>::frag Aw[NBF][KGROUP][2];
+    conv_prefetch<OpT, H, 2, KGROUP, NBF>(Aw, w1lane, a.ct1, a.ntaps);
     // epilogue operands of the LayerNorm, requested early
     const int cb = wave * 32 + 4 * hl;
     int tt[NJ1], tcl[NJ1];
@@ -813,7 +815,7 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_ffn(FrFfnArgs a) {
     for (int pass = 0; pass < FT / 2; ++pass) {
         const int ct = wave * FT + 2 * pass;
         const OpT* wl = (const OpT*)a.w1 + (size_t)ct * a.ct1 + lane * 8;
-        if (pass > 0) conv_prefetch<OpT, H, 2, KGROUP, FR_NB>(Aw, wl, a.ct1, a.ntaps);
+        if (pass > 0) conv_prefetch<OpT, H, 2, KGROUP, NBF>(Aw, wl, a.ct1, a.ntaps);
         f32x16 acc[2][NJ1];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -821,7 +823,7 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_ffn(FrFfnArgs a) {
             for (int jt = 0; jt < NJ1; ++jt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
-        conv_run<OpT, H, 2, NJ1, KGROUP, FR_NB>(acc, Aw, x_lane, wl, a.ct1, a.ntaps, 0, 1);
+        conv_run<OpT, H, 2, NJ1, KGROUP, NBF>(acc, Aw, x_lane, wl, a.ct1, a.ntaps, 0, 1);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -842,8 +844,8 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_ffn(FrFfnArgs a) {
     }
     // ---- conv_2 over the hidden tile ----
     const OpT* w2lane = (const OpT*)a.w2 + (size_t)wave * a.ct2 + lane * 8;
-    typename Op<OpT>::frag Aw2[FR_NB][KGROUP][1];
-    conv_prefetch<OpT, F, 1, KGROUP, FR_NB>(Aw2, w2lane, a.ct2, a.ntaps);
+    typename Op<OpT>::frag Aw2[NBF][KGROUP][1];
+    conv_prefetch<OpT, F, 1, KGROUP, NBF>(Aw2, w2lane, a.ct2, a.ntaps);
     __syncthreads();
     f32x16 acc2[1][NJ1];
 #pragma unroll
@@ -851,7 +853,7 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_ffn(FrFfnArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc2[0][jt][e] = 0.f;
     const char* h_lane = HS + (size_t)(lane & 31) * TLF::STRIDE + hl * 16;
-    conv_run<OpT, F, 1, NJ1, KGROUP, FR_NB>(acc2, Aw2, h_lane, w2lane, a.ct2, a.ntaps, 0, 1);
+    conv_run<OpT, F, 1, NJ1, KGROUP, NBF>(acc2, Aw2, h_lane, w2lane, a.ct2, a.ntaps, 0, 1);
 
     // ---- (* mask) + x -> LayerNorm over the H channels (statistics through LDS, two passes) ----
     __syncthreads();  // x tile is dead
