@@ -40,8 +40,9 @@ PEAK = {"bf16": 2.5e15, "fp16": 2.5e15, "fp32": 1.573e14}  # MI355X dense MFMA /
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--repeats", type=int, default=10, help="extra repetitions of the K-step loop for the median / spread report")
     p.add_argument("--batch", type=int, default=1, help="clips per rank per step (BASELINE config 2 = 1, config 3 = 64)")
     p.add_argument("--operand", default="fp16", choices=["fp16", "bf16", "fp32"])
     p.add_argument("--frames", type=int, default=T_CLIP)
@@ -52,20 +53,54 @@ def parse():
     p.add_argument("--whole", action="store_true",
                    help="time the whole net_g.infer (retrieval + enc_p + flow^-1 + decode) as THE step instead of the BASELINE hot path")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-gpu-torch-baseline", action="store_true")
+    p.add_argument("--torch-gpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--stream", action="store_true",
                    help="BASELINE configs[4]: realtime chunks (v1/40k generator, T=31 frames -> n_res, 16 queries); prints p50 latency")
     return p.parse_args()
 
 
+def _reference_generator(cfg, w):
+    """The reference's own NSFGenerator (rvc/layers/nsf.py:64-206) carrying the seeded weights, when an RVC checkout is
+    importable (RVC_REFERENCE, default /root/reference: present in the build container, absent on the GPU box)."""
+    ref = os.environ.get("RVC_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "rvc", "layers")):
+        return None
+    try:
+        sys.path.insert(0, ref)
+        from rvc.layers.nsf import NSFGenerator
+
+        net = NSFGenerator(cfg.inter_channels, "1", cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes, cfg.upsample_rates,
+                           cfg.upsample_initial_channel, cfg.upsample_kernel_sizes, cfg.gin_channels, cfg.sr)
+        net.eval()
+        net.remove_weight_norm()
+        net.load_state_dict(w, strict=True)
+        return net
+    except Exception as e:  # noqa
+        print("[bench] reference generator not usable (%s); timing the oracle port" % e, file=sys.stderr)
+        return None
+    finally:
+        if ref in sys.path:
+            sys.path.remove(ref)
+
+
 def cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, index_rate):
-    """The CPU side timed next to the GPU: the oracle (kind 'port') on this host's cores.
-    Generator = torch-CPU fp32 restatement (same ATen/oneDNN conv kernels the reference calls);
-    retrieval = the C restatement in fp32 arithmetic with OpenMP (faiss itself is not installable).
-    Sample: ONE 10 s clip (T frames + 599 queries), 1 warm-up + best of 2."""
+    """The CPU side timed next to the GPU on this host's cores (3 warm-ups, median of 5).
+    Generator: the reference's own ``NSFGenerator`` on torch-CPU fp32 when an RVC checkout is importable (kind
+    'reference'), else the oracle restatement (kind 'port': the same ATen/oneDNN conv kernels the reference calls).
+    Retrieval: the C restatement in fp32 arithmetic with OpenMP (faiss itself is not installable).
+    Sample: ONE 10 s clip (T frames + 599 queries)."""
     import ctypes as C
 
     from oracle import nsf_oracle
+
+    ref_net = _reference_generator(cfg, w)
+
+    def gen_fwd(zz, ff, gg, nn):
+        if ref_net is not None:
+            return ref_net(zz, ff, g=gg)  # draws its own noise (same work)
+        return nsf_oracle.generator_forward(cfg, w, zz, ff, gg, nn)
 
     ncpu = os.cpu_count() or 1
     # torch's intra-op pool scales badly past a few dozen threads on this op mix (61 s/clip with 256 threads on
@@ -74,9 +109,9 @@ def cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, index_rate):
     for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
         torch.set_num_threads(n)
         with torch.no_grad():
-            nsf_oracle.generator_forward(cfg, w, z[:1, :, :64], f0[:1, :64], g[:1], noise[:1, :64 * cfg.upp])
+            gen_fwd(z[:1, :, :64], f0[:1, :64], g[:1], noise[:1, :64 * cfg.upp])
             t0 = time.perf_counter()
-            nsf_oracle.generator_forward(cfg, w, z[:1, :, :160], f0[:1, :160], g[:1], noise[:1, :160 * cfg.upp])
+            gen_fwd(z[:1, :, :160], f0[:1, :160], g[:1], noise[:1, :160 * cfg.upp])
             dt = time.perf_counter() - t0
         if best_t is None or dt < best_t:
             best_t, cores = dt, n
@@ -91,7 +126,8 @@ def cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, index_rate):
     pos_last = int(np.nonzero(idx["ids"] == idx["ntotal"] - 1)[0][0])
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
 
-    def once():
+    def once(Tn=None):
+        Tn = z.shape[-1] if Tn is None else Tn
         t0 = time.perf_counter()
         feats = q.copy()
         lib.ivf_search(vp(feats), C.c_int64(nq), C.c_int(d), vp(idx["centroids"]), C.c_int64(idx["nlist"]), C.c_int(1),
@@ -100,16 +136,79 @@ def cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, index_rate):
                       C.c_float(index_rate), C.c_float(1.0 - index_rate))
         t1 = time.perf_counter()
         with torch.no_grad():
-            nsf_oracle.generator_forward(cfg, w, z[:1], f0[:1], g[:1], noise[:1])
+            gen_fwd(z[:1, :, :Tn], f0[:1, :Tn], g[:1], noise[:1, :Tn * cfg.upp])
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1
 
-    runs = [once(), once()]
-    t_ivf = min(r[0] for r in runs)
-    t_gen = min(r[1] for r in runs)
-    return {"value": CLIP_SECONDS / (t_ivf + t_gen), "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": "port",
-            "sample": "1 clip: 599 queries vs %dx%d IVF (C restatement, fp32, OpenMP) %.3fs + generator T=%d (torch-CPU fp32 oracle) %.3fs; best of 2 (no separate warm-up); torch threads chosen from {8,16,32,64}"
-                      % (idx["ntotal"], idx["d"], t_ivf, z.shape[-1], t_gen)}
+    once(400), once(400), once()  # 3 warm-ups: two short clips (allocator / thread pool), one full clip
+    runs = [once() for _ in range(5)]
+    t_ivf = float(np.median([r[0] for r in runs]))
+    t_gen = float(np.median([r[1] for r in runs]))
+    tot = sorted(r[0] + r[1] for r in runs)
+    kind = "reference" if ref_net is not None else "port"
+    return {"value": CLIP_SECONDS / (t_ivf + t_gen), "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": kind,
+            "spread_s": [tot[0], tot[-1]],
+            "sample": "1 clip: 599 queries vs %dx%d IVF (C restatement, fp32, OpenMP) %.3fs + generator T=%d (%s, torch-CPU fp32) %.3fs; "
+                      "3 warm-ups (2 short clips + 1 full), median of 5; torch threads chosen from {8,16,32,64}"
+                      % (idx["ntotal"], idx["d"], t_ivf, z.shape[-1],
+                         "the reference's rvc.layers.nsf.NSFGenerator" if ref_net is not None else "oracle restatement of NSFGenerator.forward",
+                         t_gen)}
+
+
+def torch_gpu_baseline_worker(a):
+    """The "hipify-equivalent" number: the SAME generator executed by stock
+    PyTorch-ROCm (MIOpen / rocBLAS kernels chosen by torch) on this GPU -- the oracle's functional restatement of
+    NSFGenerator.forward moved to cuda, fp32 and .half() (the reference's is_half mode, infer/modules/vc/modules.py:94-95).
+    Runs in a child process so that a slow first-time MIOpen kernel build cannot stall the headline run.  3 warm-ups, median
+    of 5, inputs resident on the device, torch.cuda.synchronize() around each forward."""
+    from oracle import nsf_oracle, synth
+
+    dev = torch.device("cuda", 0)
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    w = synth.make_dec_weights(cfg, 1234)
+    z, f0, g = synth.make_dec_inputs(cfg, 1, a.frames, seed=1234)
+    noise = nsf_oracle.reference_noise(1, a.frames, cfg.upp, 114514)
+    out = {"what": "oracle restatement of NSFGenerator.forward on device=cuda via stock PyTorch-ROCm (torch %s), generator only, B=1, T=%d; 3 warm-ups, median of 5"
+                   % (torch.__version__, a.frames)}
+    ref = None
+    for name, dt in (("fp32", torch.float32), ("fp16", torch.float16)):
+        wd = {k: v.to(dev, dt) for k, v in w.items()}
+        zd, fd, gd, nd = z.to(dev, dt), f0.to(dev, dt), g.to(dev, dt), noise.to(dev, dt)
+        ts = []
+        with torch.no_grad():
+            for i in range(8):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                o = nsf_oracle.generator_forward(cfg, wd, zd, fd, gd, nd)
+                torch.cuda.synchronize()
+                if i >= 3:
+                    ts.append(time.perf_counter() - t0)
+                elif i == 0:
+                    out[name + "_first_call_s"] = time.perf_counter() - t0
+        ts.sort()
+        med = ts[len(ts) // 2]
+        out[name] = {"ms_per_clip": 1e3 * med, "min_ms": 1e3 * ts[0], "max_ms": 1e3 * ts[-1],
+                     "value": CLIP_SECONDS * (a.frames / T_CLIP) / med, "unit": "x real-time (generator only)",
+                     "tflops": GEN_FLOP_PER_CLIP * (a.frames / T_CLIP) / med / 1e12, "finite": bool(torch.isfinite(o).all())}
+        if ref is None:
+            ref = o.float()
+        else:
+            out[name]["rms_vs_torch_fp32"] = float((o.float() - ref).pow(2).mean().sqrt())
+    print("TORCH_GPU_BASELINE " + json.dumps(out))
+
+
+def torch_gpu_baseline(a, timeout_s=420):
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--torch-gpu-baseline-worker", "--frames", str(a.frames)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("TORCH_GPU_BASELINE "):
+                return json.loads(ln[len("TORCH_GPU_BASELINE "):])
+        return {"error": "worker exited %d: %s" % (r.returncode, r.stderr[-300:])}
+    except subprocess.TimeoutExpired:
+        return {"error": "stock PyTorch-ROCm generator did not finish 2 x 8 forwards within %d s (first-time MIOpen kernel builds)" % timeout_s}
 
 
 def stream_mode(a):
@@ -187,6 +286,8 @@ def stream_mode(a):
 
 def main():
     a = parse()
+    if a.torch_gpu_baseline_worker:
+        return torch_gpu_baseline_worker(a)
     if a.stream:
         return stream_mode(a)
     rank = int(os.environ.get("RANK", "0"))
@@ -296,6 +397,27 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(out_holder["o"]).all(), "non-finite generator output"
 
+    # ---- stability report: R more repetitions of the same K-step loop (same step, same graph), per-rank wall clock ----
+    reps = None
+    if a.repeats > 0:
+        rt = []
+        for _ in range(a.repeats):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                run()
+            torch.cuda.synchronize()
+            rt.append(1e3 * (time.perf_counter() - t1) / a.steps)
+        rts = sorted(rt)
+        reps = {"n": a.repeats, "steps_each": a.steps, "ms_per_step_median": rts[len(rts) // 2], "ms_per_step_min": rts[0],
+                "ms_per_step_max": rts[-1], "ms_per_step_all": [round(x, 4) for x in rt]}
+        if use_dist:  # per-rank medians, so that the line shows every rank ran (min / max over ranks)
+            tm = torch.tensor([reps["ms_per_step_median"]], device=dev, dtype=torch.float64)
+            lo, hi = tm.clone(), tm.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            reps["rank_median_ms_min_max"] = [float(lo.item()), float(hi.item())]
+
     # ---- roofline leg: the same step, eager, every kernel bracketed by HIP events --------------
     roof = None
     if rank == 0 and not a.no_roofline:
@@ -317,15 +439,25 @@ def main():
         ach = dom["flops"] / (dom["ms"] * 1e-3)
         tot_ms = sum(s["ms"] for s in gs) / 3.0
         gen_ach = GEN_FLOP_PER_CLIP * B * (T / T_CLIP) / (tot_ms * 1e-3)
-        traffic = None  # HBM-side bytes per launch of the dominant kernel: from the committed rocprofv3 --pmc passes, if any
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom["name"])
-            if pm and B == 1 and T == T_CLIP and a.operand == "fp16":
-                traffic = pm["bytes_per_launch"]
-        except Exception:  # noqa
-            pass
+        # HBM-side bytes per launch of the dominant kernel: NOT measured in this run (PMC counters need their own rocprofv3
+        # passes); taken from the newest committed pass of the same command, and labelled as such.
+        traffic, traffic_source, traffic_all = None, None, None
+        for tag in ("r02", "r01"):
+            fn = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
+            if not os.path.exists(fn):
+                continue
+            try:
+                pmj = json.load(open(fn))
+                pm = pmj["kernels"].get(dom["name"])
+                if pm and B == 1 and T == T_CLIP and a.operand == "fp16":
+                    traffic = pm["bytes_per_launch"]
+                    traffic_source = "committed rocprofv3 --pmc pass profiles/%s_pmc_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not measured in this run" % tag
+                    traffic_all = {k: v["bytes_per_launch"] for k, v in pmj["kernels"].items()}
+                    break
+            except Exception:  # noqa
+                pass
         roof = {"bound": "mfma", "kernel": dom["name"], "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": traffic,
+                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source, "traffic_all_kernels": traffic_all,
                 "hbm_side": None if traffic is None else {"achieved": traffic / (dom["ms"] / dom["launches"] * 1e-3) / 1e9, "peak": 8000.0,
                                                          "unit": "GB/s", "frac": traffic / (dom["ms"] / dom["launches"] * 1e-3) / 8e12},
                 "avg_launch_us": 1e3 * dom["ms"] / dom["launches"], "launches_per_step": dom["launches"] // 3,
@@ -388,6 +520,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, a.index_rate)
+    tgpu = None
+    if rank == 0 and world == 1 and not a.no_gpu_torch_baseline and not a.no_cpu_baseline:
+        tgpu = torch_gpu_baseline(a)
 
     if rank == 0:
         clips = B * world * a.steps
@@ -413,6 +548,10 @@ def main():
             line["whole_infer"] = whole
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if tgpu is not None:
+            line["gpu_torch_baseline"] = tgpu
+        if reps is not None:
+            line["repeats"] = reps
         print(json.dumps(line))
     if use_dist:
         dist.barrier()  # the other ranks wait for rank 0's untimed roofline / whole-infer legs before tearing RCCL down

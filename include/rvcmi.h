@@ -287,7 +287,8 @@ int rvcmi_glue_expand_protect(const float* feats_dev, int64_t nq, int d, int rep
  *   _to_local_average_cents + _decode (rvc/f0/rmvpe.py:119-164), _resize_f0 to p_len and _interpolate_f0
  *   (rvc/f0/f0.py:31-78), post_process (rvc/f0/gen.py:10-41): key shift 2^(f0_up_key/12), mel binning to 1..255.
  * fp64 throughout, like numpy.  scratch_dev: n doubles.  pitch_dev [p_len] int64, pitchf_dev [p_len] fp32.
- * n + p_len <= 20480 frames (one block holds the sequential pass).                                  */
+ * Any length: the single sequential pass keeps its work arrays in LDS up to n + p_len = 20480 frames and
+ * in scratch_dev / pitch_dev beyond that (the reference computes f0 once per file, pipeline.py:260-266). */
 int rvcmi_glue_rmvpe_f0(const float* salience_dev, int n, int nbins, float thred, int p_len, int f0_up_key,
                         double* scratch_dev, int64_t* pitch_dev, float* pitchf_dev, void* stream);
 /* post_process only (f0 in Hz from any other estimator, fp64 [n]).                                 */

@@ -72,6 +72,35 @@ def dec_case(name: str, cfg_name: str, B: int, T: int, seed: int = 1234, use_f0:
         name, ref.pow(2).mean().sqrt().item(), err, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
 
 
+def dec_full_case(name: str = "full_v2_48k_T1198_voiced", cfg_name: str = "v2_48k", T: int = 1198, seed: int = 1234,
+                  noise_seed: int = 114514):
+    """BASELINE configs[1] at full size: one 10 s clip (T = 1198 frames), VOICED f0 (80 % of the frames,
+    the inputs bench.py times).  Only the reference's output waveform is stored (2.3 MB); inputs and noise are regenerated
+    from the seeds and verified by sha256.  Pins ``NSFGenerator.forward`` (rvc/layers/nsf.py:145-191) -- in particular the
+    cumulative harmonic phase over 1198 frames (generators.py:175-194) -- at the size the benchmark runs."""
+    import hashlib
+
+    cfg = CONFIGS[cfg_name]
+    w = synth.make_dec_weights(cfg, seed)
+    net = build_reference_dec(cfg, w)
+    z, f0, g = synth.make_dec_inputs(cfg, 1, T, seed)
+    assert float((f0 > 0).float().mean()) > 0.5, "the full-size case must be voiced"
+    torch.manual_seed(noise_seed)
+    with torch.no_grad():
+        ref = net(z, f0, g=g)
+    noise = nsf_oracle.reference_noise(1, T, cfg.upp, noise_seed)
+    with torch.no_grad():
+        ora = nsf_oracle.generator_forward(cfg, w, z, f0, g, noise)
+    err = (ora - ref).abs().max().item()
+    assert err < 2e-6, "%s: oracle restatement deviates from the reference by %g" % (name, err)
+    sha = lambda t: hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), cfg_name=cfg_name, seed=seed, noise_seed=noise_seed, T=T,
+                        weights_sha256=synth.weights_sha256(w), inputs_sha256=sha(z) + sha(f0) + sha(g) + sha(noise),
+                        out=ref.numpy(), oracle_max_abs_dev=err)
+    print("%-28s ref rms %.3f  oracle-vs-reference max dev %.2e  (%d KB)" % (
+        name, ref.pow(2).mean().sqrt().item(), err, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
 def infer_case(name: str = "infer_v2_48k_T20", T: int = 20, seed: int = 1234):
     """The whole ``SynthesizerTrnMsNSFsid.infer`` (rvc/layers/synthesizers.py:160-203) of the reference, loaded
     through the reference's own ``get_synthesizer`` from a synthetic fp16 / legacy-weight-norm checkpoint.  What the
@@ -303,6 +332,8 @@ def main_front():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if os.environ.get("GOLDEN_ONLY_FULL"):
+        return dec_full_case()
     main_front()
     if os.environ.get("GOLDEN_ONLY_FRONT"):
         return
@@ -316,6 +347,7 @@ def main():
     dec_case("dec_v1_40k_nres_T31", "v1_40k", 1, 31, n_res=37)  # realtime formant shift
     dec_case("dec_v1_40k_nres_down_T31", "v1_40k", 1, 31, n_res=26)
     infer_case()
+    dec_full_case()
 
 
 if __name__ == "__main__":

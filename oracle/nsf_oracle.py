@@ -81,7 +81,7 @@ def sine_source(f0: torch.Tensor, upp: int, sr: int, noise: Optional[torch.Tenso
     Returns the pre-linear sine waves [B, T*upp] (dim=1 harmonic only, harmonic_num=0).
     """
     f0 = f0.unsqueeze(-1)  # [B,T,1]
-    a = torch.arange(1, upp + 1, dtype=f0.dtype)
+    a = torch.arange(1, upp + 1, dtype=f0.dtype, device=f0.device)
     rad = f0 / sr * a  # [B,T,upp]                                   generators.py:154-155
     rad2 = torch.fmod(rad[:, :-1, -1:].float() + 0.5, 1.0) - 0.5  # generators.py:156
     rad_acc = rad2.cumsum(dim=1).fmod(1.0).to(f0)  #                 generators.py:157

@@ -12,8 +12,9 @@ from .pipeline import retrieve_blend
 from . import glue
 from .synthesizer import accelerate_synthesizer, get_synthesizer, load_synthesizer
 from . import dist
+from .install import install, uninstall
 
 __all__ = [
     "RvcmiError", "build", "IVFFlatHIP", "read_index", "write_index", "train_index", "GeneratorHIP", "NSFGeneratorHIP",
-    "config_from_reference", "FrontHIP", "front_config_from_reference", "infer_hip", "retrieve_blend", "accelerate_synthesizer", "get_synthesizer", "load_synthesizer", "dist", "glue",
+    "config_from_reference", "FrontHIP", "front_config_from_reference", "infer_hip", "retrieve_blend", "accelerate_synthesizer", "get_synthesizer", "load_synthesizer", "dist", "glue", "install", "uninstall",
 ]

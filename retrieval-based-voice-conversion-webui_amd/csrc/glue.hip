@@ -1,10 +1,24 @@
 // C entry points of the device-resident glue; kernels in glue_kernels.hpp.
+#include <atomic>
 #include <cmath>
 
 #include "common.hpp"
 #include "glue_kernels.hpp"
 
 using namespace rvcmi;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: set it once for every device a call is made on (a process-global
+// flag would leave the second GPU of a multi-GPU process without it).
+template <typename K>
+static void ensure_dyn_lds(K kernel, int bytes, std::atomic<unsigned long long>& done_mask) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_mask.load(std::memory_order_acquire) & bit) return;
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done_mask.fetch_or(bit, std::memory_order_release);
+}
+static std::atomic<unsigned long long> g_attr_f0{0}, g_attr_sola{0};
 
 extern "C" {
 
@@ -25,19 +39,18 @@ int rvcmi_glue_rmvpe_f0(const float* salience, int n, int nbins, float thred, in
     return guarded([&] {
         if (!salience || !scratch || !pitch || !pitchf || n < 1 || nbins < 1 || p_len < 1)
             RVCMI_FAIL(RVCMI_ERR_INVALID, "rmvpe_f0: bad argument");
-        const size_t smem = (size_t)(n + p_len) * sizeof(double);
-        if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_NOMEM, "rmvpe_f0: %d + %d frames exceed the single-block f0 pass (20480)", n, p_len);
+        // work arrays: LDS when (n + p_len) doubles fit, else global (scratch in place + the pitch buffer) -- no length limit
+        size_t smem = (size_t)(n + p_len) * sizeof(double);
+        const bool in_lds = smem <= 160 * 1024;
+        if (!in_lds) smem = 0;
         hipStream_t st = (hipStream_t)stream;
         hipLaunchKernelGGL(k_rmvpe_decode, dim3((n + 3) / 4), dim3(256), 0, st, salience, n, nbins, thred, scratch);
-        static bool attr = false;
-        if (!attr) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f0_post), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr = true;
-        }
+        ensure_dyn_lds(k_f0_post, 160 * 1024, g_attr_f0);
         // the host evaluates the scalars exactly as the reference does (python floats / math.log, rvc/f0/gen.py:18, 70-73)
         const double key_mul = std::pow(2.0, (double)f0_up_key / 12.0);
         const double mel_min = 1127.0 * std::log(1.0 + 50.0 / 700.0), mel_max = 1127.0 * std::log(1.0 + 1100.0 / 700.0);
-        hipLaunchKernelGGL(k_f0_post, dim3(1), dim3(256), smem, st, scratch, n, p_len, 1, 1, key_mul, mel_min, mel_max, pitch, pitchf);
+        hipLaunchKernelGGL(k_f0_post, dim3(1), dim3(256), smem, st, scratch, n, p_len, 1, 1, key_mul, mel_min, mel_max, pitch, pitchf,
+                           in_lds ? nullptr : scratch, in_lds ? nullptr : reinterpret_cast<double*>(pitch));
         HIP_CHECK(hipGetLastError());
     });
 }
@@ -45,16 +58,14 @@ int rvcmi_glue_rmvpe_f0(const float* salience, int n, int nbins, float thred, in
 int rvcmi_glue_f0_post(const double* f0, int n, int f0_up_key, int64_t* pitch, float* pitchf, void* stream) {
     return guarded([&] {
         if (!f0 || !pitch || !pitchf || n < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "f0_post: bad argument");
-        const size_t smem = (size_t)(2 * n) * sizeof(double);
-        if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_NOMEM, "f0_post: %d frames exceed the single-block f0 pass (10240)", n);
-        static bool attr = false;
-        if (!attr) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_f0_post), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr = true;
-        }
+        size_t smem = (size_t)(2 * n) * sizeof(double);
+        const bool in_lds = smem <= 160 * 1024;
+        if (!in_lds) smem = 0;
+        ensure_dyn_lds(k_f0_post, 160 * 1024, g_attr_f0);
         const double key_mul = std::pow(2.0, (double)f0_up_key / 12.0);
         const double mel_min = 1127.0 * std::log(1.0 + 50.0 / 700.0), mel_max = 1127.0 * std::log(1.0 + 1100.0 / 700.0);
-        hipLaunchKernelGGL(k_f0_post, dim3(1), dim3(256), smem, (hipStream_t)stream, f0, n, n, 0, 0, key_mul, mel_min, mel_max, pitch, pitchf);
+        hipLaunchKernelGGL(k_f0_post, dim3(1), dim3(256), smem, (hipStream_t)stream, f0, n, n, 0, 0, key_mul, mel_min, mel_max, pitch, pitchf,
+                           (double*)nullptr, in_lds ? nullptr : reinterpret_cast<double*>(pitch));
         HIP_CHECK(hipGetLastError());
     });
 }
@@ -81,11 +92,7 @@ int rvcmi_glue_sola(const float* infer_wav, int64_t n, float* sola_buffer, int L
                        block_frame, Lb);
         const size_t smem = (size_t)(2 * Lb + Ls) * sizeof(float);
         if (smem > 150 * 1024) RVCMI_FAIL(RVCMI_ERR_NOMEM, "sola: buffer + search window too large");
-        static bool attr = false;
-        if (!attr) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sola), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));  // + 2 KB static
-            attr = true;
-        }
+        ensure_dyn_lds(k_sola, 150 * 1024, g_attr_sola);  // + 2 KB static
         hipLaunchKernelGGL(k_sola, dim3(1), dim3(256), smem, (hipStream_t)stream, infer_wav, sola_buffer, Lb, Ls, fade_in, fade_out,
                            block_frame, out_block, offset_out);
         HIP_CHECK(hipGetLastError());

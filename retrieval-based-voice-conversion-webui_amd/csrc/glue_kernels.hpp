@@ -124,18 +124,23 @@ static __global__ void __launch_bounds__(256) k_rmvpe_decode(const float* __rest
 
 // _resize_f0 (np.interp with NaN for unvoiced, f0.py:68-78) -> _interpolate_f0 (f0.py:31-66, sequential, with its
 // aliasing quirks) -> post_process (gen.py:18,34-41).  Single block; src [n] fp64 -> pitch [p_len] int64, pitchf [p_len] fp32.
-// Dynamic LDS: (n + p_len) doubles.
-static __global__ void __launch_bounds__(256) k_f0_post(const double* __restrict__ src, int n, int p_len, int do_resize,
+// Work arrays a [n] and r [p_len] (fp64): dynamic LDS when they fit (<= 20480 frames), otherwise the caller's global
+// buffers ga / gr -- a whole file's f0 is computed in ONE call by the reference (pipeline.py:260-266; a 3-minute song is
+// ~36k frames), so there must be no length limit.  ga may alias src (in-place NaN marking); gr may be the `pitch` output
+// buffer itself (same size: the last loop reads r[i] and writes pitch[i] from the same thread).
+static __global__ void __launch_bounds__(256) k_f0_post(const double* src, int n, int p_len, int do_resize,
                                                         int do_interp, double key_mul, double mel_min, double mel_max,
-                                                        int64_t* __restrict__ pitch, float* __restrict__ pitchf) {
+                                                        int64_t* pitch, float* __restrict__ pitchf, double* ga, double* gr) {
 #pragma clang fp contract(off)
     extern __shared__ double sm[];
-    double* a = sm;       // [n]   source with NaN for unvoiced
-    double* r = sm + n;   // [p_len]
+    double* a = ga ? ga : sm;           // [n]   source with NaN for unvoiced
+    double* r = gr ? gr : sm + n;       // [p_len]
     const double NaN = __longlong_as_double(0x7ff8000000000000LL);
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double v = src[i];
-        a[i] = (do_resize && v < 0.001) ? NaN : v;
+    if (do_resize) {
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const double v = src[i];
+            a[i] = v < 0.001 ? NaN : v;
+        }
     }
     __syncthreads();
     if (do_resize) {
@@ -199,7 +204,7 @@ static __global__ void __launch_bounds__(256) k_f0_post(const double* __restrict
     }
     __syncthreads();
     for (int i = threadIdx.x; i < p_len; i += 256) {
-        const double f = r[i] * key_mul;  // np.multiply(f0, pow(2, f0_up_key / 12))
+        const double f = r[i] * key_mul;  // np.multiply(f0, pow(2, f0_up_key / 12))   (read BEFORE pitch[i] is written: gr may alias it)
         double mel = 1127.0 * log(1.0 + f / 700.0);
         if (mel > 0.0) mel = (mel - mel_min) * 254.0 / (mel_max - mel_min) + 1.0;
         if (mel <= 1.0) mel = 1.0;

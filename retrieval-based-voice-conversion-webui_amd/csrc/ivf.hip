@@ -460,11 +460,12 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
 // 345 registers, ran one block per CU and turned the clip's 599 query blocks into three serial rounds of HBM-latency-bound
 // work; at 32 lanes per row every block of the launch is resident at once.
 template <int VL, int LPR, int RU>
-__global__ void __launch_bounds__(256) k_scan_v(const float* __restrict__ q, const int64_t* __restrict__ assign, int nprobe,
+// q and bfeats are NOT __restrict__: the fused blend runs in place (rvcmi_ivf_search_blend passes the same buffer for both).
+__global__ void __launch_bounds__(256) k_scan_v(const float* q, const int64_t* __restrict__ assign, int nprobe,
                                                    const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
                                                    const float* __restrict__ vecs, int64_t nq, int k, float* __restrict__ D,
                                                    int64_t* __restrict__ I, int64_t* __restrict__ P, int* __restrict__ any_short,
-                                                   float* __restrict__ bfeats, float rate, float omr, int64_t pos_last) {
+                                                   float* bfeats, float rate, float omr, int64_t pos_last) {
     constexpr int d = LPR * 4 * VL;
     __shared__ float bd[KMAX];      // fused blend (bfeats != nullptr): the query's k results, by rank
     __shared__ long long bp[KMAX];

@@ -49,21 +49,29 @@ def _as_reference_subclass(new, old):
     ref_cls = type(old)
     name = type(new).__name__
     try:
-        dyn = type(name, (type(new), ref_cls), {"__init__": lambda self, *a, **k: None})
+        # __call__: the reference classes override it with a fixed signature (rvc/layers/nsf.py:136-143) that would come
+        # first in the MRO and reject the HIP module's extra keyword (``noise=``); route calls straight to nn.Module's.
+        dyn = type(name, (type(new), ref_cls), {"__init__": lambda self, *a, **k: None, "__call__": torch.nn.Module.__call__})
         new.__class__ = dyn
     except TypeError:
         pass
     return new
 
 
-def get_synthesizer(cpt, device=torch.device("cpu"), operand: str = "fp16"):
-    from rvc.synthesizer import get_synthesizer as _ref_get  # the reference's own loader
+def _reference_get_synthesizer():
+    """The reference's own loader (rvc/synthesizer.py:10); after ``rvc_amd.install()`` rebinds that name, the original."""
+    import rvc.synthesizer as rs
 
-    net_g, cpt = _ref_get(cpt, device)
+    fn = rs.get_synthesizer
+    return getattr(fn, "_rvcmi_original", fn)
+
+
+def get_synthesizer(cpt, device=torch.device("cpu"), operand: str = "fp16", front: bool = True):
+    net_g, cpt = _reference_get_synthesizer()(cpt, device)
     if torch.device(device).type == "cuda":
-        accelerate_synthesizer(net_g, device, operand)
+        accelerate_synthesizer(net_g, device, operand, front=front)
     return net_g, cpt
 
 
-def load_synthesizer(pth_path, device=torch.device("cpu"), operand: str = "fp16"):
-    return get_synthesizer(torch.load(pth_path, map_location=torch.device("cpu"), weights_only=True), device, operand)
+def load_synthesizer(pth_path, device=torch.device("cpu"), operand: str = "fp16", front: bool = True):
+    return get_synthesizer(torch.load(pth_path, map_location=torch.device("cpu"), weights_only=True), device, operand, front)

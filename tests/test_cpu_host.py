@@ -205,3 +205,40 @@ def test_infer_hip_orchestration_against_reference_golden_on_cpu(name):
                                 opt("return_length2"), noise_zp=torch.from_numpy(d["noise_zp"]), noise_dec=torch.from_numpy(d["noise_dec"]))
     assert out.shape == d["out"].shape
     assert np.abs(out.numpy() - d["out"]).max() < 2e-5
+
+
+def test_install_rebinds_names_without_editing_the_callers():
+    """rvc_amd.install() on the compute-free RVC skeleton (tests/skeleton): names bound before and after the call, the faiss
+    shim behind `import faiss`, and a clean uninstall.  (Device work is covered by tests/test_gpu_dropin.py.)"""
+    import sys
+
+    skel = os.path.join(os.path.dirname(os.path.abspath(__file__)), "skeleton")
+    if os.path.isdir(os.path.join(os.environ.get("RVC_REFERENCE", "/root/reference"), "rvc")):
+        for m in [m for m in sys.modules if m.split(".")[0] in ("rvc", "infer")]:
+            del sys.modules[m]  # a previous test imported the real reference package
+    had_faiss = sys.modules.get("faiss")
+    sys.path.insert(0, skel)
+    try:
+        import infer.modules.vc.modules as vm
+        import rvc.synthesizer as rs
+
+        orig = rs.get_synthesizer
+        rvc_amd.install()
+        rvc_amd.install()
+        assert rs.get_synthesizer is not orig and rs.get_synthesizer._rvcmi_original is orig
+        assert vm.get_synthesizer is rs.get_synthesizer and vm.load_synthesizer is rs.load_synthesizer
+        import infer.modules.vc.pipeline as pl
+
+        assert type(pl.faiss).__name__ == "_FaissShim"
+        with pytest.raises(rvc_amd.RvcmiError):
+            pl.load_index("/nonexistent/added.index")  # routed to the HIP reader (which fails loudly)
+        if had_faiss is None:
+            with pytest.raises(AttributeError, match="faiss is not installed"):
+                pl.faiss.index_factory
+        rvc_amd.uninstall()
+        assert rs.get_synthesizer is orig and vm.get_synthesizer is orig and sys.modules.get("faiss") is had_faiss
+    finally:
+        rvc_amd.uninstall()
+        sys.path.remove(skel)
+        for m in [m for m in sys.modules if m.split(".")[0] in ("rvc", "infer")]:
+            del sys.modules[m]

@@ -217,3 +217,53 @@ def test_front_full_clip_size_vs_oracle_and_windowed_waveform(gpu):
     y = ref[0, 0, m * cfg.upp:(m + b - a) * cfg.upp]
     ew = rms(x, y)
     assert ew <= 1e-3, "full-size whole infer (window %d..%d): waveform RMS error %.3e" % (a, b, ew)
+
+
+def test_whole_infer_full_clip_voiced_vs_oracle(gpu):
+    """BASELINE configs[1] end to end: the whole ``infer`` (front + generator on HIP) over one 10 s clip with VOICED pitch
+    (80 % of the 1198 frames) against oracle front + oracle generator -- the complete waveform, no window."""
+    import rvc_amd
+
+    T = 1198
+    fcfg, cfg = FrontConfig(), nsf_oracle.CONFIGS["v2_48k"]
+    wf, wd = synth.make_front_weights(fcfg, 1234), synth.make_dec_weights(cfg, 1234)
+    phone, pitchf = synth.make_phone(1, T, 768, 1234), synth.make_f0(1, T)
+    pitch = synth.make_pitch(pitchf)
+    assert float((pitchf > 0).float().mean()) > 0.5
+    lengths, sid = torch.tensor([T]), torch.tensor([0])
+    nz = torch.randn(1, 192, T, generator=torch.Generator().manual_seed(8))
+    noise = nsf_oracle.reference_noise(1, T, cfg.upp, 114514)
+    with torch.no_grad():
+        zr, m1, g = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, nz)
+        ref = nsf_oracle.generator_forward(cfg, wd, zr * m1, pitchf, g, noise)
+    fr = hip_front(fcfg, wf, "fp16", gpu, max_B=1, max_T=T)
+    dec = rvc_amd.NSFGeneratorHIP(vars(cfg), wd, device=gpu, operand="fp16", max_B=1, max_T=T)
+    z = fr(phone.to(gpu), pitch.to(gpu), lengths.to(gpu), g.to(gpu), 0, noise=nz.to(gpu))
+    out = dec(z, pitchf.to(gpu), g.to(gpu), noise=noise.to(gpu)).cpu()
+    e = rms(out, ref)
+    assert e <= 1e-3, "whole infer, full voiced clip: waveform RMS error %.3e" % e
+
+
+def test_front_batch_16_equals_single_clips(gpu):
+    """The large-batch launch shapes of the front (64-row tiles, pick_nj) at B = 16, T = 1198 with ragged lengths: every item
+    must equal the same clip run alone (tile height changes no element's summation order)."""
+    B, T = 16, 1198
+    fcfg = FrontConfig()
+    wf = synth.make_front_weights(fcfg, 1234)
+    phone, pitchf = synth.make_phone(B, T, 768, 1234), synth.make_f0(B, T)
+    pitch = synth.make_pitch(pitchf)
+    lengths = torch.tensor([T - 31 * b for b in range(B)])
+    sid = torch.arange(B) % 7
+    nz = torch.randn(B, 192, T, generator=torch.Generator().manual_seed(8))
+    g = wf["emb_g.weight"][sid].unsqueeze(-1)
+    fr = hip_front(fcfg, wf, "fp16", gpu, max_B=B, max_T=T)
+    z = fr(phone.to(gpu), pitch.to(gpu), lengths.to(gpu), g.to(gpu), 0, noise=nz.to(gpu))
+    assert z.shape == (B, 192, T) and torch.isfinite(z).all()
+    for b in (0, 5, 15):
+        one = fr(phone[b:b + 1].to(gpu), pitch[b:b + 1].to(gpu), lengths[b:b + 1].to(gpu), g[b:b + 1].to(gpu), 0, noise=nz[b:b + 1].to(gpu))
+        e = rms(one[0].cpu(), z[b].cpu())
+        assert e <= 1e-6, "front batch item %d differs from its single-clip result: %.3e" % (b, e)
+        assert float(z[b, :, int(lengths[b]):].abs().max()) == 0.0  # masked tail
+    with torch.no_grad():
+        zr, m1, _ = front_oracle.infer_front(fcfg, wf, phone[15:16], pitch[15:16], lengths[15:16], sid[15:16], nz[15:16])
+    assert rms(z[15:16].cpu(), zr * m1) <= Z_BAR["fp16"]

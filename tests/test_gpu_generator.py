@@ -207,3 +207,71 @@ def test_smoke_entry_point(gpu):
     import __graft_entry__
 
     __graft_entry__.smoke()
+
+
+def _full_clip_inputs():
+    """bench.py's exact inputs: synth.make_dec_inputs(cfg, 1, 1198, 1234) (80 % voiced f0) and the reference's noise seed."""
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    w = synth.make_dec_weights(cfg, 1234)
+    z, f0, g = synth.make_dec_inputs(cfg, 1, 1198, 1234)
+    noise = nsf_oracle.reference_noise(1, 1198, cfg.upp, 114514)
+    return cfg, w, z, f0, g, noise
+
+
+def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
+    """BASELINE configs[1]: the WHOLE 10 s clip (T = 1198, voiced) against (a) the waveform the real reference produced
+    (fixture full_v2_48k_T1198_voiced, oracle/make_golden.py:dec_full_case) and (b) the oracle run here, plus the `har`
+    tap: with T > 256 every thread of k_phase_scan scans several frames and the running phase crosses waves through
+    LDS -- with non-zero increments, which the f0 = 0 locality test cannot exercise."""
+    import hashlib
+
+    import rvc_amd
+
+    cfg, w, z, f0, g, noise = _full_clip_inputs()
+    d = load_golden("full_v2_48k_T1198_voiced")
+    sha = lambda t: hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+    assert synth.weights_sha256(w) == d["weights_sha256"]
+    assert sha(z) + sha(f0) + sha(g) + sha(noise) == str(d["inputs_sha256"]), "seeded inputs differ from the fixture's"
+    assert float((f0 > 0).float().mean()) > 0.5
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=1, max_T=1198)
+    zd, fd, gd, nd = z.to(gpu), f0.to(gpu), g.to(gpu), noise.to(gpu)
+    out = gen(zd, fd, gd, noise=nd).cpu()
+    assert out.shape == d["out"].shape and torch.isfinite(out).all()
+    e_ref = rms(out, d["out"])
+    assert e_ref <= 1e-3, "whole 10 s clip vs the reference waveform: RMS %.3e" % e_ref
+    taps = {}
+    with torch.no_grad():
+        ora = nsf_oracle.generator_forward(cfg, w, z, f0, g, noise, taps=taps)
+    assert rms(ora, d["out"]) <= 2e-6  # the oracle reproduces the reference at full size on this host too
+    assert rms(out, ora) <= 1e-3
+    har = gen.debug_tap("har", zd, fd, gd, noise=nd)
+    rel = rms(har, taps["har"]) / float(taps["har"].pow(2).mean().sqrt())
+    assert rel <= 1e-6, "har (sine source over 1198 voiced frames): relative RMS %.2e" % rel
+    # exact-fp32 path on the same clip
+    gen32 = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp32", max_B=1, max_T=1198)
+    assert rms(gen32(zd, fd, gd, noise=nd).cpu(), d["out"]) <= 2e-5
+
+
+def test_batch_16_full_clips_equal_their_single_clip_results(gpu):
+    """BASELINE configs[2] geometry (grid.z = batch, multi-GB streams, the large-batch launch shapes): 16 different full-size
+    voiced clips in one call; every item must be BIT-equal to the same clip run alone, and item 0 must meet the parity bar
+    against the reference golden."""
+    import rvc_amd
+
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    w = synth.make_dec_weights(cfg, 1234)
+    B, T = 16, 1198
+    zs, fs, gs, ns = [], [], [], []
+    for b in range(B):
+        z, f0, g = synth.make_dec_inputs(cfg, 1, T, 1234 + b)
+        zs.append(z), fs.append(torch.roll(f0, 37 * b, dims=1)), gs.append(g)
+        ns.append(nsf_oracle.reference_noise(1, T, cfg.upp, 114514 + b))
+    Z, F, G, N = torch.cat(zs).to(gpu), torch.cat(fs).to(gpu), torch.cat(gs).to(gpu), torch.cat(ns).to(gpu)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T)
+    out = gen(Z, F, G, noise=N)
+    assert out.shape == (B, 1, T * cfg.upp) and torch.isfinite(out).all()
+    d = load_golden("full_v2_48k_T1198_voiced")
+    assert rms(out[0:1].cpu(), d["out"]) <= 1e-3
+    for b in (0, 1, 7, 15):
+        one = gen(Z[b:b + 1].contiguous(), F[b:b + 1].contiguous(), G[b:b + 1].contiguous(), noise=N[b:b + 1].contiguous())
+        assert torch.equal(one[0], out[b]), "batch item %d differs from its single-clip result" % b

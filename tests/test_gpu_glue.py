@@ -46,6 +46,31 @@ def test_f0_post_only(gpu):
         assert np.allclose(pitchf[0].cpu().numpy(), ref_f.astype(np.float32), rtol=1e-6, atol=0)
 
 
+def test_f0_chain_has_no_length_limit(gpu):
+    """The reference computes f0 ONCE for the whole file (pipeline.py:260-266, 100 frames/s): a 6-minute file is 36 000
+    frames.  Beyond 20 480 frames the sequential pass keeps its work arrays in global memory instead of LDS."""
+    import rvc_amd
+
+    rng = np.random.default_rng(9)
+    n, p_len = 36000, 36011
+    sal = (rng.random((n, 360), dtype=np.float32) * 0.02).astype(np.float32)
+    centre = (150 + 100 * np.sin(np.arange(n) / 40.0)).astype(int)
+    voiced = (np.arange(n) % 300) >= 45
+    voiced[-200:] = False  # trailing unvoiced run (the interpolation's tail branch)
+    for w_ in range(-4, 5):
+        sal[np.arange(n)[voiced], centre[voiced] + w_] += np.float32(0.9 * np.exp(-0.5 * (w_ / 2.0) ** 2))
+    ref_p, ref_f = glue_oracle.rmvpe_f0(sal, p_len, 3, 0.03)
+    pitch, pitchf = rvc_amd.glue.rmvpe_f0(torch.from_numpy(sal).to(gpu), p_len, 3, 0.03)
+    assert np.allclose(pitchf[0].cpu().numpy(), ref_f, rtol=1e-6, atol=0)
+    assert np.array_equal(pitch[0].cpu().numpy(), ref_p)
+    f0 = rng.uniform(40, 1300, 30000)
+    f0[rng.random(30000) < 0.2] = 0.0
+    ref_c, ref_f2 = glue_oracle.post_process(f0.copy(), -4)
+    pitch2, pitchf2 = rvc_amd.glue.f0_post(torch.from_numpy(f0).to(gpu), -4)
+    assert np.array_equal(pitch2[0].cpu().numpy(), ref_c.astype(np.int64))
+    assert np.allclose(pitchf2[0].cpu().numpy(), ref_f2.astype(np.float32), rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("use_index,protect,p_len", [(True, 0.33, 117), (True, 0.5, 120), (False, 0.2, 120), (False, 0.5, 101), (True, 0.0, 1)])
 def test_retrieve_blend_expand_matches_pipeline_expression(use_index, protect, p_len, gpu):
     """search + blend + x2 + protect mix in one pass == the pipeline.py:118-159 expression evaluated with torch-CPU on the
