@@ -398,7 +398,7 @@ def main():
     assert torch.isfinite(out_holder["o"]).all(), "non-finite generator output"
 
     # ---- stability report: R more repetitions of the same K-step loop (same step, same graph), per-rank wall clock ----
-    reps = None
+    rep_stats = None
     if a.repeats > 0:
         rt = []
         for _ in range(a.repeats):
@@ -409,14 +409,14 @@ def main():
             torch.cuda.synchronize()
             rt.append(1e3 * (time.perf_counter() - t1) / a.steps)
         rts = sorted(rt)
-        reps = {"n": a.repeats, "steps_each": a.steps, "ms_per_step_median": rts[len(rts) // 2], "ms_per_step_min": rts[0],
+        rep_stats = {"n": a.repeats, "steps_each": a.steps, "ms_per_step_median": rts[len(rts) // 2], "ms_per_step_min": rts[0],
                 "ms_per_step_max": rts[-1], "ms_per_step_all": [round(x, 4) for x in rt]}
         if use_dist:  # per-rank medians, so that the line shows every rank ran (min / max over ranks)
-            tm = torch.tensor([reps["ms_per_step_median"]], device=dev, dtype=torch.float64)
+            tm = torch.tensor([rep_stats["ms_per_step_median"]], device=dev, dtype=torch.float64)
             lo, hi = tm.clone(), tm.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            reps["rank_median_ms_min_max"] = [float(lo.item()), float(hi.item())]
+            rep_stats["rank_median_ms_min_max"] = [float(lo.item()), float(hi.item())]
 
     # ---- roofline leg: the same step, eager, every kernel bracketed by HIP events --------------
     roof = None
@@ -550,8 +550,8 @@ def main():
             line["cpu_baseline"] = cpu
         if tgpu is not None:
             line["gpu_torch_baseline"] = tgpu
-        if reps is not None:
-            line["repeats"] = reps
+        if rep_stats is not None:
+            line["repeats"] = rep_stats
         print(json.dumps(line))
     if use_dist:
         dist.barrier()  # the other ranks wait for rank 0's untimed roofline / whole-infer legs before tearing RCCL down

@@ -12,9 +12,9 @@ import sys
 from typing import List
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librvcmi.so")
+LIB_PATH = os.environ.get("RVCMI_LIB") or os.path.join(_HERE, "librvcmi.so")  # RVCMI_LIB: dev A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["nsf.hip", "ivf.hip", "front.hip", "glue.hip"]
+SOURCES = ["nsf.hip", "rb_stream.hip", "ivf.hip", "front.hip", "glue.hip"]
 
 RVCMI_MAX_UPS, RVCMI_MAX_RB, RVCMI_MAX_DIL = 8, 4, 4
 OPERANDS = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2}

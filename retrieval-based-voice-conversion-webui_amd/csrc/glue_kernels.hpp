@@ -11,6 +11,8 @@
 // float64 (the whole f0 chain), fp32 with contraction off wherever torch computes in float32.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "exact_fp.hpp"
 #include <stdint.h>
 
 namespace rvcmi {
@@ -32,18 +34,18 @@ static __global__ void __launch_bounds__(256) k_blend_expand(const float* __rest
     float w[8];
     if (blend) {
         for (int s = 0; s < k; ++s) {
-            const float inv = __fdiv_rn(1.0f, D[qi * k + s]);
-            w[s] = __fmul_rn(inv, inv);
+            const float inv = div_rn(1.0f, D[qi * k + s]);
+            w[s] = mul_rn(inv, inv);
         }
         float sum;
         if (k == 8) {
-            sum = __fadd_rn(__fadd_rn(__fadd_rn(w[0], w[1]), __fadd_rn(w[2], w[3])),
-                            __fadd_rn(__fadd_rn(w[4], w[5]), __fadd_rn(w[6], w[7])));
+            sum = add_rn(add_rn(add_rn(w[0], w[1]), add_rn(w[2], w[3])),
+                            add_rn(add_rn(w[4], w[5]), add_rn(w[6], w[7])));
         } else {
             sum = w[0];
-            for (int s = 1; s < k; ++s) sum = __fadd_rn(sum, w[s]);
+            for (int s = 1; s < k; ++s) sum = add_rn(sum, w[s]);
         }
-        for (int s = 0; s < k; ++s) w[s] = __fdiv_rn(w[s], sum);
+        for (int s = 0; s < k; ++s) w[s] = div_rn(w[s], sum);
     }
     for (int e = threadIdx.x; e < d; e += 256) {
         const float f = feats[qi * d + e];
@@ -53,10 +55,10 @@ static __global__ void __launch_bounds__(256) k_blend_expand(const float* __rest
             for (int s = 0; s < k; ++s) {
                 int64_t p = P[qi * k + s];
                 if (p < 0) p = pos_last;
-                const float prod = __fmul_rn(vecs[p * d + e], w[s]);
-                acc = s == 0 ? prod : __fadd_rn(acc, prod);
+                const float prod = mul_rn(vecs[p * d + e], w[s]);
+                acc = s == 0 ? prod : add_rn(acc, prod);
             }
-            x = __fadd_rn(__fmul_rn(acc, rate), __fmul_rn(omr, f));
+            x = add_rn(mul_rn(acc, rate), mul_rn(omr, f));
         }
         for (int r = 0; r < reps; ++r) {
             const int64_t t = qi * reps + r;
@@ -64,7 +66,7 @@ static __global__ void __launch_bounds__(256) k_blend_expand(const float* __rest
             float o = x;
             if (pitchf) {
                 const float pf = pitchf[t] < 1.f ? protect : 1.f;  // pitchff[pitchf > 0] = 1; pitchff[pitchf < 1] = protect
-                o = __fadd_rn(__fmul_rn(x, pf), __fmul_rn(f, __fsub_rn(1.f, pf)));
+                o = add_rn(mul_rn(x, pf), mul_rn(f, sub_rn(1.f, pf)));
             }
             out[t * d + e] = o;
         }
@@ -112,8 +114,8 @@ static __global__ void __launch_bounds__(256) k_rmvpe_decode(const float* __rest
         }
         // numpy pairwise sum of 9 elements: 8 accumulators combined as a tree, then the 9th
         const double ps = (((prod[0] + prod[1]) + (prod[2] + prod[3])) + ((prod[4] + prod[5]) + (prod[6] + prod[7]))) + prod[8];
-        const float ws = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(wv[0], wv[1]), __fadd_rn(wv[2], wv[3])),
-                                             __fadd_rn(__fadd_rn(wv[4], wv[5]), __fadd_rn(wv[6], wv[7]))), wv[8]);
+        const float ws = add_rn(add_rn(add_rn(add_rn(wv[0], wv[1]), add_rn(wv[2], wv[3])),
+                                             add_rn(add_rn(wv[4], wv[5]), add_rn(wv[6], wv[7]))), wv[8]);
         double cents = ps / (double)ws;
         if (best <= thred) cents = 0.0;
         double hz = 10.0 * pow(2.0, cents / 1200.0);
@@ -245,7 +247,7 @@ static __global__ void __launch_bounds__(256) k_scale_int16_range(float* __restr
     double mi = 32768.0;
     if (amax > 1.0) mi /= amax;
     const float sc = (float)mi;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = __fmul_rn(x[i], sc);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = mul_rn(x[i], sc);
 }
 
 // SOLA (gui.py:1057-1090, "SOLA algorithm from DDSP-SVC"): find the offset in [0, Ls] at which the new chunk best continues
@@ -275,7 +277,7 @@ static __global__ void __launch_bounds__(256) k_sola(const float* __restrict__ x
             nom += v * (double)bs[i];
             en += v * v;
         }
-        const float r = __fdiv_rn((float)nom, sqrtf(__fadd_rn((float)en, 1e-8f)));
+        const float r = div_rn((float)nom, sqrtf(add_rn((float)en, 1e-8f)));
         if (r > best) {
             best = r;
             bo = o;
@@ -299,7 +301,7 @@ static __global__ void __launch_bounds__(256) k_sola(const float* __restrict__ x
     if (threadIdx.x == 0 && offset_out) *offset_out = off;
     auto y = [&](int p) {  // the shifted, cross-faded chunk at position p
         const float v = x[off + p];
-        return p < Lb ? __fadd_rn(__fmul_rn(v, fade_in[p]), __fmul_rn(bs[p], fade_out[p])) : v;
+        return p < Lb ? add_rn(mul_rn(v, fade_in[p]), mul_rn(bs[p], fade_out[p])) : v;
     };
     for (int i = threadIdx.x; i < block; i += 256) out[i] = y(i);
     for (int i = threadIdx.x; i < Lb; i += 256) buf[i] = y(block + i);  // old tail is in LDS: safe to overwrite

@@ -565,28 +565,28 @@ __global__ void __launch_bounds__(256) k_scan_v(const float* q, const int64_t* _
         __syncthreads();
         float w[KMAX];
         for (int s = 0; s < k; ++s) {
-            const float inv = __fdiv_rn(1.0f, bd[s]);
-            w[s] = __fmul_rn(inv, inv);
+            const float inv = div_rn(1.0f, bd[s]);
+            w[s] = mul_rn(inv, inv);
         }
         float sum;
         if (k == 8) {
-            sum = __fadd_rn(__fadd_rn(__fadd_rn(w[0], w[1]), __fadd_rn(w[2], w[3])),
-                            __fadd_rn(__fadd_rn(w[4], w[5]), __fadd_rn(w[6], w[7])));
+            sum = add_rn(add_rn(add_rn(w[0], w[1]), add_rn(w[2], w[3])),
+                            add_rn(add_rn(w[4], w[5]), add_rn(w[6], w[7])));
         } else {
             sum = w[0];
-            for (int s = 1; s < k; ++s) sum = __fadd_rn(sum, w[s]);
+            for (int s = 1; s < k; ++s) sum = add_rn(sum, w[s]);
         }
-        for (int s = 0; s < k; ++s) w[s] = __fdiv_rn(w[s], sum);
+        for (int s = 0; s < k; ++s) w[s] = div_rn(w[s], sum);
         for (int e = threadIdx.x; e < d; e += 256) {
             float acc = 0.f;
             for (int s = 0; s < k; ++s) {
                 long long p = bp[s];
                 if (p < 0) p = pos_last;
-                const float prod = __fmul_rn(vecs[p * d + e], w[s]);
-                acc = s == 0 ? prod : __fadd_rn(acc, prod);
+                const float prod = mul_rn(vecs[p * d + e], w[s]);
+                acc = s == 0 ? prod : add_rn(acc, prod);
             }
             const float f = bfeats[qi * d + e];
-            bfeats[qi * d + e] = __fadd_rn(__fmul_rn(acc, rate), __fmul_rn(omr, f));
+            bfeats[qi * d + e] = add_rn(mul_rn(acc, rate), mul_rn(omr, f));
         }
     }
 }
@@ -605,28 +605,28 @@ __global__ void __launch_bounds__(256) k_blend(float* __restrict__ feats, const 
     const int64_t qi = blockIdx.x;
     float w[KMAX];
     for (int s = 0; s < k; ++s) {
-        const float inv = __fdiv_rn(1.0f, D[qi * k + s]);
-        w[s] = __fmul_rn(inv, inv);
+        const float inv = div_rn(1.0f, D[qi * k + s]);
+        w[s] = mul_rn(inv, inv);
     }
     float sum;
     if (k == 8) {
-        sum = __fadd_rn(__fadd_rn(__fadd_rn(w[0], w[1]), __fadd_rn(w[2], w[3])),
-                        __fadd_rn(__fadd_rn(w[4], w[5]), __fadd_rn(w[6], w[7])));
+        sum = add_rn(add_rn(add_rn(w[0], w[1]), add_rn(w[2], w[3])),
+                        add_rn(add_rn(w[4], w[5]), add_rn(w[6], w[7])));
     } else {
         sum = w[0];
-        for (int s = 1; s < k; ++s) sum = __fadd_rn(sum, w[s]);
+        for (int s = 1; s < k; ++s) sum = add_rn(sum, w[s]);
     }
-    for (int s = 0; s < k; ++s) w[s] = __fdiv_rn(w[s], sum);
+    for (int s = 0; s < k; ++s) w[s] = div_rn(w[s], sum);
     for (int e = threadIdx.x; e < d; e += 256) {
         float acc = 0.f;
         for (int s = 0; s < k; ++s) {
             int64_t p = P[qi * k + s];
             if (p < 0) p = pos_last;
-            const float prod = __fmul_rn(vecs[p * d + e], w[s]);
-            acc = s == 0 ? prod : __fadd_rn(acc, prod);
+            const float prod = mul_rn(vecs[p * d + e], w[s]);
+            acc = s == 0 ? prod : add_rn(acc, prod);
         }
         const float f = feats[qi * d + e];
-        feats[qi * d + e] = __fadd_rn(__fmul_rn(acc, rate), __fmul_rn(omr, f));
+        feats[qi * d + e] = add_rn(mul_rn(acc, rate), mul_rn(omr, f));
     }
 }
 

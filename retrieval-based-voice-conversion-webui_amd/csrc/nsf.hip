@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "nsf_kernels.hpp"
 #include "conv_pack.hpp"
+#include "rb_stream.hpp"
 
 namespace rvcmi {
 
@@ -505,6 +506,57 @@ static void set_lds_rbf() {
 }
 
 // Fill the common part of ConvArgs for `L` and launch it in the handle's operand mode.
+// RVCMI_RB_STREAM: unset = auto (streaming kernel when the strips are long enough), 1 = always when supported, 0 = never.
+static int rb_stream_mode() {
+    const char* e = getenv("RVCMI_RB_STREAM");
+    if (!e || !e[0]) return 2;
+    return e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
+}
+
+// Whole resblocks of a stage on the streaming kernel (ND = 3).  Fills src[j] with the output streams on success.
+static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int L, int B, int nk, const float** src, hipStream_t st) {
+    const int mode = rb_stream_mode();
+    if (mode == 0 || op == RVCMI_OPERAND_F32 || nk > 3) return false;
+    for (int j = 0; j < nk; ++j)
+        if (s.rb[j].size() != 3) return false;
+    if (!rb_stream_supported(op, C, 3)) return false;
+    RbStreamDesc sd[3];
+    int order[3];
+    for (int j = 0; j < nk; ++j) order[j] = j;
+    std::sort(order, order + nk, [&](int a1, int b1) { return s.rb[a1][0].first.ntaps[0] > s.rb[b1][0].first.ntaps[0]; });
+    double flops = 0, bytes = 0;
+    for (int oj = 0; oj < nk; ++oj) {
+        const int j = order[oj];
+        RbStreamDesc& d = sd[oj];
+        memset(&d, 0, sizeof(d));
+        d.src = h->X0.as<float>();
+        d.dst = h->Ya[j].as<float>();
+        d.k = s.rb[j][0].first.ntaps[0];
+        d.k_p = s.rb[j][0].first.ntaps_p;
+        d.ct1 = s.rb[j][0].first.ct_stride;
+        d.ct2 = s.rb[j][0].second.ct_stride;
+        for (int m = 0; m < 3; ++m) {
+            const ConvLayer& c1 = s.rb[j][m].first;
+            const ConvLayer& c2 = s.rb[j][m].second;
+            d.w1[m] = c1.w_pack.p;
+            d.w2[m] = c2.w_pack.p;
+            d.b1[m] = c1.bias.as<float>();
+            d.b2[m] = c2.bias.as<float>();
+            d.dil[m] = c1.dstep;
+            flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
+            bytes += 2.0 * d.k * C * C * 2;
+        }
+        bytes += (double)B * L * C * 8;
+    }
+    char nm[48];
+    snprintf(nm, sizeof(nm), "rb_stream_c%d", C);
+    if (!rb_stream_launch(op, C, 3, sd, nk, L, B, (long)L * C, mode == 1, st, true)) return false;
+    h->prof.launch(nm, flops, bytes, st, [&] { rb_stream_launch(op, C, 3, sd, nk, L, B, (long)L * C, mode == 1, st); });
+    HIP_CHECK(hipGetLastError());
+    for (int j = 0; j < nk; ++j) src[j] = h->Ya[j].as<float>();
+    return true;
+}
+
 static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const char* name, hipStream_t st) {
     a.cin = L.cin;
     a.cout = L.cout;
@@ -830,6 +882,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     run_conv(h, s.rb[j][m].second, a, B, nm, st);
                     src[j] = dst;
                 }
+        } else if (try_rb_stream_full(h, s, op, C, (int)L, B, nk, src, st)) {
+            // streaming fused resblocks (rb_stream_kernels.hpp): persistent blocks walk strips of the time axis
         } else if (C <= 64 && maxnd <= 3 && !getenv("RVCMI_NO_RBFULL")) {
             // whole resblocks fused (x resident in registers): ONE launch for the stage   residuals.py:68-85
             snprintf(nm, sizeof(nm), "rb_full_c%d", C);
@@ -968,7 +1022,22 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     HIP_CHECK(hipMemsetAsync(h->dbg.p, 0, nblk * NWp * 64, st));
                     ra.ts = h->dbg.as<unsigned long long>();
                 }
-                h->prof.launch(nm, flops, bytes, st, [&] { launch_rb_pair(op, C, ra, max_tiles, nj, B, max_rows, st); });
+                bool streamed = false;
+                if (rb_stream_mode() != 0 && rb_stream_supported(op, C, 1)) {
+                    RbStreamDesc sd[RVCMI_MAX_RB];
+                    for (int q = 0; q < nj; ++q) {
+                        const RbJob& J = ra.job[q];
+                        memset(&sd[q], 0, sizeof(sd[q]));
+                        sd[q].src = J.src; sd[q].dst = J.dst; sd[q].w1[0] = J.w1; sd[q].w2[0] = J.w2; sd[q].b1[0] = J.b1; sd[q].b2[0] = J.b2;
+                        sd[q].ct1 = J.ct1; sd[q].ct2 = J.ct2; sd[q].k = J.k; sd[q].k_p = J.k_p; sd[q].dil[0] = J.dil;
+                    }
+                    char nms[48];
+                    snprintf(nms, sizeof(nms), "rb_stream1_c%d", C);
+                    const bool force = rb_stream_mode() == 1;
+                    if (rb_stream_launch(op, C, 1, sd, nj, (int)L, B, L * C, force, st, true))
+                        h->prof.launch(nms, flops, bytes, st, [&] { streamed = rb_stream_launch(op, C, 1, sd, nj, (int)L, B, L * C, force, st); });
+                }
+                if (!streamed) h->prof.launch(nm, flops, bytes, st, [&] { launch_rb_pair(op, C, ra, max_tiles, nj, B, max_rows, st); });
                 if ((ra.dbg & 32) && m == 0) {  // dev only: per-phase cycles of pair level 0, per kernel size
                     HIP_CHECK(hipStreamSynchronize(st));
                     std::vector<unsigned long long> ts(nblk * NWp * 8);

@@ -14,6 +14,8 @@
 //   stage mean, post, tanh rvc/layers/nsf.py:186-189
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "exact_fp.hpp"
 #include <stdint.h>
 
 namespace rvcmi {
@@ -48,8 +50,8 @@ static __global__ void __launch_bounds__(256) k_phase_scan(const float* __restri
     const int end = min(n, beg + per);
     double local = 0.0;
     for (int t = beg; t < end; ++t) {
-        float rad = __fmul_rn(__fdiv_rn(f[t], sr), upp);
-        float w = __fsub_rn(fmodf(__fadd_rn(rad, 0.5f), 1.0f), 0.5f);
+        float rad = mul_rn(div_rn(f[t], sr), upp);
+        float w = sub_rn(fmodf(add_rn(rad, 0.5f), 1.0f), 0.5f);
         local += (double)w;
     }
     // inclusive wave scan of the per-thread sums, then the waves' totals through LDS
@@ -64,8 +66,8 @@ static __global__ void __launch_bounds__(256) k_phase_scan(const float* __restri
     for (int w = 0; w < wave; ++w) run += wsum[w];
     if (tid == 0) ph[0] = 0.f;
     for (int t = beg; t < end; ++t) {
-        float rad = __fmul_rn(__fdiv_rn(f[t], sr), upp);
-        float w = __fsub_rn(fmodf(__fadd_rn(rad, 0.5f), 1.0f), 0.5f);
+        float rad = mul_rn(div_rn(f[t], sr), upp);
+        float w = sub_rn(fmodf(add_rn(rad, 0.5f), 1.0f), 0.5f);
         run += (double)w;
         ph[t + 1] = fmodf((float)run, 1.0f);
     }
@@ -81,13 +83,13 @@ static __global__ void __launch_bounds__(256) k_sine_source(const float* __restr
     size_t frame = i / (size_t)upp;  // b*T + t
     int n = (int)(i - frame * upp) + 1;
     float f = f0[frame];
-    float rad = __fadd_rn(__fmul_rn(__fdiv_rn(f, sr), (float)n), phase[frame]);
-    float s = __fmul_rn(sinf(__fmul_rn(6.2831855f, rad)), 0.1f);
+    float rad = add_rn(mul_rn(div_rn(f, sr), (float)n), phase[frame]);
+    float s = mul_rn(sinf(mul_rn(6.2831855f, rad)), 0.1f);
     float uv = f > 0.f ? 1.f : 0.f;
-    float amp = f > 0.f ? 0.003f : __fdiv_rn(0.1f, 3.0f);
+    float amp = f > 0.f ? 0.003f : div_rn(0.1f, 3.0f);
     float nz = noise ? noise[i] : 0.f;
-    float v = __fadd_rn(__fmul_rn(s, uv), __fmul_rn(amp, nz));
-    har[i] = tanhf(__fadd_rn(__fmul_rn(v, lw), lb));
+    float v = add_rn(mul_rn(s, uv), mul_rn(amp, nz));
+    har[i] = tanhf(add_rn(mul_rn(v, lw), lb));
 }
 
 // F.interpolate(mode="linear", align_corners=False) along the last axis of [rows][Lin] -> [rows][Lout]

@@ -1,0 +1,231 @@
+// Launch side of k_rb_stream: strip planning (how many persistent blocks per resblock, how long their strips) and the
+// per-channel-count instantiations.  See rb_stream_kernels.hpp for the kernel and tools/model_rb_stream.py for its model.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <array>
+#include <cstdlib>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "common.hpp"
+#include "rb_stream.hpp"
+#include "rb_stream_kernels.hpp"
+
+namespace rvcmi {
+
+namespace {
+
+struct Geo {
+    int MI, NJ, NCO, bpc;  // bpc = blocks per CU (one wave per SIMD: NCO * bpc = 4)
+};
+// Time tiles per wave: 6 (R = 192 rows per step) for the one-tile-of-channels waves, 3 (R = 96) for C = 256: everything
+// stays in registers.  The larger alternatives 8 / 4 spill 100-400 registers per step (outside the K loops) and measured
+// slower (C = 128: 0.88 vs 0.76 ms per clip); RVCMI_RS_SMALL=0 selects them for A/B runs.
+bool small_tiles() {
+    const char* e = getenv("RVCMI_RS_SMALL");
+    return !(e && e[0] == '0');
+}
+bool geo_for(int C, int nd, Geo& g) {
+    const bool sm = small_tiles();
+    if (C == 256 && nd == 1) { g = {2, sm ? 3 : 4, 4, 1}; return true; }
+    if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1}; return true; }
+    // C = 64 / 32 (two / four blocks per CU) were built and measured: a pair-step holds too little MFMA work for one wave
+    // per SIMD (0.58 vs 0.40 ms and 0.49 vs 0.26 ms per clip against k_rb_full), so they are not instantiated.
+    return false;
+}
+
+int num_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    int v = cached[dev & 63].load();
+    if (!v) {
+        hipDeviceProp_t p;
+        HIP_CHECK(hipGetDeviceProperties(&p, dev));
+        v = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+        cached[dev & 63].store(v);
+    }
+    return v;
+}
+
+template <typename OpT, int C, int MI, int NJ, int NCO, int ND>
+void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    auto kern = &k_rb_stream<OpT, C, MI, NJ, NCO, ND, 4, 2>;
+    if (!(attr_done.load() & bit)) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done.fetch_or(bit);
+    }
+    hipLaunchKernelGGL(kern, dim3(nblocks, 1, B), dim3(64 * NCO), smem, st, a);
+}
+
+template <typename OpT>
+void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
+    if (C == 256 && nd == 1 && NJ == 4) return launch_inst<OpT, 256, 2, 4, 4, 1>(a, nblocks, B, smem, st);
+    if (C == 256 && nd == 1 && NJ == 3) return launch_inst<OpT, 256, 2, 3, 4, 1>(a, nblocks, B, smem, st);
+    if (C == 128 && nd == 3 && NJ == 8) return launch_inst<OpT, 128, 1, 8, 4, 3>(a, nblocks, B, smem, st);
+    if (C == 128 && nd == 3 && NJ == 6) return launch_inst<OpT, 128, 1, 6, 4, 3>(a, nblocks, B, smem, st);
+    RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: no instantiation for C=%d nd=%d", C, nd);
+}
+
+}  // namespace
+
+bool rb_stream_supported(int operand, int C, int nd) {
+    Geo g;
+    return operand != RVCMI_OPERAND_F32 && geo_for(C, nd, g);
+}
+
+bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B, long bstride, bool force,
+                      hipStream_t st, bool dry_run) {
+    Geo g;
+    if (operand == RVCMI_OPERAND_F32 || !geo_for(C, nd, g) || njobs < 1 || njobs > 3) return false;
+    const int R = 32 * g.NJ;
+    RbStreamArgs a;
+    memset(&a, 0, sizeof(a));
+    a.njobs = njobs;
+    a.L = L;
+    a.bstride = bstride;
+    // blocks available to one utterance, shared by the resblocks
+    const int slots = std::max(njobs, num_cus() * g.bpc / std::max(1, B));
+    int nblocks = 0, side_rows = 0, min_steps = 1 << 30;
+    int warm[3] = {0, 0, 0};
+    for (int j = 0; j < njobs; ++j) {
+        const RbStreamDesc& d = jobs[j];
+        RbStreamJob& J = a.job[j];
+        J.src = d.src;
+        J.dst = d.dst;
+        J.ct1 = d.ct1;
+        J.ct2 = d.ct2;
+        J.k = d.k;
+        J.k_p = d.k_p;
+        const int p2 = (d.k - 1) / 2;
+        int sx = 0;
+        warm[j] = 32 * nd + nd * p2;
+        for (int m = 0; m < nd; ++m) {
+            J.w1[m] = d.w1[m];
+            J.w2[m] = d.w2[m];
+            J.b1[m] = d.b1[m];
+            J.b2[m] = d.b2[m];
+            J.dil[m] = d.dil[m];
+            const int p1 = d.dil[m] * (d.k - 1) / 2;
+            if (p1 + p2 > 32 || 2 * p2 > RS_HROW || 32 + p1 - p2 > RS_HEAD - RS_HROW || p1 + p2 + d.dil[m] - 32 > RS_SLACK)
+                return false;  // halo larger than the 32-row lag / the head room of the tile: not this kernel
+            warm[j] += p1;
+            J.sx_off[m] = sx;
+            sx += 32 + p1 - p2;
+        }
+        for (int m = 0; m < nd; ++m) {
+            J.sh_off[m] = sx;
+            sx += 2 * p2;
+        }
+        side_rows = std::max(side_rows, sx);
+    }
+    // Strips.  A block's time is steps x (per-step cost), steps = ceil((rows + warm-up) / R) and the per-step cost measured with
+    // the phase stamps is ~ (k + 4.4) units (14.8k + 3.4k * k cycles per pair-step at C = 128): choose the number of strips of
+    // every resblock so that the slowest block finishes earliest (brute force over the splits of the slots; cached).
+    int nst[3] = {1, 1, 1};
+    {
+        struct Key { int C, nd, L, slots, R, k[3], n; };
+        static std::mutex mu;
+        static std::vector<std::pair<Key, std::array<int, 3>>> cache;
+        Key key{C, nd, L, slots, R, {jobs[0].k, njobs > 1 ? jobs[1].k : 0, njobs > 2 ? jobs[2].k : 0}, njobs};
+        bool hit = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& e : cache)
+                if (!memcmp(&e.first, &key, sizeof(Key))) { nst[0] = e.second[0]; nst[1] = e.second[1]; nst[2] = e.second[2]; hit = true; break; }
+        }
+        if (!hit) {
+            const int maxn = std::max(1, L / R);
+            auto tcost = [&](int j, int n) {
+                const int rows = (L + n - 1) / n;
+                const int steps = (rows + warm[j] + R - 1) / R;
+                return steps * (jobs[j].k + 4.4);
+            };
+            double best = 1e300;
+            const int lim0 = std::min(maxn, slots - (njobs - 1));
+            for (int n0 = 1; n0 <= lim0; ++n0) {
+                if (njobs == 1) {
+                    const double t = tcost(0, n0);
+                    if (t < best) { best = t; nst[0] = n0; }
+                    continue;
+                }
+                const int lim1 = std::min(maxn, slots - n0 - (njobs - 2));
+                for (int n1 = 1; n1 <= lim1; ++n1) {
+                    double t = std::max(tcost(0, n0), tcost(1, n1));
+                    if (t >= best) continue;
+                    if (njobs == 2) { best = t; nst[0] = n0; nst[1] = n1; continue; }
+                    const int n2 = std::min(maxn, slots - n0 - n1);
+                    if (n2 < 1) continue;
+                    t = std::max(t, tcost(2, n2));
+                    if (t < best) { best = t; nst[0] = n0; nst[1] = n1; nst[2] = n2; }
+                }
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (cache.size() > 64) cache.clear();
+            cache.push_back({key, {nst[0], nst[1], nst[2]}});
+        }
+    }
+    for (int j = 0; j < njobs; ++j) {
+        RbStreamJob& J = a.job[j];
+        const int rows = (L + nst[j] - 1) / nst[j];
+        const int steps = (rows + warm[j] + R - 1) / R;
+        const int len = std::max(rows, steps * R - warm[j]);
+        J.strip_len = len;
+        J.nstrips = (L + len - 1) / len;
+        J.blk0 = nblocks;
+        nblocks += J.nstrips;
+        min_steps = std::min(min_steps, steps);
+    }
+    a.side_rows = side_rows;
+    // auto mode: only where the persistent walk measured faster than the tile kernels -- C = 128 (whole resblocks) from 4 steps
+    // per block; C = 256 (pair level) only with long strips (large batches).
+    if (!force && min_steps < (C == 128 ? 4 : 8)) return false;
+    const size_t smem = (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
+    if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large (C=%d)", smem, C);
+    if (dry_run) return true;
+    // dev only: RVCMI_RS_STAMPS=1 prints the per-phase cycle breakdown of every launch (synchronises; never set it in a timed run)
+    static const bool want_stamps = getenv("RVCMI_RS_STAMPS") && getenv("RVCMI_RS_STAMPS")[0] == '1';
+    unsigned long long* ts = nullptr;
+    const size_t nts = (size_t)nblocks * B * g.NCO * 16;
+    if (want_stamps) {
+        HIP_CHECK(hipMalloc(&ts, nts * 8));
+        HIP_CHECK(hipMemsetAsync(ts, 0, nts * 8, st));
+        a.ts = ts;
+    }
+    if (operand == RVCMI_OPERAND_BF16) launch_t<__bf16>(C, nd, g.NJ, a, nblocks, B, smem, st);
+    else launch_t<_Float16>(C, nd, g.NJ, a, nblocks, B, smem, st);
+    if (want_stamps) {
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(nts);
+        HIP_CHECK(hipMemcpy(h.data(), ts, nts * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(ts);
+        static const char* names[10] = {"phaseA", "barA", "conv1", "bar1", "phaseB", "barB", "conv2", "bar2", "xload", "store"};
+        for (int j = 0; j < njobs; ++j) {
+            double sum[10] = {0}, steps = 0, tot_max = 0;
+            long cnt = 0;
+            for (size_t w = 0; w < (size_t)nblocks * B * g.NCO; ++w) {
+                const unsigned long long* p = &h[w * 16];
+                if ((int)p[11] != j || !p[10]) continue;
+                double tot = 0;
+                for (int i = 0; i < 10; ++i) { sum[i] += (double)p[i]; tot += (double)p[i]; }
+                tot_max = std::max(tot_max, tot);
+                steps += (double)p[10];
+                ++cnt;
+            }
+            if (!cnt) continue;
+            fprintf(stderr, "[rs stamps] C=%d nd=%d NJ=%d k=%d strips=%d len=%d steps/blk=%.1f  cycles per PAIR-step:", C, nd, g.NJ, a.job[j].k,
+                    a.job[j].nstrips, a.job[j].strip_len, steps / cnt);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f", names[i], sum[i] / (steps * nd));
+            fprintf(stderr, " | per step: xload %.0f store %.0f | slowest wave total %.0f cycles\n", sum[8] / steps, sum[9] / steps, tot_max);
+        }
+    }
+    return true;
+}
+
+}  // namespace rvcmi

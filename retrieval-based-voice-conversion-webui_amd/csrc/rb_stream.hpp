@@ -1,0 +1,27 @@
+// Host interface of the streaming fused ResBlock kernel (rb_stream_kernels.hpp); implemented in rb_stream.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rvcmi {
+
+struct RbStreamDesc {  // one resblock (ND = 3: all its pairs) or one pair level of it (ND = 1)
+    const float* src;
+    float* dst;
+    const void* w1[3];
+    const void* w2[3];
+    const float* b1[3];
+    const float* b2[3];
+    long ct1, ct2;
+    int k, k_p;
+    int dil[3];
+};
+
+// Channel counts / fusion depths the kernel is instantiated for.
+bool rb_stream_supported(int operand, int C, int nd);
+// Plans strips for `B` utterances of `L` rows and launches ONE kernel covering all `njobs` resblocks.  Returns false
+// (nothing launched) when the strips would be too short for the persistent walk to pay and `force` is not set.
+// `dry_run`: plan only (same return value), launch nothing.
+bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B, long bstride, bool force,
+                      hipStream_t st, bool dry_run = false);
+
+}  // namespace rvcmi

@@ -1,0 +1,311 @@
+// Streaming fused ResBlock1 (rvc/layers/residuals.py:68-85) for gfx950: a persistent block walks a STRIP of consecutive
+// time rows of one (utterance, resblock) and keeps every halo on the CU, so nothing is re-read or re-computed:
+//
+//   * the block advances R = 32*NJ rows per step; per (conv1, conv2) pair m it holds in LDS the last Hx_m = 32 + p1 - p2
+//     activated input rows ("X history") and the last 2*p2 activated h rows ("H history") of the previous step;
+//   * each pair's output window lags its input window by exactly 32 rows (>= p1 + p2, the rows a pair cannot produce
+//     yet).  32 rows = one MFMA column tile, so the fp32 residual  x' = conv2(h) + x  needs no data movement: output tile
+//     jt adds input tile jt-1, which the SAME lane of the same wave already holds in registers (tile NJ-1 is carried to
+//     the next step).  The fp32 residual stream therefore never leaves the register file between the pairs;
+//   * with ND = 3 all pairs of a resblock run back to back on the resident rows: ONE read and ONE write of the stream
+//     per resblock, no overlap-save recomputation (k_rb_full computes R rows to keep R - 2*HL).  With ND = 1 the same
+//     code is the pair-level kernel for channel counts whose three histories do not fit (C = 256).
+//
+// One wave per SIMD (512 registers): waves split OUTPUT CHANNELS only (NCO slices of 32*MI), all on the same time
+// window, so the residual tile shift never crosses a wave.  LDS: one operand tile M of HEAD + R rows used alternately as
+// X (new rows at HEAD) and H (new rows at HROW), the per-pair history side buffers, and the biases.
+//
+// The schedule (row arithmetic, masks, history copies, tile shift) is modelled line by line in tools/model_rb_stream.py
+// and checked there against a direct evaluation of the resblock.
+#pragma once
+#include "nsf_kernels.hpp"
+
+namespace rvcmi {
+
+constexpr int RS_HEAD = 62;   // first M row of the new X rows: 2*p2 (<= 10) rows of H head + Hx (<= 52) rows of X head in front
+constexpr int RS_HROW = 10;   // first M row of the new H rows
+constexpr int RS_SLACK = 4;   // zero rows behind the tile: the last padded tap of conv1 may read p1 + p2 + dil - 32 <= 3 rows beyond
+constexpr int RS_MAXND = 3;
+
+struct RbStreamJob {
+    const float* src;
+    float* dst;
+    const void* w1[RS_MAXND];
+    const void* w2[RS_MAXND];
+    const float* b1[RS_MAXND];
+    const float* b2[RS_MAXND];
+    long ct1, ct2;       // packed elements per 32-channel output tile
+    int k, k_p;          // real / padded taps
+    int dil[RS_MAXND];
+    int blk0;            // first blockIdx.x of this job
+    int nstrips;
+    int strip_len;       // output rows per strip
+    int sx_off[RS_MAXND];  // LDS row offset of pair m's X history inside the side area
+    int sh_off[RS_MAXND];  // ... and of its H history
+};
+struct RbStreamArgs {
+    RbStreamJob job[3];
+    int njobs;
+    int L;
+    long bstride;
+    int side_rows;  // rows of the side area (max over jobs)
+    unsigned long long* ts;  // dev only (RVCMI_RS_STAMPS=1): per-wave cycle sums per phase, [block][wave][16]
+};
+
+// cooperative LDS -> LDS copy of `rows` operand rows (whole 16-byte words, pad included)
+// (a batched variant -- 4 reads in flight, then 4 predicated writes -- measured SLOWER: phase A 3.5k -> 5.7k cycles)
+template <int STRIDE, int NT>
+__device__ __forceinline__ void rs_copy_rows(char* dst, const char* src, int rows) {
+    constexpr int W = STRIDE / 16;
+    const int total = rows * W;
+    for (int i = threadIdx.x; i < total; i += NT) *(uint4*)(dst + (size_t)i * 16) = *(const uint4*)(src + (size_t)i * 16);
+}
+
+template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG, int NB>
+static __global__ void __launch_bounds__(64 * NCO, 1) k_rb_stream(RbStreamArgs a) {
+    using TL = Tile<C>;
+    using frag = typename Op<OpT>::frag;
+    using o4 = __attribute__((ext_vector_type(4))) OpT;
+    constexpr int STRIDE = TL::STRIDE;
+    constexpr int NT = 64 * NCO;
+    constexpr int R = 32 * NJ;
+    constexpr int CP = 32 * MI * NCO;
+    static_assert(CP == C, "waves must tile the channels exactly");
+    constexpr int MROWS = RS_HEAD + R + RS_SLACK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* M = smem;
+    char* side = smem + (size_t)MROWS * STRIDE;
+    // after the side area: one dump row (discarded history writes), then the biases [ND][2][CP]
+    char* dump = side + (size_t)a.side_rows * STRIDE;
+    float* bias_l = (float*)(dump + STRIDE);
+
+    // ---- which job / strip ------------------------------------------------------------------------------------------
+    int ji = 0;
+#pragma unroll
+    for (int j = 1; j < 3; ++j)
+        if (j < a.njobs && (int)blockIdx.x >= a.job[j].blk0) ji = j;
+    const RbStreamJob& J = a.job[ji];
+    const int strip = (int)blockIdx.x - J.blk0;
+    if (strip >= J.nstrips) return;
+    const int b = blockIdx.z;
+    const float* src = J.src + (size_t)b * a.bstride;
+    float* dst = J.dst + (size_t)b * a.bstride;
+    const int L = a.L;
+    const int S0 = strip * J.strip_len;
+    const int S1 = min(L, S0 + J.strip_len);
+    const int p2 = (J.k - 1) / 2;
+    int HL = ND * p2;
+#pragma unroll
+    for (int m = 0; m < ND; ++m) HL += J.dil[m] * (J.k - 1) / 2;
+    const int r0 = S0 - HL;                                       // first row loaded by step 0
+    const int nsteps = (S1 - r0 + 32 * ND + R - 1) / R;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ct0 = wave * MI;               // first 32-channel output tile of this wave
+    const int half4 = 4 * (lane >> 5);
+    const int lrow = lane & 31;
+
+    // ---- zero the whole LDS image once (histories start empty, slack rows stay zero), stage the biases ----------------
+    {
+        const int total16 = (int)(((size_t)(MROWS + a.side_rows + 1) * STRIDE) / 16);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < total16; i += NT) *(uint4*)(smem + (size_t)i * 16) = z;
+        for (int i = threadIdx.x; i < ND * 2 * CP; i += NT) {
+            const int m = i / (2 * CP), w = (i / CP) & 1, c = i % CP;
+            bias_l[i] = (w ? J.b2[m] : J.b1[m])[c];
+        }
+    }
+
+    // dev-only phase timing: wave-uniform s_memtime deltas summed over all steps / pairs (scalar registers)
+    unsigned long long tprev = 0, tsum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool stamps = a.ts != nullptr;
+    auto stamp = [&](int ph) {
+        if (stamps) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            tsum[ph] += t - tprev;
+            tprev = t;
+        }
+    };
+    if (stamps) tprev = __builtin_readcyclecounter();
+
+    f32x16 carry[ND][MI];
+#pragma unroll
+    for (int m = 0; m < ND; ++m)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) carry[m][mi][e] = 0.f;
+
+    frag A[NB][KG][MI];  // weight register ring, requested one phase ahead of its use
+    conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w1[0] + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p);
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        // ---- load the next R rows of x straight into the accumulator layout (clamped addresses, masked values) -------
+        f32x16 xin[MI][NJ];
+        {
+            const int w0 = r0 + step * R;
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                const int tg = w0 + jt * 32 + lrow;
+                const unsigned msk = (tg >= 0 && tg < L) ? 0xffffffffu : 0u;
+                const int tgc = min(max(tg, 0), L - 1);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = *(const f32x4*)(src + (size_t)tgc * C + (ct0 + mi) * 32 + 8 * g + half4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xin[mi][jt][4 * g + e] = mask_bits(v[e], msk);
+                    }
+            }
+        }
+        stamp(8);  // x loads issued
+#pragma unroll
+        for (int m = 0; m < ND; ++m) {
+            const int dil = J.dil[m];
+            const int p1 = dil * (J.k - 1) / 2;
+            const int Hx = 32 + p1 - p2;
+            const int wm = r0 - 32 * m + step * R;  // global row of xin tile 0 / row 0
+            const bool interior = wm - 32 >= 0 && wm + R <= L;  // block-uniform: every row of the X and H windows is inside the utterance
+            char* sideX = side + (size_t)J.sx_off[m] * STRIDE;
+            char* sideH = side + (size_t)J.sh_off[m] * STRIDE;
+            const OpT* w1l = (const OpT*)J.w1[m] + (size_t)ct0 * J.ct1 + lane * 8;
+            const OpT* w2l = (const OpT*)J.w2[m] + (size_t)ct0 * J.ct2 + lane * 8;
+
+            // ---- phase A: M <- [H head | X head | lrelu(x) new rows] ---------------------------------------------------
+            rs_copy_rows<STRIDE, NT>(M + (size_t)(RS_HEAD - Hx) * STRIDE, sideX, Hx);
+            rs_copy_rows<STRIDE, NT>(M + (size_t)(RS_HROW - 2 * p2) * STRIDE, sideH, 2 * p2);
+            {
+                unsigned rowmask[NJ];
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) {
+                    const int t = wm + jt * 32 + lrow;
+                    rowmask[jt] = (t >= 0 && t < L) ? 0xffffffffu : 0u;
+                }
+                char* xw = M + (size_t)(RS_HEAD + lrow) * STRIDE + (ct0 * 32 + half4) * 2;
+                if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(xw, xin, rowmask);
+                else publish_operand<OpT, C, MI, NJ, STRIDE, true>(xw, xin, rowmask);
+            }
+            // residual tiles of this pair's output window (= input window - 32 rows): pure register renaming
+            f32x16 res[MI][NJ];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                res[mi][0] = carry[m][mi];
+#pragma unroll
+                for (int jt = 1; jt < NJ; ++jt) res[mi][jt] = xin[mi][jt - 1];
+                carry[m][mi] = xin[mi][NJ - 1];
+            }
+            stamp(0);  // phase A (waits for the x loads when m == 0)
+            __syncthreads();
+            stamp(1);
+
+            // ---- conv1 (dilated): h rows [a_m, a_m + R), a_m = wm - 32 + p2 ---------------------------------------------
+            f32x16 hacc[MI][NJ];
+            {
+                const float* bl = bias_l + (m * 2 + 0) * CP + ct0 * 32 + half4;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = *(const f32x4*)(bl + mi * 32 + 8 * g);
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hacc[mi][jt][4 * g + e] = bv[e];
+                    }
+            }
+            conv_run<OpT, C, MI, NJ, KG, NB>(hacc, A, M + (size_t)(RS_HEAD - Hx + lrow) * STRIDE + (lane >> 5) * 16, w1l, J.ct1, J.k_p, 0, dil);
+            conv_prefetch<OpT, C, MI, KG, NB>(A, w2l, J.ct2, J.k_p);  // in flight across the publish + barriers
+            stamp(2);  // conv1
+            __syncthreads();  // every wave is done reading X
+            stamp(3);
+
+            // ---- phase B: save the X tail, M <- lrelu(h) new rows (+ their tail into the H history) ----------------------
+            rs_copy_rows<STRIDE, NT>(sideX, M + (size_t)(RS_HEAD + R - Hx) * STRIDE, Hx);
+            {
+                const int am = wm - 32 + p2;
+                unsigned rowmask[NJ];
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) {
+                    const int t = am + jt * 32 + lrow;
+                    rowmask[jt] = (t >= 0 && t < L) ? 0xffffffffu : 0u;
+                }
+                char* hw = M + (size_t)(RS_HROW + lrow) * STRIDE + (ct0 * 32 + half4) * 2;
+                if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(hw, hacc, rowmask);
+                else publish_operand<OpT, C, MI, NJ, STRIDE, true>(hw, hacc, rowmask);
+                // the last 2*p2 rows of the new h rows are next step's H head
+                const int srow = lrow - (32 - 2 * p2);
+                char* tw = (srow >= 0 ? sideH + (size_t)srow * STRIDE : dump) + (ct0 * 32 + half4) * 2;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        o4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = to_op<OpT>(mask_bits(lrelu_max(hacc[mi][NJ - 1][4 * g + e], 0.1f), rowmask[NJ - 1]));
+                        *(o4*)(tw + (mi * 32 + 8 * g) * 2) = o;
+                    }
+            }
+            stamp(4);  // phase B
+            __syncthreads();
+            stamp(5);
+
+            // ---- conv2 accumulates onto the residual: x' rows [wm - 32, wm - 32 + R) ------------------------------------
+            {
+                const float* bl = bias_l + (m * 2 + 1) * CP + ct0 * 32 + half4;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = *(const f32x4*)(bl + mi * 32 + 8 * g);
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) res[mi][jt][4 * g + e] += bv[e];
+                    }
+            }
+            conv_run<OpT, C, MI, NJ, KG, NB>(res, A, M + (size_t)(RS_HROW - 2 * p2 + lrow) * STRIDE + (lane >> 5) * 16, w2l, J.ct2, J.k_p, 0, 1);
+            {  // next conv1's weights (next pair, or pair 0 of the next step)
+                const int mn = (m + 1 < ND) ? m + 1 : 0;
+                conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w1[mn] + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p);
+            }
+            stamp(6);  // conv2
+            __syncthreads();  // every wave is done reading H
+            stamp(7);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) xin[mi][jt] = res[mi][jt];
+        }
+        // ---- store the rows of this strip ------------------------------------------------------------------------------
+        {
+            const int wout = r0 - 32 * ND + step * R;
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                const int tg = wout + jt * 32 + lrow;
+                if (tg >= S0 && tg < S1) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = {xin[mi][jt][4 * g + 0], xin[mi][jt][4 * g + 1], xin[mi][jt][4 * g + 2], xin[mi][jt][4 * g + 3]};
+                            *(f32x4*)(dst + (size_t)tg * C + (ct0 + mi) * 32 + 8 * g + half4) = v;
+                        }
+                }
+            }
+        }
+        stamp(9);  // stores issued
+    }
+    if (stamps && lane < 12) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v = (lane == i) ? tsum[i] : v;
+        if (lane == 10) v = (unsigned long long)nsteps;
+        if (lane == 11) v = (unsigned long long)ji;
+        a.ts[((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * NCO + wave) * 16 + lane] = v;
+    }
+}
+
+}  // namespace rvcmi

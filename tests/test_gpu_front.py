@@ -263,7 +263,8 @@ def test_front_batch_16_equals_single_clips(gpu):
         one = fr(phone[b:b + 1].to(gpu), pitch[b:b + 1].to(gpu), lengths[b:b + 1].to(gpu), g[b:b + 1].to(gpu), 0, noise=nz[b:b + 1].to(gpu))
         e = rms(one[0].cpu(), z[b].cpu())
         assert e <= 1e-6, "front batch item %d differs from its single-clip result: %.3e" % (b, e)
-        assert float(z[b, :, int(lengths[b]):].abs().max()) == 0.0  # masked tail
+        if int(lengths[b]) < T:
+            assert float(z[b, :, int(lengths[b]):].abs().max()) == 0.0  # masked tail
     with torch.no_grad():
         zr, m1, _ = front_oracle.infer_front(fcfg, wf, phone[15:16], pitch[15:16], lengths[15:16], sid[15:16], nz[15:16])
     assert rms(z[15:16].cpu(), zr * m1) <= Z_BAR["fp16"]

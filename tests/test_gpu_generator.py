@@ -149,13 +149,17 @@ def test_handle_rejects_bad_shapes_and_grows_its_workspace(gpu):
         rvc_amd.NSFGeneratorHIP(vars(cfg), bad, device=gpu)
 
 
-def test_full_clip_size_properties(gpu):
-    """BASELINE size (v2/48k, T = 1198 frames = one 10 s clip): determinism, batch independence and locality.
+@pytest.mark.parametrize("rb_stream", ["0", "1"])
+def test_full_clip_size_properties(rb_stream, gpu, monkeypatch):
+    """(Both ResBlock kernel families: RVCMI_RB_STREAM=0 the tile kernels, =1 the streaming kernel; a fixed choice, because
+    the launcher otherwise picks per clip length and the two families differ in the last fp32 bit of the residual add.)
+    BASELINE size (v2/48k, T = 1198 frames = one 10 s clip): determinism, batch independence and locality.
     Locality is the size-independent property of a conv stack: the waveform of frames [a, b) computed from the
     whole clip equals the one computed from a window with a receptive-field margin -- across completely different
     tile boundaries, phase offsets and grid sizes -- so it exercises every halo / tiling decision at full scale."""
     import rvc_amd
 
+    monkeypatch.setenv("RVCMI_RB_STREAM", rb_stream)
     cfg = nsf_oracle.CONFIGS["v2_48k"]
     w = synth.make_dec_weights(cfg, 1234)
     T = 1198
@@ -252,11 +256,16 @@ def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
     assert rms(gen32(zd, fd, gd, noise=nd).cpu(), d["out"]) <= 2e-5
 
 
-def test_batch_16_full_clips_equal_their_single_clip_results(gpu):
+@pytest.mark.parametrize("rb_stream", ["0", "1"])
+def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu, monkeypatch):
     """BASELINE configs[2] geometry (grid.z = batch, multi-GB streams, the large-batch launch shapes): 16 different full-size
-    voiced clips in one call; every item must be BIT-equal to the same clip run alone, and item 0 must meet the parity bar
-    against the reference golden."""
+    voiced clips in one call; every item must be BIT-equal to the same clip run alone -- with the ResBlock kernel family
+    pinned (tile kernels / streaming kernel, whose strip partition changes completely between B = 16 and B = 1) -- and item
+    0 must meet the parity bar against the reference golden.  Unpinned (the launcher's own choice) the two runs may pick
+    different families per stage and agree to fp32 rounding instead."""
     import rvc_amd
+
+    monkeypatch.setenv("RVCMI_RB_STREAM", rb_stream)
 
     cfg = nsf_oracle.CONFIGS["v2_48k"]
     w = synth.make_dec_weights(cfg, 1234)
@@ -275,3 +284,56 @@ def test_batch_16_full_clips_equal_their_single_clip_results(gpu):
     for b in (0, 1, 7, 15):
         one = gen(Z[b:b + 1].contiguous(), F[b:b + 1].contiguous(), G[b:b + 1].contiguous(), noise=N[b:b + 1].contiguous())
         assert torch.equal(one[0], out[b]), "batch item %d differs from its single-clip result" % b
+    monkeypatch.delenv("RVCMI_RB_STREAM")
+    auto = gen(Z, F, G, noise=N)
+    assert rms(auto.cpu(), out.cpu()) <= 5e-4  # different families: last-bit fp32 differences re-round some fp16 operands
+
+
+# ---- streaming fused ResBlock kernel (csrc/rb_stream_kernels.hpp) -------------------------------------------------------
+# At full clip size the launcher picks it by itself (the full-size tests above run it); RVCMI_RB_STREAM=1 forces it for
+# the small golden cases too (single short strips, sequence ends inside the first step), RVCMI_RS_SMALL=1 selects the
+# smaller time tiles.
+
+@pytest.mark.parametrize("small", ["0", "1"])
+@pytest.mark.parametrize("name", ["dec_v2_48k_B1_T70", "dec_v2_48k_B2_T24", "dec_v1_40k_B1_T20", "dec_v1_32k_B1_T16",
+                                  "dec_nof0_v2_48k_B1_T16", "dec_v1_40k_nres_T31"])
+def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu, monkeypatch):
+    monkeypatch.setenv("RVCMI_RB_STREAM", "1")
+    monkeypatch.setenv("RVCMI_RS_SMALL", small)
+    d = load_golden(name)
+    cfg, w = golden_config_and_weights(d)
+    for operand in ("fp16", "bf16"):
+        out = run_golden(d, cfg, w, operand, gpu)
+        assert torch.isfinite(out).all()
+        e = rms(out, d["out"])
+        assert e <= BAR[operand], "%s/%s (streaming resblocks): RMS error %.3e" % (name, operand, e)
+
+
+@pytest.mark.parametrize("small", ["0", "1"])
+def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu, monkeypatch):
+    """Forced onto a clip of 300 frames: hundreds of strips of one to three steps each (every strip boundary, warm-up
+    and tail case), batch of 2 with different inputs; per-stage taps and the waveform against the oracle."""
+    import rvc_amd
+
+    monkeypatch.setenv("RVCMI_RB_STREAM", "1")
+    monkeypatch.setenv("RVCMI_RS_SMALL", small)
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    w = synth.make_dec_weights(cfg, 31)
+    B, T = 2, 300
+    z, f0, g = synth.make_dec_inputs(cfg, B, T, 31)
+    noise = nsf_oracle.reference_noise(B, T, cfg.upp, 17)
+    taps = {}
+    with torch.no_grad():
+        ref = nsf_oracle.generator_forward(cfg, w, z, f0, g, noise, taps=taps)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T)
+    zd, fd, gd, nd = z.to(gpu), f0.to(gpu), g.to(gpu), noise.to(gpu)
+    out = gen(zd, fd, gd, noise=nd).cpu()
+    assert rms(out, ref) <= 1e-3, "streaming resblocks, T=300 B=2: %.3e" % rms(out, ref)
+    for k in ("stage0", "stage1", "stage2", "stage3"):
+        got = gen.debug_tap(k, zd, fd, gd, noise=nd)
+        exp = taps[k] * cfg.num_kernels
+        rel = rms(got, exp) / float(exp.pow(2).mean().sqrt())
+        assert rel <= 2e-3, "%s: relative RMS %.2e" % (k, rel)
+    monkeypatch.setenv("RVCMI_RB_STREAM", "0")  # and the tile kernels on the same input agree with it to operand rounding
+    out0 = gen(zd, fd, gd, noise=nd).cpu()
+    assert rms(out0, ref) <= 1e-3 and rms(out0, out) <= 5e-4
