@@ -61,7 +61,7 @@ void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStre
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.fetch_or(bit);
     }
-    hipLaunchKernelGGL(kern, dim3(nblocks, 1, B), dim3(64 * NCO), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(64 * NCO), smem, st, a);
 }
 
 template <typename OpT>
@@ -88,6 +88,7 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
     RbStreamArgs a;
     memset(&a, 0, sizeof(a));
     a.njobs = njobs;
+    a.B = B;
     a.L = L;
     a.bstride = bstride;
     // blocks available to one utterance, shared by the resblocks

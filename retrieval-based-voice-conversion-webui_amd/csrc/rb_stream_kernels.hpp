@@ -46,6 +46,7 @@ struct RbStreamJob {
 struct RbStreamArgs {
     RbStreamJob job[3];
     int njobs;
+    int B;          // utterances; the grid is (sum of nstrips) * B blocks
     int L;
     long bstride;
     int side_rows;  // rows of the side area (max over jobs)
@@ -79,15 +80,25 @@ static __global__ void __launch_bounds__(64 * NCO, 1) k_rb_stream(RbStreamArgs a
     char* dump = side + (size_t)a.side_rows * STRIDE;
     float* bias_l = (float*)(dump + STRIDE);
 
-    // ---- which job / strip ------------------------------------------------------------------------------------------
+    // ---- which job / utterance / strip ---------------------------------------------------------------------------------
+    // The launch is one 1-D grid of (strips of all jobs) x B blocks.  Hardware places block i on XCD i % 8; the logical
+    // order is JOB-major and each XCD takes one contiguous chunk of it, so an XCD's 4 MB L2 mostly serves ONE resblock's
+    // weights (2.2 MB at k = 11) instead of all three (4.1 MB: with the round-robin order the weight loads missed L2 and the
+    // kernel fetched 2.4x its activation bytes).  Placement only affects speed, never results.
+    int lb;
+    {
+        const int nb = (int)gridDim.x, q = nb >> 3, r = nb & 7, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
     int ji = 0;
 #pragma unroll
     for (int j = 1; j < 3; ++j)
-        if (j < a.njobs && (int)blockIdx.x >= a.job[j].blk0) ji = j;
+        if (j < a.njobs && lb >= a.job[j].blk0 * a.B) ji = j;
     const RbStreamJob& J = a.job[ji];
-    const int strip = (int)blockIdx.x - J.blk0;
-    if (strip >= J.nstrips) return;
-    const int b = blockIdx.z;
+    const int rem = lb - J.blk0 * a.B;
+    const int b = rem / J.nstrips;
+    const int strip = rem - b * J.nstrips;
+    if (b >= a.B) return;
     const float* src = J.src + (size_t)b * a.bstride;
     float* dst = J.dst + (size_t)b * a.bstride;
     const int L = a.L;
@@ -304,7 +315,7 @@ static __global__ void __launch_bounds__(64 * NCO, 1) k_rb_stream(RbStreamArgs a
         for (int i = 0; i < 12; ++i) v = (lane == i) ? tsum[i] : v;
         if (lane == 10) v = (unsigned long long)nsteps;
         if (lane == 11) v = (unsigned long long)ji;
-        a.ts[((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * NCO + wave) * 16 + lane] = v;
+        a.ts[((size_t)blockIdx.x * NCO + wave) * 16 + lane] = v;
     }
 }
 

@@ -40,3 +40,47 @@ for pm in sorted(glob.glob(os.path.join(root, "pmc*"))):
     print("%-60s " % "kernel" + " ".join("%18s" % n[-18:] for n in names))
     for k in sorted(agg, key=lambda k: -max(agg[k].values())):
         print("%-60s " % k[:60] + " ".join("%18.4g" % (agg[k][n] / max(1, cnt[(k, n)])) for n in names))
+
+# ---- machine-readable HBM-side traffic of the ResBlock kernels (bench.py reads profiles/rNN_pmc_traffic.json) ------------
+import json
+import re
+
+
+def logical(name):
+    m = re.search(r"k_rb_(pair|full|stream)I\w+?Li(\d+)E", name)
+    if not m:
+        return None
+    fam = {"pair": "rb_pair", "full": "rb_full", "stream": "rb_stream"}[m.group(1)]
+    if fam == "rb_stream" and re.search(r"k_rb_streamI\w+?Li\d+ELi\d+ELi\d+ELi\d+ELi1E", name):
+        fam = "rb_stream1"
+    return "%s_c%s" % (fam, m.group(2))
+
+
+vals = defaultdict(dict)
+for pm in sorted(glob.glob(os.path.join(root, "pmc*"))):
+    files = glob.glob(os.path.join(pm, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    acc, n = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(files[0])):
+        lg = logical(r["Kernel_Name"])
+        if lg and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE",
+                                        "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"):
+            acc[(lg, r["Counter_Name"])] += float(r["Counter_Value"])
+            n[(lg, r["Counter_Name"])] += 1
+    for (lg, c), v in acc.items():
+        vals[lg][c] = v / n[(lg, c)]
+out = {"source": "rocprofv3 --pmc passes of `bench.py --steps 5 --warmup 2 --graph 0` (tools/profile.sh); per-dispatch averages; "
+                 "bytes_per_launch = FETCH_SIZE KB x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE KB",
+       "kernels": {}}
+for lg, d in sorted(vals.items()):
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        e = {"fetch_size_kb": d["FETCH_SIZE"], "fetch_correction": 2.0, "write_size_kb": d["WRITE_SIZE"],
+             "bytes_per_launch": (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0}
+        for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"):
+            if c in d:
+                e[c] = d[c]
+        out["kernels"][lg] = e
+if out["kernels"]:
+    json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
+    print("== wrote pmc_traffic.json for", sorted(out["kernels"]))
