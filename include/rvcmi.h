@@ -264,6 +264,10 @@ int rvcmi_ivf_search_blend_expand(rvcmi_ivf* h, int64_t nq, const float* feats_d
 /* index.reconstruct_n(i0, n) -> out_host [n,d] rows in id order (pipeline.py:215).             */
 int rvcmi_ivf_reconstruct_n(const rvcmi_ivf* h, int64_t i0, int64_t n, float* out_host);
 
+/* Copies the packed index blob into caller-owned device memory (>= the size rvcmi_ivf_blob reports) on `stream`:
+ * the source buffer of the RCCL broadcast of rvc_amd.dist.broadcast_index, made by this library's own HIP runtime.  */
+int rvcmi_ivf_blob_copy(const rvcmi_ivf* h, void* dst_dev, size_t capacity, void* stream);
+
 /* The whole index as ONE device blob (header + centroids + offsets + ids + vectors) so that a
  * single RCCL broadcast replicates it across the GPUs of a node.                */
 int rvcmi_ivf_blob(const rvcmi_ivf* h, void** dev_ptr, size_t* bytes);

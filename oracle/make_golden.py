@@ -320,6 +320,19 @@ def glue_case(name: str = "glue_f0"):
     print("%-28s %d cases, oracle == reference bit-exact  (%d KB)" % (name, len(cases), os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
 
 
+def mute_case(name: str = "mute_hubert"):
+    """The only REAL HuBERT features in the reference checkout: logs/mute/3_feature{256,768}/mute.npy (149 frames of the
+    'mute' training clip).  Near-silence features are almost collinear and contain exact duplicate
+    rows -- the worst case for distance ties -- so retrieval tests build their index / queries from this distribution."""
+    out = {}
+    for dim in (256, 768):
+        a = np.load(os.path.join(REF, "logs", "mute", "3_feature%d" % dim, "mute.npy"))
+        assert a.shape == (149, dim) and a.dtype == np.float32
+        out["f%d" % dim] = a
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print("%-28s 149 real HuBERT rows x {256, 768}  (%d KB)" % (name, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
 def main_front():
     glue_case()
     front_case("front_v2_B2_T50", 2, 50, [50, 43])
@@ -334,6 +347,9 @@ def main():
     torch.set_num_threads(8)
     if os.environ.get("GOLDEN_ONLY_FULL"):
         return dec_full_case()
+    if os.environ.get("GOLDEN_ONLY_MUTE"):
+        return mute_case()
+    mute_case()
     main_front()
     if os.environ.get("GOLDEN_ONLY_FRONT"):
         return

@@ -196,6 +196,26 @@ def make_ivf(n: int, d: int, nlist: Optional[int] = None, seed: int = 4321, kmea
         src = rng.integers(0, n, size=dup)
         dst = rng.integers(0, n, size=dup)
         x[dst] = x[src]
+    return make_ivf_from_rows(x, nlist, rng, kmeans_iters)
+
+
+def make_mute_rows(feats: np.ndarray, copies: int = 40, jitter: float = 2e-3, seed: int = 5) -> np.ndarray:
+    """A training-set-like matrix with the REAL HuBERT distribution of the reference's mute clip (tests/golden/mute_hubert.npz):
+    the 149 rows, one exact second copy of them (exact distance ties between different ids, on top of the duplicate rows the
+    clip itself contains), and `copies - 2` jittered copies (near ties)."""
+    rng = np.random.default_rng(seed)
+    parts = [feats, feats.copy()]
+    for _ in range(max(0, copies - 2)):
+        parts.append((feats + jitter * rng.standard_normal(feats.shape, dtype=np.float32)).astype(np.float32))
+    x = np.concatenate(parts).astype(np.float32)
+    return np.ascontiguousarray(x[rng.permutation(x.shape[0])])
+
+
+def make_ivf_from_rows(x: np.ndarray, nlist: Optional[int] = None, rng=None, kmeans_iters: int = 2) -> dict:
+    """The IVF layout of `make_ivf` for a given training matrix x [n, d] (ids = row numbers, the sequential `add`)."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, d = x.shape
     if nlist is None:
         nlist = ivf_nlist(n)
     cent = x[rng.choice(n, size=nlist, replace=False)].copy()

@@ -829,11 +829,15 @@ static rvcmi_ivf* read_faiss(const char* path, int device) {
     int qd, qmetric;
     int64_t qn;
     read_index_header(r, qd, qn, qmetric);
+    if (qmetric != 1) RVCMI_FAIL(RVCMI_ERR_IO, "%s: the coarse quantizer '%s' uses metric %d; only a flat L2 quantizer is supported", path, cc, qmetric);
     const uint64_t nfl = r.get<uint64_t>();
     if (qd != d || (uint64_t)qn != nlist || nfl != nlist * (uint64_t)d) RVCMI_FAIL(RVCMI_ERR_IO, "%s: quantizer shape mismatch", path);
     std::vector<float> cent(nfl);
     r.read(cent.data(), nfl * 4);
-    (void)r.get<int8_t>();  // direct map type
+    const int dm_type = r.get<int8_t>();  // DirectMap::Type: 0 NoMap, 1 Array (a vector<idx_t> follows), 2 Hashtable
+    if (dm_type != 0 && dm_type != 1)
+        RVCMI_FAIL(RVCMI_ERR_IO, "%s: direct map type %d (Hashtable) is not supported; re-write the index without a direct map "
+                   "(RVC never builds one, web.py:547-571)", path, dm_type);
     const uint64_t dmn = r.get<uint64_t>();
     if (fseek(f, (long)(dmn * 8), SEEK_CUR)) RVCMI_FAIL(RVCMI_ERR_IO, "%s: truncated direct map", path);
     r.fourcc(cc);
@@ -953,7 +957,9 @@ struct BlendFuse {
 static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, int64_t* I, hipStream_t st,
                    const BlendFuse* bf = nullptr) {
     if (!h || nq < 0 || (nq && (!q || !D || !I))) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
-    if (k < 1 || k > KMAX) RVCMI_FAIL(RVCMI_ERR_INVALID, "k=%d outside [1,%d]", k, KMAX);
+    if (k < 1 || k > KMAX)
+        RVCMI_FAIL(RVCMI_ERR_INVALID, "k=%d outside [1,%d]: the kernels keep at most %d neighbours per query (RVC asks for 8, "
+                   "pipeline.py:126; legacy top-1 tools/cmd/infer-pm-index256.py:161)", k, KMAX, KMAX);
     if (nq == 0) return false;
     reserve(h, nq);
     const BlobHeader& b = h->hdr;
@@ -1238,10 +1244,18 @@ int rvcmi_ivf_reconstruct_n(const rvcmi_ivf* h, int64_t i0, int64_t n, float* ou
         std::vector<float> vecs((size_t)b.ntotal * b.d);
         HIP_CHECK(hipMemcpy(ids.data(), h->blob + b.off_ids, ids.size() * 8, hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(vecs.data(), h->blob + b.off_vecs, vecs.size() * 4, hipMemcpyDeviceToHost));
+        // faiss' reconstruct_n needs a direct map and raises for ids it cannot find; here rows the index does not hold (ids
+        // that are not a permutation of 0..ntotal-1, e.g. after add_with_ids) are an error too, never uninitialised memory
+        std::vector<char> seen((size_t)n, 0);
         for (int64_t p = 0; p < b.ntotal; ++p) {
             const int64_t id = ids[p];
-            if (id >= i0 && id < i0 + n) memcpy(out_host + (size_t)(id - i0) * b.d, vecs.data() + (size_t)p * b.d, (size_t)b.d * 4);
+            if (id >= i0 && id < i0 + n) {
+                memcpy(out_host + (size_t)(id - i0) * b.d, vecs.data() + (size_t)p * b.d, (size_t)b.d * 4);
+                seen[(size_t)(id - i0)] = 1;
+            }
         }
+        for (int64_t i = 0; i < n; ++i)
+            if (!seen[(size_t)i]) RVCMI_FAIL(RVCMI_ERR_INVALID, "reconstruct_n: id %lld is not in the index (ids are not sequential)", (long long)(i0 + i));
     });
 }
 int rvcmi_ivf_blob(const rvcmi_ivf* h, void** dev_ptr, size_t* bytes) {
@@ -1249,6 +1263,14 @@ int rvcmi_ivf_blob(const rvcmi_ivf* h, void** dev_ptr, size_t* bytes) {
         if (!h || !dev_ptr || !bytes) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
         *dev_ptr = h->blob;
         *bytes = h->hdr.total_bytes;
+    });
+}
+int rvcmi_ivf_blob_copy(const rvcmi_ivf* h, void* dst_dev, size_t capacity, void* stream) {
+    return guarded([&] {
+        if (!h || !dst_dev) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        if (capacity < h->hdr.total_bytes) RVCMI_FAIL(RVCMI_ERR_INVALID, "blob_copy: destination holds %zu bytes, the index needs %zu", capacity, (size_t)h->hdr.total_bytes);
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipMemcpyAsync(dst_dev, h->blob, h->hdr.total_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     });
 }
 int rvcmi_ivf_create_from_blob(void* dev_ptr, size_t bytes, int device, int take_ownership, rvcmi_ivf** out) {

@@ -87,10 +87,8 @@ class IVFFlatHIP:
         _lib.check(_lib.lib().rvcmi_ivf_blob(self._h, C.byref(p), C.byref(n)))
         out = torch.empty(n.value, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            torch.cuda.current_stream().synchronize()
-            rc = _hip_memcpy_d2d(out.data_ptr(), p.value, n.value)
-        if rc:
-            raise _lib.RvcmiError("hipMemcpy failed (%d)" % rc)
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().rvcmi_ivf_blob_copy(self._h, C.c_void_p(out.data_ptr()), n.value, C.c_void_p(st)))
         return out
 
     def __del__(self):
@@ -196,13 +194,6 @@ def _cuda(device) -> torch.device:
 
 def _idx(dev: torch.device) -> int:
     return dev.index if dev.index is not None else torch.cuda.current_device()
-
-
-def _hip_memcpy_d2d(dst: int, src: int, n: int) -> int:
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    hip.hipMemcpy.restype = C.c_int
-    return hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), n, 3)  # hipMemcpyDeviceToDevice
 
 
 def train_index(big_npy: np.ndarray, path: str = None, nlist: int = None, niter: int = 10, seed: int = 1234, device="cuda:0") -> IVFFlatHIP:

@@ -220,3 +220,42 @@ def test_faiss_file_layout_roundtrip_python(tmp_path):
 def test_index_recipe_nlist():
     # web.py:544  min(int(16*sqrt(N)), N//39)
     assert synth.ivf_nlist(10000) == 256 and synth.ivf_nlist(200000) == 5128 and synth.ivf_nlist(1000000) == 16000
+
+
+def test_real_hubert_rows_tie_semantics_and_the_faiss_validator(tmp_path, capsys):
+    """The oracle on the real-feature distribution (fixture mute_hubert: duplicate rows => exact ties): python and C
+    restatements agree, ties resolve to the lowest id; and oracle/validate_faiss_index.py accepts a well-formed file with a
+    matching (D, I) dump and names the problem in a damaged one."""
+    import ctypes as C
+    import sys
+
+    from conftest import load_golden
+    from oracle import validate_faiss_index as V
+
+    feats = load_golden("mute_hubert")["f256"]
+    x = synth.make_mute_rows(feats, copies=12)
+    idx = synth.make_ivf_from_rows(x)
+    q = np.concatenate([feats[:80], (feats[:40] + np.float32(1e-3)).astype(np.float32)])
+    D, I = ivf_oracle.search(idx, q, 8)
+    assert (D[:80, :2] == 0).all()
+    for i in range(80):  # the zero-distance group is listed in ascending id order
+        z = I[i][D[i] == 0]
+        assert (np.diff(z) > 0).all()
+    path = str(tmp_path / "mute.index")
+    ivf_oracle.write_index(idx, path)
+    np.savez(str(tmp_path / "qdi.npz"), q=q, D=D, I=I, big_head=x[:64])
+    old = sys.argv
+    try:
+        sys.argv = ["validate", path, "--dump", str(tmp_path / "qdi.npz")]
+        assert V.main() == 0
+        out = capsys.readouterr().out
+        assert "layout: as expected" in out and "genuine id mismatches 0" in out
+        buf = bytearray(open(path, "rb").read())
+        assert bytes(buf[4 + 33 + 16:4 + 33 + 20]) == b"IxF2"
+        buf[4 + 33 + 16:4 + 33 + 20] = b"IxXX"  # the quantizer fourcc
+        open(path, "wb").write(buf)
+        sys.argv = ["validate", path]
+        assert V.main() == 1
+        assert "quantizer fourcc is b'IxXX'" in capsys.readouterr().out
+    finally:
+        sys.argv = old

@@ -255,3 +255,63 @@ def test_index_build_handles_empty_lists_and_is_deterministic(gpu):
     assert torch.equal(a.blob(), b.blob())
     D, I = a.search(x[::20], 8)
     assert np.all(D[:, 0] == 0)
+
+
+@pytest.mark.parametrize("dim", [768, 256])
+def test_real_hubert_distribution_with_exact_duplicates(dim, gpu):
+    """Index and queries drawn from the only REAL HuBERT features of the reference checkout (logs/mute/3_feature*/mute.npy,
+    fixture mute_hubert): near-collinear rows, exact duplicate rows and an exact second copy of every row -- distance ties
+    between different ids everywhere.  ids must still be bit-exact (ties -> lowest id), trained index included."""
+    import rvc_amd
+    from conftest import load_golden
+
+    feats = load_golden("mute_hubert")["f%d" % dim]
+    x = synth.make_mute_rows(feats)
+    idx = synth.make_ivf_from_rows(x)
+    h = make(idx, gpu)
+    q = np.concatenate([feats, (feats[:60] + np.float32(1e-3)).astype(np.float32)])  # exact hits (score 0) and near hits
+    D, I = h.search(q, 8)
+    Dr, Ir = ivf_oracle.search(idx, q, 8)
+    assert np.array_equal(I, Ir), "%d id mismatches on the real-feature index" % int((I != Ir).sum())
+    assert np.array_equal(D, Dr)
+    assert (D[:149, 0] == 0).all() and (D[:149, 1] == 0).all()  # every row has its exact second copy: a tie at distance 0
+    # the GPU-built index (k-means on the same rows) answers its own oracle the same way
+    built = rvc_amd.IVFFlatHIP.train(x, niter=4, device=gpu)
+    assert np.array_equal(built.reconstruct_n(0, built.ntotal), x)
+    Db, Ib = built.search(feats, 8)
+    assert (Db[:, 0] == 0).all() and np.array_equal(x[Ib[:, 0]], feats)  # an exact hit is found in its own cell, lowest id first
+    assert (Ib[:, 0] < Ib[:, 1]).all() and (Db[:, 1] == 0).all()
+
+
+def test_reader_and_object_reject_what_they_do_not_support_with_a_clear_message(tmp_path, gpu):
+    import struct
+
+    import rvc_amd
+
+    idx = synth.make_ivf(600, 64, seed=2)
+    good = str(tmp_path / "ok.index")
+    ivf_oracle.write_index(idx, good)
+    buf = bytearray(open(good, "rb").read())
+    pos_dm = 4 + 33 + 16 + 4 + 33 + 8 + 4 * idx["nlist"] * 64  # fourcc, header, nlist/nprobe, quantizer fourcc + header, count, centroids
+    assert buf[pos_dm] == 0
+    bad = bytearray(buf)
+    bad[pos_dm] = 2  # DirectMap::Hashtable
+    p = str(tmp_path / "hash.index")
+    open(p, "wb").write(bad)
+    with pytest.raises(rvc_amd.RvcmiError, match="direct map type 2"):
+        rvc_amd.read_index(p, device=gpu)
+    bad = bytearray(buf)
+    struct.pack_into("<i", bad, 4 + 33 + 16 + 4 + 29, 0)  # quantizer metric_type -> METRIC_INNER_PRODUCT
+    p = str(tmp_path / "ip.index")
+    open(p, "wb").write(bad)
+    with pytest.raises(rvc_amd.RvcmiError, match="quantizer"):
+        rvc_amd.read_index(p, device=gpu)
+    h = rvc_amd.read_index(good, device=gpu)
+    with pytest.raises(rvc_amd.RvcmiError, match="at most 8"):
+        h.search(np.zeros((2, 64), np.float32), 9)
+    ids = idx["ids"].copy()
+    ids[ids == 5] = 10 ** 6  # add_with_ids-style gap: id 5 does not exist
+    h2 = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], ids, idx["vecs"], device=gpu)
+    with pytest.raises(rvc_amd.RvcmiError, match="id 5 is not in the index"):
+        h2.reconstruct_n(0, 600)
+    assert np.array_equal(h2.reconstruct_n(6, 100), idx["xb"][6:106])
