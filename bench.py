@@ -211,10 +211,44 @@ def torch_gpu_baseline(a, timeout_s=420):
         return {"error": "stock PyTorch-ROCm generator did not finish 2 x 8 forwards within %d s (first-time MIOpen kernel builds)" % timeout_s}
 
 
+def _percentiles(lat):
+    lat = sorted(lat)
+    n = len(lat)
+    return {"p50_ms": lat[n // 2], "p90_ms": lat[int(0.9 * n)], "p99_ms": lat[min(n - 1, int(0.99 * n))], "min_ms": lat[0], "chunks": n}
+
+
+def _time_chunks(fn, n=300, warm=30, graph=True):
+    """Per-chunk wall latency (sync - launch - sync).  With `graph`, the chunk is captured once (fixed (T, n_res, queries)
+    bucket, inputs copied into static buffers by the graph's first nodes) and replayed, as a realtime loop would for the
+    block size the GUI was started with (gui.py:783-840 fixes it)."""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    run, captured = fn, False
+    if graph:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            run, captured = g.replay, True
+        except Exception as e:  # noqa
+            print("[bench] stream graph capture failed (%s); eager launches" % e, file=sys.stderr)
+            torch.cuda.synchronize()
+    lat = []
+    for i in range(n + warm):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        if i >= warm:
+            lat.append(1e3 * (time.perf_counter() - t0))
+    return _percentiles(lat), captured
+
+
 def stream_mode(a):
     """Realtime chunk latency (gui.py geometry): block 0.256 s -> decoder T=31 frames
     (n_res = 31, no formant shift), retrieval on the last 16 HuBERT frames; v1/40k generator, 768-d index.
-    Eager launches (a realtime loop cannot replay a fixed graph when f0/n_res vary); p50 over 200 chunks."""
+    p50 / p90 / p99 over 300 chunks after 30 warm-ups, replayed from a hipGraph of the fixed-shape chunk (--graph 0: eager)."""
     import rvc_amd
     from oracle import nsf_oracle, synth
 
@@ -229,20 +263,20 @@ def stream_mode(a):
     gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=dev, operand=a.operand, max_B=1, max_T=64)
     zd, fd, gd, nd = z.to(dev), f0.to(dev), g.to(dev), noise.to(dev)
     feats = synth.make_phone(1, NQ, a.index_d)[0].to(dev).contiguous()
-    lat = []
-    for i in range(220):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        f = feats.clone()
-        index.search_blend(f, a.index_rate, 8, skip_if_short=True)
-        o = gen(zd, fd, gd, noise=nd)
-        torch.cuda.synchronize()
-        if i >= 20:
-            lat.append(1e3 * (time.perf_counter() - t0))
-    lat.sort()
-    line = {"metric": "realtime chunk latency p50 (retrieval + NSF decode), v1/40k, 256 ms block", "value": lat[len(lat) // 2],
-            "unit": "ms", "p90": lat[int(0.9 * len(lat))], "higher_is_better": False, "n_gpus": 1, "dtype": a.operand,
-            "data": "synthetic", "config": {"workload": "BASELINE configs[4] (hot path only): T=31 frames -> 12400 samples, 16 queries, eager launches"}}
+    fbuf = torch.empty_like(feats)
+    hold = {}
+
+    def hot():
+        fbuf.copy_(feats)
+        index.search_blend(fbuf, a.index_rate, 8, skip_if_short=True)
+        hold["o"] = gen(zd, fd, gd, noise=nd)
+
+    st, cap = _time_chunks(hot, graph=bool(a.graph))
+    assert torch.isfinite(hold["o"]).all()
+    line = {"metric": "realtime chunk latency p50 (retrieval + NSF decode), v1/40k, 256 ms block", "value": st["p50_ms"],
+            "unit": "ms", "p90": st["p90_ms"], "p99": st["p99_ms"], "higher_is_better": False, "n_gpus": 1, "dtype": a.operand,
+            "data": "synthetic", "hot_path": st,
+            "config": {"workload": "BASELINE configs[4] (hot path only): T=31 frames -> 12400 samples, 16 queries", "hipgraph": cap}}
     if a.operand != "fp32" and a.index_d == 768:
         # the whole RVC.infer of the realtime loop after HuBERT / f0 (infer/lib/rtrvc.py:163-251, gui.py:1057-1090):
         # 141 feature rows, retrieval on the last 16 (guarded), x2 -> 282 frames, protect mix, infer(skip_head=250,
@@ -253,6 +287,7 @@ def stream_mode(a):
         front = rvc_amd.FrontHIP(vars(fcfg), synth.make_front_weights(fcfg, 1234), device=dev, operand=a.operand, max_B=1, max_T=288)
         NF, P_LEN, SKIP, RET = 141, 282, 250, 31
         hub = synth.make_phone(1, NF, 768)[0].to(dev).contiguous()
+        hbuf = torch.empty_like(hub)
         pitchf_all = synth.make_f0(1, P_LEN).to(dev)
         pitch_all = synth.make_pitch(pitchf_all.cpu()).to(dev)
         zc, Lb, Ls = cfg.sr // 100, 4 * (cfg.sr // 100), cfg.sr // 100
@@ -264,23 +299,18 @@ def stream_mode(a):
         net = type("N", (), {})()
         net.emb_g = lambda sid: sid_g.reshape(1, -1)
         net.dec = gen
-        lat2 = []
-        for i in range(220):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            f = hub.clone()
-            index.search_blend(f[SKIP // 2:], a.index_rate, 8, skip_if_short=True)          # rtrvc.py:167-186
-            ph = rvc_amd.glue.retrieve_blend_expand(f.unsqueeze(0), None, 0.0, pitchf_all, 0.33, P_LEN)   # :221-233 (x2, protect; blend done above)
-            wav = rvc_amd.infer_hip(net, front, ph, None, torch.zeros(1, dtype=torch.long, device=dev), pitch_all, pitchf_all,
-                                    SKIP, RET, RET)[0, 0]                                 # :236-247
-            out = rvc_amd.glue.sola(wav.contiguous(), sola_buf, fade_in, fade_out, blk, Ls)  # gui.py:1057-1090
-            torch.cuda.synchronize()
-            if i >= 20:
-                lat2.append(1e3 * (time.perf_counter() - t0))
-        lat2.sort()
-        assert torch.isfinite(out).all()
-        line["whole_chunk"] = {"what": "retrieval (16 rows, guarded) + x2 + protect + enc_p(282) + flow(56) + decode(31) + SOLA, eager",
-                               "p50_ms": lat2[len(lat2) // 2], "p90_ms": lat2[int(0.9 * len(lat2))]}
+        sid0 = torch.zeros(1, dtype=torch.long, device=dev)
+
+        def whole():
+            hbuf.copy_(hub)
+            index.search_blend(hbuf[SKIP // 2:], a.index_rate, 8, skip_if_short=True)          # rtrvc.py:167-186
+            ph = rvc_amd.glue.retrieve_blend_expand(hbuf.unsqueeze(0), None, 0.0, pitchf_all, 0.33, P_LEN)   # :221-233 (x2, protect; blend done above)
+            wav = rvc_amd.infer_hip(net, front, ph, None, sid0, pitch_all, pitchf_all, SKIP, RET, RET)[0, 0]  # :236-247
+            hold["w"] = rvc_amd.glue.sola(wav.contiguous(), sola_buf, fade_in, fade_out, blk, Ls)  # gui.py:1057-1090
+
+        st2, cap2 = _time_chunks(whole, graph=bool(a.graph))
+        assert torch.isfinite(hold["w"]).all()
+        line["whole_chunk"] = dict(st2, what="retrieval (16 rows, guarded) + x2 + protect + enc_p(282) + flow(56) + decode(31) + SOLA", hipgraph=cap2)
     print(json.dumps(line))
 
 

@@ -264,6 +264,10 @@ int rvcmi_ivf_search_blend_expand(rvcmi_ivf* h, int64_t nq, const float* feats_d
 /* index.reconstruct_n(i0, n) -> out_host [n,d] rows in id order (pipeline.py:215).             */
 int rvcmi_ivf_reconstruct_n(const rvcmi_ivf* h, int64_t i0, int64_t n, float* out_host);
 
+/* The coarse centroids [nlist, d] (k-means cluster centres of a built index), e.g. as the 10k-centre reduction of a
+ * large training set (web.py:522-536).                                                                             */
+int rvcmi_ivf_centroids(const rvcmi_ivf* h, float* out_host);
+
 /* Copies the packed index blob into caller-owned device memory (>= the size rvcmi_ivf_blob reports) on `stream`:
  * the source buffer of the RCCL broadcast of rvc_amd.dist.broadcast_index, made by this library's own HIP runtime.  */
 int rvcmi_ivf_blob_copy(const rvcmi_ivf* h, void* dst_dev, size_t capacity, void* stream);
@@ -298,6 +302,14 @@ int rvcmi_glue_rmvpe_f0(const float* salience_dev, int n, int nbins, float thred
 /* post_process only (f0 in Hz from any other estimator, fp64 [n]).                                 */
 int rvcmi_glue_f0_post(const double* f0_dev, int n, int f0_up_key, int64_t* pitch_dev, float* pitchf_dev,
                        void* stream);
+
+/* change_rms (infer/modules/vc/pipeline.py:26-46, called at :351 when rms_mix_rate != 1): mixes the loudness envelope of the
+ * input (data1 at sr1 = 16000) into the converted audio data2 (sr2 = tgt_sr), IN PLACE on data2:
+ *   data2 *= rms1^(1-rate) * max(rms2,1e-6)^(rate-1), rms_i = half-second frame RMS (librosa.feature.rms, centred, zero
+ *   padded) linearly interpolated to len(data2).  scratch_dev: (1 + n1/(sr1/2)) + (1 + n2/(sr2/2)) floats.
+ * The frame energies are summed in fp64; librosa sums in float32 in an order nothing in the reference pins.          */
+int rvcmi_glue_change_rms(const float* data1_dev, int64_t n1, int sr1, float* data2_dev, int64_t n2, int sr2, float rate,
+                          float* scratch_dev, void* stream);
 
 /* pipeline.py:355-359: audio *= 32768 / max(1, abs(audio).max()/0.99), in place.  scratch_dev: 256 floats. */
 int rvcmi_glue_scale_int16_range(float* audio_dev, int64_t n, float* scratch_dev, void* stream);

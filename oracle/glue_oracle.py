@@ -114,6 +114,39 @@ def rmvpe_f0(salience: np.ndarray, p_len: int, f0_up_key: int, thred: float = 0.
     return coarse[:p_len].astype(np.int64), f0[:p_len].astype(np.float32)
 
 
+def frame_rms(y: np.ndarray, frame_length: int, hop_length: int) -> np.ndarray:
+    """``librosa.feature.rms(y=y, frame_length=..., hop_length=...)[0]`` as librosa >= 0.10.2 (requirements/main.txt:5)
+    documents it: ``center=True, pad_mode="constant"`` (zero padding of frame_length//2 on both sides), frames
+    ``y[i*hop : i*hop + frame_length]``, ``sqrt(mean(abs2(frame, dtype=float32)))``.
+
+    PARITY UNPINNED: librosa is not installable here and the reference holds no fixture for this function.  The float32
+    squares are summed here in float64 (librosa/numpy sum them in float32, in an order that depends on numpy's reduction
+    loop for the strided frame view); the difference is below 1e-6 relative."""
+    y = np.asarray(y, dtype=np.float32)
+    pad = frame_length // 2
+    yp = np.pad(y, (pad, pad), mode="constant")
+    n_frames = 1 + (len(yp) - frame_length) // hop_length
+    out = np.empty(n_frames, np.float32)
+    for i in range(n_frames):
+        fr = yp[i * hop_length: i * hop_length + frame_length]
+        out[i] = np.sqrt(np.float32((fr * fr).astype(np.float64).sum() / frame_length))
+    return out
+
+
+def change_rms(data1: np.ndarray, sr1: int, data2: np.ndarray, sr2: int, rate: float) -> np.ndarray:
+    """pipeline.py:26-46 with the same torch calls (F.interpolate linear, torch.pow with a float32 0-dim exponent)."""
+    import torch.nn.functional as F
+
+    rms1 = torch.from_numpy(frame_rms(data1, sr1 // 2 * 2, sr1 // 2)[None])
+    rms2 = torch.from_numpy(frame_rms(data2, sr2 // 2 * 2, sr2 // 2)[None])
+    rms1 = F.interpolate(rms1.unsqueeze(0), size=data2.shape[0], mode="linear").squeeze()
+    rms2 = F.interpolate(rms2.unsqueeze(0), size=data2.shape[0], mode="linear").squeeze()
+    rms2 = torch.max(rms2, torch.zeros_like(rms2) + 1e-6)
+    out = np.array(data2, dtype=np.float32)
+    out *= (torch.pow(rms1, torch.tensor(1 - rate)) * torch.pow(rms2, torch.tensor(rate - 1))).numpy()
+    return out
+
+
 def scale_int16_range(audio: np.ndarray) -> np.ndarray:
     # pipeline.py:355-359
     audio = np.array(audio, dtype=np.float32)

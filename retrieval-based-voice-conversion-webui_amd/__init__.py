@@ -5,7 +5,7 @@ reference's own Python call surface.  See DESIGN.md / INTEGRATION.md.
 """
 from . import _lib
 from ._lib import RvcmiError, build
-from .ivf import IVFFlatHIP, read_index, train_index, write_index
+from .ivf import IVFFlatHIP, read_index, reduce_features, train_index, write_index
 from .front import FrontHIP, front_config_from_reference, infer_hip
 from .nsf import GeneratorHIP, NSFGeneratorHIP, config_from_reference
 from .pipeline import retrieve_blend
@@ -15,6 +15,6 @@ from . import dist
 from .install import install, uninstall
 
 __all__ = [
-    "RvcmiError", "build", "IVFFlatHIP", "read_index", "write_index", "train_index", "GeneratorHIP", "NSFGeneratorHIP",
+    "RvcmiError", "build", "IVFFlatHIP", "read_index", "write_index", "train_index", "reduce_features", "GeneratorHIP", "NSFGeneratorHIP",
     "config_from_reference", "FrontHIP", "front_config_from_reference", "infer_hip", "retrieve_blend", "accelerate_synthesizer", "get_synthesizer", "load_synthesizer", "dist", "glue", "install", "uninstall",
 ]

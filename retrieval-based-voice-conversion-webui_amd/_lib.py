@@ -92,6 +92,7 @@ SYMBOLS = [
     ("rvcmi_ivf_search_blend_expand", C.c_int, [_P, C.c_int64, _P, C.c_float, C.c_int, C.c_int, _P, C.c_float, C.c_int64, _P, _P]),
     ("rvcmi_ivf_reconstruct_n", C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     ("rvcmi_ivf_blob", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("rvcmi_ivf_centroids", C.c_int, [_P, _P]),
     ("rvcmi_ivf_blob_copy", C.c_int, [_P, _P, C.c_size_t, _P]),
     ("rvcmi_ivf_create_from_blob", C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.POINTER(_P)]),
     ("rvcmi_ivf_profile_enable", C.c_int, [_P, C.c_int]),
@@ -99,6 +100,7 @@ SYMBOLS = [
     ("rvcmi_glue_expand_protect", C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, C.c_float, C.c_int64, _P, _P]),
     ("rvcmi_glue_rmvpe_f0", C.c_int, [_P, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P, _P]),
     ("rvcmi_glue_f0_post", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
+    ("rvcmi_glue_change_rms", C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, C.c_float, _P, _P]),
     ("rvcmi_glue_scale_int16_range", C.c_int, [_P, C.c_int64, _P, _P]),
     ("rvcmi_glue_sola", C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
 ]

@@ -99,4 +99,20 @@ int rvcmi_glue_sola(const float* infer_wav, int64_t n, float* sola_buffer, int L
     });
 }
 
+int rvcmi_glue_change_rms(const float* data1, int64_t n1, int sr1, float* data2, int64_t n2, int sr2, float rate, float* scratch,
+                          void* stream) {
+    return guarded([&] {
+        if (!data1 || !data2 || !scratch || n1 < 1 || n2 < 1 || sr1 < 2 || sr2 < 2) RVCMI_FAIL(RVCMI_ERR_INVALID, "change_rms: bad argument");
+        const int h1 = sr1 / 2, h2 = sr2 / 2;
+        const int nf1 = 1 + (int)(n1 / h1), nf2 = 1 + (int)(n2 / h2);
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL(k_frame_rms, dim3(nf1), dim3(256), 0, st, data1, n1, 2 * h1, h1, nf1, scratch);
+        hipLaunchKernelGGL(k_frame_rms, dim3(nf2), dim3(256), 0, st, (const float*)data2, n2, 2 * h2, h2, nf2, scratch + nf1);
+        // torch.pow(rms, torch.tensor(1 - rate)): the exponent is the python double rounded to float32
+        const float e1 = (float)(1.0 - (double)rate), e2 = (float)((double)rate - 1.0);
+        hipLaunchKernelGGL(k_change_rms, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, data2, n2, scratch, nf1, scratch + nf1, nf2, e1, e2);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 }  // extern "C"

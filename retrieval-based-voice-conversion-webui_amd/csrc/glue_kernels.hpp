@@ -307,4 +307,59 @@ static __global__ void __launch_bounds__(256) k_sola(const float* __restrict__ x
     for (int i = threadIdx.x; i < Lb; i += 256) buf[i] = y(block + i);  // old tail is in LDS: safe to overwrite
 }
 
+// ------------------------------------------------------------------------------------------------
+// change_rms (infer/modules/vc/pipeline.py:26-46): the output's loudness envelope mixed with the input's.
+//   rms_i = librosa.feature.rms(y, frame_length = sr//2*2, hop_length = sr//2)   (centred frames, zero padding -- the
+//           default of the librosa >= 0.10.2 the reference requires), one point per half second;
+//   both envelopes linearly interpolated to len(data2) (F.interpolate, align_corners=False); rms2 = max(rms2, 1e-6);
+//   data2 *= rms1^(1-rate) * rms2^(rate-1).
+// The frame energy is accumulated in fp64 (numpy sums the float32 squares in float32; its summation order for this strided
+// view is not pinned by anything in the reference, see oracle/glue_oracle.py:change_rms) and rounded to fp32 before the sqrt.
+// ------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) k_frame_rms(const float* __restrict__ y, int64_t n, int frame, int hop, int nframes,
+                                                          float* __restrict__ rms) {
+    __shared__ double red[256];
+    const int f = blockIdx.x;
+    if (f >= nframes) return;
+    const int64_t lo = (int64_t)f * hop - frame / 2;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < frame; i += 256) {
+        const int64_t t = lo + i;
+        if (t >= 0 && t < n) {
+            const float v = y[t];
+            acc += (double)mul_rn(v, v);  // abs2 in float32, like librosa's util.abs2(dtype=float32)
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rms[f] = sqrtf((float)(red[0] / (double)frame));
+}
+
+__device__ __forceinline__ float interp_linear_1d(const float* __restrict__ r, int nin, int64_t nout, int64_t o) {
+    // F.interpolate(mode="linear", align_corners=False): src = scale*(o+0.5)-0.5 clamped at 0, scale = nin/nout (fp32)
+    const float scale = (float)nin / (float)nout;
+    float src = sub_rn(mul_rn(scale, add_rn((float)o, 0.5f)), 0.5f);
+    if (src < 0.f) src = 0.f;
+    int i0 = (int)src;
+    if (i0 > nin - 1) i0 = nin - 1;
+    const int i1 = i0 + (i0 < nin - 1 ? 1 : 0);
+    const float l1 = sub_rn(src, (float)i0);
+    const float l0 = sub_rn(1.f, l1);
+    return add_rn(mul_rn(l0, r[i0]), mul_rn(l1, r[i1]));
+}
+
+static __global__ void __launch_bounds__(256) k_change_rms(float* __restrict__ data2, int64_t n2, const float* __restrict__ rms1, int nf1,
+                                                           const float* __restrict__ rms2, int nf2, float e1, float e2) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n2) return;
+    const float r1 = interp_linear_1d(rms1, nf1, n2, t);
+    float r2 = interp_linear_1d(rms2, nf2, n2, t);
+    r2 = fmaxf(r2, 1e-6f);
+    data2[t] = mul_rn(data2[t], mul_rn(powf(r1, e1), powf(r2, e2)));
+}
+
 }  // namespace rvcmi

@@ -1265,6 +1265,13 @@ int rvcmi_ivf_blob(const rvcmi_ivf* h, void** dev_ptr, size_t* bytes) {
         *bytes = h->hdr.total_bytes;
     });
 }
+int rvcmi_ivf_centroids(const rvcmi_ivf* h, float* out_host) {
+    return guarded([&] {
+        if (!h || !out_host) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        HIP_CHECK(hipSetDevice(h->device));
+        HIP_CHECK(hipMemcpy(out_host, h->centroids(), (size_t)h->hdr.nlist * h->hdr.d * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
 int rvcmi_ivf_blob_copy(const rvcmi_ivf* h, void* dst_dev, size_t capacity, void* stream) {
     return guarded([&] {
         if (!h || !dst_dev) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");

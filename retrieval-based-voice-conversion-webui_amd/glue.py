@@ -4,6 +4,7 @@ row 2), so that nothing between the PyTorch-ROCm feature extractors and ``net_g.
     retrieve_blend_expand(feats, index, index_rate, pitchf, protect, p_len)   pipeline.py:118-159
     rmvpe_f0(salience, p_len, f0_up_key, thred)                               rvc/f0/rmvpe.py:115-164, f0.py:31-78, gen.py:10-41
     f0_post(f0, f0_up_key)                                                    rvc/f0/gen.py:10-41
+    change_rms(audio16k, 16000, audio_opt, tgt_sr, rms_mix_rate)              pipeline.py:26-46,351
     scale_int16_range(audio)                                                  pipeline.py:355-359
 
 All take and return CUDA (ROCm) tensors and enqueue on the current stream; a CPU tensor raises (no fallback).
@@ -89,6 +90,21 @@ def f0_post(f0: torch.Tensor, f0_up_key: int = 0) -> Tuple[torch.Tensor, torch.T
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().rvcmi_glue_f0_post(_ptr(x), n, int(f0_up_key), _ptr(pitch), _ptr(pitchf), _stream(dev)))
     return pitch.unsqueeze(0), pitchf.unsqueeze(0)
+
+
+def change_rms(data1: torch.Tensor, sr1: int, data2: torch.Tensor, sr2: int, rate: float) -> torch.Tensor:
+    """``change_rms(audio, 16000, audio_opt, tgt_sr, rms_mix_rate)`` of pipeline.py:26-46,351 on the device, IN PLACE on
+    ``data2`` (returned): ``data2 *= rms1**(1-rate) * max(rms2, 1e-6)**(rate-1)`` with half-second frame RMS envelopes."""
+    dev = _dev(data2, "data2")
+    for t, nm in ((data1, "data1"), (data2, "data2")):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 1 or t.device != dev:
+            raise ValueError("%s must be a contiguous 1-D float32 tensor on %s" % (nm, dev))
+    n1, n2 = int(data1.numel()), int(data2.numel())
+    scratch = torch.empty(2 + n1 // (int(sr1) // 2) + n2 // (int(sr2) // 2), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().rvcmi_glue_change_rms(_ptr(data1), n1, int(sr1), _ptr(data2), n2, int(sr2), float(rate), _ptr(scratch),
+                                                    _stream(dev)))
+    return data2
 
 
 def scale_int16_range(audio: torch.Tensor) -> torch.Tensor:

@@ -124,6 +124,12 @@ class IVFFlatHIP:
         _lib.check(_lib.lib().rvcmi_ivf_reserve(self._h, int(max_nq)))
         return self
 
+    def centroids(self) -> np.ndarray:
+        """The coarse quantizer's centres [nlist, d] (``faiss.extract_index_ivf(index).quantizer.reconstruct_n(0, nlist)``)."""
+        out = np.empty((self.nlist, self.d), dtype=np.float32)
+        _lib.check(_lib.lib().rvcmi_ivf_centroids(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def reconstruct_n(self, i0: int = 0, n: int = None) -> np.ndarray:
         n = self.ntotal - i0 if n is None else int(n)
         out = np.empty((n, self.d), dtype=np.float32)
@@ -194,6 +200,19 @@ def _cuda(device) -> torch.device:
 
 def _idx(dev: torch.device) -> int:
     return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+def reduce_features(big_npy: np.ndarray, n_clusters: int = 10000, threshold: float = 2e5, niter: int = 10, seed: int = 1234,
+                    device="cuda:0") -> np.ndarray:
+    """The training-set reduction of web.py:522-536: more than 2e5 feature rows are replaced by ``n_clusters`` k-means
+    centres before the index is trained.  The reference runs sklearn's ``MiniBatchKMeans(init="random")`` on the host
+    (stochastic mini-batches, its own RNG: not reproducible elsewhere); this runs full-batch Lloyd iterations on the GPU with
+    the exact coarse-assignment kernels of the search path (same objective, lower final inertia).  Smaller sets are returned
+    unchanged, like the reference's ``if big_npy.shape[0] > 2e5``."""
+    x = np.ascontiguousarray(big_npy, dtype=np.float32)
+    if x.shape[0] <= threshold:
+        return x
+    return IVFFlatHIP.train(x, nlist=int(n_clusters), niter=niter, seed=seed, device=device).centroids()
 
 
 def train_index(big_npy: np.ndarray, path: str = None, nlist: int = None, niter: int = 10, seed: int = 1234, device="cuda:0") -> IVFFlatHIP:

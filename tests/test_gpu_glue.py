@@ -134,3 +134,28 @@ def test_sola_matches_gui_expression(true_off, gpu):
     out, off = rvc_amd.glue.sola(wav.to(gpu), dbuf, fade_in.to(gpu), fade_out.to(gpu), blk, Ls, return_offset=True)
     assert int(off.item()) == ref_off
     assert torch.equal(out.cpu(), ref_out) and torch.equal(dbuf.cpu(), ref_buf)
+
+
+@pytest.mark.parametrize("rate", [0.25, 0.0, 0.8])
+def test_change_rms_matches_the_pipeline_expression(rate, gpu):
+    """rms-mix (pipeline.py:26-46,351; WebUI default rms_mix_rate = 0.25): device result against the oracle restatement
+    (torch's own F.interpolate / pow; the librosa frame RMS is restated and UNPINNED, see oracle/glue_oracle.py:frame_rms).
+    Bar: 2e-6 relative (device powf vs torch's, fp64 vs float32 frame sums)."""
+    import rvc_amd
+
+    rng = np.random.default_rng(3)
+    n1 = 16000 * 7 + 1234
+    t = np.arange(n1) / 16000.0
+    env = (0.05 + 0.9 * (np.sin(2 * np.pi * 0.3 * t) ** 2)).astype(np.float32)
+    data1 = (env * rng.standard_normal(n1).astype(np.float32) * 0.3).astype(np.float32)
+    data1[20000:36000] = 0.0  # a silent second: rms1 -> 0
+    n2 = int(n1 * 3)  # 48 kHz output
+    data2 = (0.2 * rng.standard_normal(n2)).astype(np.float32)
+    data2[100000:180000] = 0.0  # silent output stretch: the 1e-6 floor of rms2
+    ref = glue_oracle.change_rms(data1, 16000, data2.copy(), 48000, rate)
+    d2 = torch.from_numpy(data2.copy()).to(gpu)
+    out = rvc_amd.glue.change_rms(torch.from_numpy(data1).to(gpu), 16000, d2, 48000, rate)
+    assert out.data_ptr() == d2.data_ptr()
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.allclose(got, ref, rtol=2e-6, atol=1e-9), "max rel %.2e" % np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-9))

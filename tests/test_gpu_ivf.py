@@ -315,3 +315,22 @@ def test_reader_and_object_reject_what_they_do_not_support_with_a_clear_message(
     with pytest.raises(rvc_amd.RvcmiError, match="id 5 is not in the index"):
         h2.reconstruct_n(0, 600)
     assert np.array_equal(h2.reconstruct_n(6, 100), idx["xb"][6:106])
+
+
+def test_reduce_features_is_the_large_set_branch_of_the_index_recipe(gpu):
+    """web.py:522-536: > 2e5 rows -> 10k k-means centres (here scaled down: threshold 3000 -> 64 centres).  The centres must
+    be a valid k-means solution: every centre is the mean of the rows nearest to it, and the objective beats random rows."""
+    import rvc_amd
+
+    rng = np.random.default_rng(8)
+    blobs = rng.standard_normal((64, 32)).astype(np.float32) * 4
+    x = (blobs[rng.integers(0, 64, 6000)] + rng.standard_normal((6000, 32)).astype(np.float32)).astype(np.float32)
+    assert rvc_amd.reduce_features(x[:2000], 64, threshold=3000, device=gpu) is not None and rvc_amd.reduce_features(x[:2000], 64, threshold=3000, device=gpu).shape == (2000, 32)
+    c = rvc_amd.reduce_features(x, 64, threshold=3000, niter=15, device=gpu)
+    assert c.shape == (64, 32) and c.dtype == np.float32 and np.isfinite(c).all()
+    a = synth.assign_nearest(x, c)
+    means = np.stack([x[a == j].astype(np.float64).mean(0) if (a == j).any() else c[j] for j in range(64)])
+    assert np.abs(means - c).max() <= 5e-2  # a Lloyd fixed point up to the last iteration's movement
+    obj = ((x - c[a]) ** 2).sum()
+    c0 = x[rng.choice(6000, 64, replace=False)]
+    assert obj < 0.8 * ((x - c0[synth.assign_nearest(x, c0)]) ** 2).sum()
