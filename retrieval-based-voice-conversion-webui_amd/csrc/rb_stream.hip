@@ -92,7 +92,7 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
     a.L = L;
     a.bstride = bstride;
     // blocks available to one utterance, shared by the resblocks
-    const int slots = std::max(njobs, num_cus() * g.bpc / std::max(1, B));
+    const int slots1 = std::max(njobs, num_cus() * g.bpc / std::max(1, B));
     int nblocks = 0, side_rows = 0, min_steps = 1 << 30;
     int warm[3] = {0, 0, 0};
     for (int j = 0; j < njobs; ++j) {
@@ -134,7 +134,7 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
         struct Key { int C, nd, L, slots, R, k[3], n; };
         static std::mutex mu;
         static std::vector<std::pair<Key, std::array<int, 3>>> cache;
-        Key key{C, nd, L, slots, R, {jobs[0].k, njobs > 1 ? jobs[1].k : 0, njobs > 2 ? jobs[2].k : 0}, njobs};
+        Key key{C, nd, L, slots1, R, {jobs[0].k, njobs > 1 ? jobs[1].k : 0, njobs > 2 ? jobs[2].k : 0}, njobs};
         bool hit = false;
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -148,23 +148,35 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
                 const int steps = (rows + warm[j] + R - 1) / R;
                 return steps * (jobs[j].k + 4.4);
             };
-            double best = 1e300;
-            const int lim0 = std::min(maxn, slots - (njobs - 1));
-            for (int n0 = 1; n0 <= lim0; ++n0) {
-                if (njobs == 1) {
-                    const double t = tcost(0, n0);
-                    if (t < best) { best = t; nst[0] = n0; }
-                    continue;
+            // With a large batch an utterance gets only a handful of blocks, too few to split in proportion to the three
+            // costs (B = 64: 4 blocks as 2+1+1 = 75 % balance).  Strips are cheap (156 warm-up rows each), so also try
+            // 2x, 3x, 4x the blocks -- whole extra rounds of equally long blocks -- and keep the fastest estimate.
+            double best_total = 1e300;
+            for (int mult = 1; mult <= (slots1 >= 64 ? 1 : 4); ++mult) {
+                const int slots = slots1 * mult;
+                int cand[3] = {1, 1, 1};
+                double best = 1e300;
+                const int lim0 = std::min(maxn, slots - (njobs - 1));
+                for (int n0 = 1; n0 <= lim0; ++n0) {
+                    if (njobs == 1) {
+                        const double t = tcost(0, n0);
+                        if (t < best) { best = t; cand[0] = n0; }
+                        continue;
+                    }
+                    const int lim1 = std::min(maxn, slots - n0 - (njobs - 2));
+                    for (int n1 = 1; n1 <= lim1; ++n1) {
+                        double t = std::max(tcost(0, n0), tcost(1, n1));
+                        if (t >= best) continue;
+                        if (njobs == 2) { best = t; cand[0] = n0; cand[1] = n1; continue; }
+                        const int n2 = std::min(maxn, slots - n0 - n1);
+                        if (n2 < 1) continue;
+                        t = std::max(t, tcost(2, n2));
+                        if (t < best) { best = t; cand[0] = n0; cand[1] = n1; cand[2] = n2; }
+                    }
                 }
-                const int lim1 = std::min(maxn, slots - n0 - (njobs - 2));
-                for (int n1 = 1; n1 <= lim1; ++n1) {
-                    double t = std::max(tcost(0, n0), tcost(1, n1));
-                    if (t >= best) continue;
-                    if (njobs == 2) { best = t; nst[0] = n0; nst[1] = n1; continue; }
-                    const int n2 = std::min(maxn, slots - n0 - n1);
-                    if (n2 < 1) continue;
-                    t = std::max(t, tcost(2, n2));
-                    if (t < best) { best = t; nst[0] = n0; nst[1] = n1; nst[2] = n2; }
+                if (best * mult < best_total * 0.97) {  // (a larger grid has to pay for itself)
+                    best_total = best * mult;
+                    nst[0] = cand[0]; nst[1] = cand[1]; nst[2] = cand[2];
                 }
             }
             std::lock_guard<std::mutex> lk(mu);
