@@ -47,6 +47,10 @@ class FrontHIP(torch.nn.Module):
         if operand not in _lib.OPERANDS or _lib.OPERANDS[operand] == 0:
             raise ValueError("front operand must be 'fp16' or 'bf16'")
         self.operand = operand
+        if operand == "bf16":
+            from .nsf import _warn_bf16
+
+            _warn_bf16("encoder / flow: 1.4e-2 RMS on z")
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.RvcmiError("the HIP front needs a GPU device (got %s); there is no CPU fallback" % device)

@@ -242,3 +242,14 @@ def test_install_rebinds_names_without_editing_the_callers():
         sys.path.remove(skel)
         for m in [m for m in sys.modules if m.split(".")[0] in ("rvc", "infer")]:
             del sys.modules[m]
+
+
+def test_bf16_operands_warn_before_anything_else():
+    """operand='bf16' misses the 1e-3 bar: constructing with it warns -- even where the constructor then
+    fails for lack of a GPU."""
+    from oracle import nsf_oracle, synth
+
+    cfg = nsf_oracle.CONFIGS["v1_40k"]
+    with pytest.warns(RuntimeWarning, match="bf16"):
+        with pytest.raises(Exception):
+            rvc_amd.NSFGeneratorHIP(vars(cfg), {}, device="cuda:0" if torch.cuda.is_available() else "cuda:0", operand="bf16")

@@ -1,9 +1,10 @@
-python -m pytest tests -m gpu -q 2>&1 | tail -5
-python bench.py --batch 64 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_b64.json 2> gpurun_out/r02_bench_b64.err; tail -2 gpurun_out/r02_bench_b64.err
-python bench.py --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_b16.json 2> gpurun_out/r02_bench_b16.err
-python bench.py --whole --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_whole_b16.json 2> gpurun_out/r02_bench_whole_b16.err
-python -c "
-import json
-for f in ('r02_bench_b64','r02_bench_b16','r02_bench_whole_b16'):
-    d=json.load(open('gpurun_out/%s.json'%f)); r=d.get('roofline',{}); print(f, d['ms_per_step'], d['value'], d.get('repeats',{}).get('ms_per_step_median'), r.get('frac'), {k:v for k,v in r.get('kernels_ms_per_step',{}).items() if k.startswith('rb')})
-"
+for nb in 2 3 4; do
+RVCMI_RS_NB=$nb python bench.py --no-cpu-baseline --repeats 0 --steps 50 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read());r=d['roofline'];print('NB=$nb',round(d['ms_per_step'],4),r['kernels_ms_per_step']['rb_stream_c128'])"
+done
+for v in 0 1 2 3; do
+RVCMI_IVF_VAR=$v python bench.py --no-cpu-baseline --repeats 0 --steps 50 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read());r=d['roofline'];print('IVF_VAR=$v',round(d['ms_per_step'],4),r['kernels_ms_per_step']['ivf_scan'],r['kernels_ms_per_step']['ivf_coarse'])"
+done
+python -m pytest tests/test_gpu_ivf.py -q -k "bit_exact or real_hubert" 2>&1 | tail -2
+RVCMI_IVF_VAR=3 python -m pytest tests/test_gpu_ivf.py -q -k "bit_exact or real_hubert or blend" 2>&1 | tail -2
