@@ -31,6 +31,9 @@ bool geo_for(int C, int nd, Geo& g) {
     const bool sm = small_tiles();
     if (C == 256 && nd == 1) { g = {2, sm ? 3 : 4, 4, 1}; return true; }
     if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1}; return true; }
+    // (C = 128 pair by pair with TWO blocks per CU -- NJ = 4, 225 registers, 0 spills -- was measured: both waves of a SIMD sit in
+    //  their K loops at the same time (72 cycles per MFMA per wave), the phases overlap no better than in the one-wave design
+    //  (MFMA pipe 66 % busy in both) and three launches move 3x the bytes: 0.82 vs 0.71 ms on the same box.  Not kept.)
     // C = 64 / 32 (two / four blocks per CU) were built and measured: a pair-step holds too little MFMA work for one wave
     // per SIMD (0.58 vs 0.40 ms and 0.49 vs 0.26 ms per clip against k_rb_full), so they are not instantiated.
     return false;
@@ -50,13 +53,13 @@ int num_cus() {
     return v;
 }
 
-template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int NB = 2>
+template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int NB = 2, int OCC = 1>
 void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
-    auto kern = &k_rb_stream<OpT, C, MI, NJ, NCO, ND, 4, NB>;
+    auto kern = &k_rb_stream<OpT, C, MI, NJ, NCO, ND, 4, NB, OCC>;
     if (!(attr_done.load() & bit)) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.fetch_or(bit);

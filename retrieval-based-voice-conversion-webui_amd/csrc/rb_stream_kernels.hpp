@@ -62,8 +62,8 @@ __device__ __forceinline__ void rs_copy_rows(char* dst, const char* src, int row
     for (int i = threadIdx.x; i < total; i += NT) *(uint4*)(dst + (size_t)i * 16) = *(const uint4*)(src + (size_t)i * 16);
 }
 
-template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG, int NB>
-static __global__ void __launch_bounds__(64 * NCO, 1) k_rb_stream(RbStreamArgs a) {
+template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG, int NB, int OCC = 1>
+static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs a) {
     using TL = Tile<C>;
     using frag = typename Op<OpT>::frag;
     using o4 = __attribute__((ext_vector_type(4))) OpT;
