@@ -5,6 +5,7 @@
 //     z_p = (m_p + exp(logs_p) * noise * 0.66666) * x_mask
 //     z   = flow(z_p, x_mask, g, reverse=True);  out = z * x_mask   (channel-first, what dec.forward takes)
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <memory>
 #include <string>
@@ -57,6 +58,16 @@ const float* wdata(const WeightMap& wm, const std::string& name, std::initialize
     return (const float*)wm.get(name, shape).data;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set it once per (kernel instantiation, device).
+static void ensure_dyn_lds(const void* kern, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.fetch_or(bit, std::memory_order_release);
+}
+
 // Time-tile height: 64 rows (NJ = 2) when that still gives every CU a block, else 32 rows -- at B = 1 a 10 s clip is
 // only 38 tiles of 32 frames, and one tile's MFMA work on one CU is the latency floor of a launch.
 static int pick_nj(int B, int T) {
@@ -80,11 +91,8 @@ void launch_conv_nj(rvcmi_front* h, const char* name, FrConvArgs a, const ConvLa
     const int ctiles = (L.cout + 31) / 32;
     const int gy = (ctiles + NW * MI - 1) / (NW * MI);
     auto kern = k_fr_conv<OpT, CIN, MI, NJ, NW, EPI>;
-    static bool attr_done = false;  // one instantiation = one static
-    if (!attr_done) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};  // one instantiation = one static; one bit per device
+    ensure_dyn_lds(reinterpret_cast<const void*>(kern), attr_done);
     const double flops = L.flops_per_pos * (double)a.T * B;
     h->prof.launch(name, flops, 0.0, st, [&] {
         hipLaunchKernelGGL(kern, dim3((a.T + TT - 1) / TT, gy, B), dim3(64 * NW), smem, st, a);
@@ -111,11 +119,8 @@ void launch_wn_nj(rvcmi_front* h, FrWnArgs a, const ConvLayer& Lin, const ConvLa
     constexpr int TT = NJ * 32;
     const size_t smem = (size_t)(TT + a.ntaps - 1 + 2 + TT + 2) * Tile<H>::STRIDE + 2 * H * sizeof(float);
     auto kern = k_fr_wn<OpT, H, NJ, LAST>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};  // one instantiation = one static; one bit per device
+    ensure_dyn_lds(reinterpret_cast<const void*>(kern), attr_done);
     const double flops = (Lin.flops_per_pos + Lrs.flops_per_pos) * (double)a.T * B;
     static unsigned long long* stamps = nullptr;  // dev only
     if (getenv("RVCMI_FR_STAMPS") && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 64 * 8));
@@ -153,11 +158,8 @@ void launch_ffn_nj(rvcmi_front* h, FrFfnArgs a, const ConvLayer& L1, const ConvL
     const int TV = HR - (a.ntaps - 1);
     const size_t smem = (size_t)(HR + a.ntaps - 1 + 2) * Tile<H>::STRIDE + (size_t)(HR + a.ntaps - 1 + 2) * Tile<F>::STRIDE;
     auto kern = k_fr_ffn<OpT, H, F, NJ1>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};  // one instantiation = one static; one bit per device
+    ensure_dyn_lds(reinterpret_cast<const void*>(kern), attr_done);
     const double flops = (L1.flops_per_pos + L2.flops_per_pos) * (double)a.T * B;
     h->prof.launch("enc_ffn_ln", flops, 0.0, st, [&] {
         hipLaunchKernelGGL(kern, dim3((a.T + TV - 1) / TV, B), dim3(64 * (H / 32)), smem, st, a);

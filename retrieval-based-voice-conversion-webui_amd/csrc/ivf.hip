@@ -461,12 +461,18 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
 // work; at 32 lanes per row every block of the launch is resident at once.
 template <int VL, int LPR, int RU>
 // q and bfeats are NOT __restrict__: the fused blend runs in place (rvcmi_ivf_search_blend passes the same buffer for both).
-__global__ void __launch_bounds__(256) k_scan_v(const float* q, const int64_t* __restrict__ assign, int nprobe,
+// (3 blocks per CU: a clip's 599 query blocks must all be resident, see the register note above)
+__global__ void __launch_bounds__(256, 3) k_scan_v(const float* q, const int64_t* __restrict__ assign, int nprobe,
                                                    const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
                                                    const float* __restrict__ vecs, int64_t nq, int k, float* __restrict__ D,
                                                    int64_t* __restrict__ I, int64_t* __restrict__ P, int* __restrict__ any_short,
-                                                   float* bfeats, float rate, float omr, int64_t pos_last) {
+                                                   float* bfeats, float rate, float omr, int64_t pos_last, unsigned long long* ts = nullptr) {
     constexpr int d = LPR * 4 * VL;
+    // dev only: wall-clock stamps of block 0's phases (RVCMI_IVF_STAMPS=1)
+    auto stamp = [&](int i) {
+        if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[i] = wall_clock64();
+    };
+    stamp(0);
     __shared__ float bd[KMAX];      // fused blend (bfeats != nullptr): the query's k results, by rank
     __shared__ long long bp[KMAX];
     constexpr int G = 256 / LPR;
@@ -486,23 +492,29 @@ __global__ void __launch_bounds__(256) k_scan_v(const float* q, const int64_t* _
     }
     for (int p = 0; p < nprobe; ++p) {
         const int64_t l = assign[qi * nprobe + p];
+        if (ts && threadIdx.x == 0 && blockIdx.x == 0) { asm volatile("" ::"v"((int)l)); ts[1] = wall_clock64(); }
         if (l < 0) continue;
         const int64_t beg = list_off[l], end = list_off[l + 1];
+        if (ts && threadIdx.x == 0 && blockIdx.x == 0) { asm volatile("" ::"v"((int)beg), "v"((int)end)); ts[2] = wall_clock64(); }
         if (end <= beg) continue;
-        for (int64_t r0 = beg + grp; r0 < end; r0 += G * RU) {
-            float4 v[RU][VL];
-            int64_t rr[RU], idv[RU];
+        // Row loop, software-pipelined: the loads of the NEXT 16 rows are in flight while the current ones are reduced (one
+        // iteration used to be a full load -> fp64 -> shuffle -> LDS-insertion round trip, 3.5 us; lists are size-biased, the
+        // longest one sets the kernel time).  Addresses are clamped to the list's last row, so every load is unconditional.
+        auto load_rows = [&](float4(&v)[RU][VL], int64_t(&idv)[RU], int64_t r0) {
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
-                rr[u] = r0 + u * G;
-                const int64_t rc = rr[u] < end ? rr[u] : end - 1;  // clamped: loads stay unconditional
+                const int64_t rr = r0 + u * G;
+                const int64_t rc = rr < end ? rr : end - 1;
                 const float4* row = (const float4*)(vecs + rc * d);
 #pragma unroll
                 for (int i = 0; i < VL; ++i) v[u][i] = row[sub + LPR * i];
                 idv[u] = ids[rc];
             }
+        };
+        auto proc_rows = [&](const float4(&v)[RU][VL], const int64_t(&idv)[RU], int64_t r0) {
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
+                const int64_t rr = r0 + u * G;
                 double acc = 0.0;
 #pragma unroll
                 for (int i = 0; i < VL; ++i) {
@@ -514,7 +526,7 @@ __global__ void __launch_bounds__(256) k_scan_v(const float* q, const int64_t* _
                     acc = fma(t3, t3, acc);
                 }
                 for (int off = LPR / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-                if (sub == 0 && rr[u] < end && before(acc, idv[u], t.d[KMAX - 1], t.id[KMAX - 1])) {
+                if (sub == 0 && rr < end && before(acc, idv[u], t.d[KMAX - 1], t.id[KMAX - 1])) {
                     int s = KMAX - 1;  // insertion into the sorted LDS list
                     while (s > 0 && before(acc, idv[u], t.d[s - 1], t.id[s - 1])) {
                         t.d[s] = t.d[s - 1];
@@ -524,18 +536,35 @@ __global__ void __launch_bounds__(256) k_scan_v(const float* q, const int64_t* _
                     }
                     t.d[s] = acc;
                     t.id[s] = idv[u];
-                    t.pos[s] = rr[u];
+                    t.pos[s] = rr;
                 }
             }
+        };
+        float4 va[RU][VL], vb[RU][VL];
+        int64_t ia[RU], ib[RU];
+        int64_t r0 = beg + grp;
+        stamp(3);
+        load_rows(va, ia, r0);
+        while (r0 < end) {
+            load_rows(vb, ib, r0 + G * RU);
+            proc_rows(va, ia, r0);
+            r0 += G * RU;
+            if (!(r0 < end)) break;
+            load_rows(va, ia, r0 + G * RU);
+            proc_rows(vb, ib, r0);
+            r0 += G * RU;
         }
     }
+    stamp(6);
     __syncthreads();
+    stamp(7);
     if (threadIdx.x < G * KMAX) {
         const int me = threadIdx.x;
         const int mg = me / KMAX, ms = me % KMAX;
         const double md = merge[mg].d[ms];
         const int64_t mid = merge[mg].id[ms];
         int rank = 0;
+#pragma unroll 8
         for (int o = 0; o < G * KMAX; ++o) {
             const double od = merge[o / KMAX].d[o % KMAX];
             const int64_t oid = merge[o / KMAX].id[o % KMAX];
@@ -577,18 +606,29 @@ __global__ void __launch_bounds__(256) k_scan_v(const float* q, const int64_t* _
             for (int s = 1; s < k; ++s) sum = add_rn(sum, w[s]);
         }
         for (int s = 0; s < k; ++s) w[s] = div_rn(w[s], sum);
+        long long pp[KMAX];  // gather positions in registers; all KMAX row loads of an element are issued before the sums
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            const long long p = s < k ? bp[s] : 0;
+            pp[s] = p < 0 ? pos_last : p;
+        }
         for (int e = threadIdx.x; e < d; e += 256) {
-            float acc = 0.f;
-            for (int s = 0; s < k; ++s) {
-                long long p = bp[s];
-                if (p < 0) p = pos_last;
-                const float prod = mul_rn(vecs[p * d + e], w[s]);
-                acc = s == 0 ? prod : add_rn(acc, prod);
-            }
+            float gv[KMAX];
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) gv[s] = vecs[pp[s] * d + e];
             const float f = bfeats[qi * d + e];
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+                if (s < k) {
+                    const float prod = mul_rn(gv[s], w[s]);
+                    acc = s == 0 ? prod : add_rn(acc, prod);
+                }
+            }
             bfeats[qi * d + e] = add_rn(mul_rn(acc, rate), mul_rn(omr, f));
         }
     }
+    stamp(8);
 }
 
 // pipeline.py:129-138 with numpy's fp32 operation order:
@@ -617,15 +657,25 @@ __global__ void __launch_bounds__(256) k_blend(float* __restrict__ feats, const 
         for (int s = 1; s < k; ++s) sum = add_rn(sum, w[s]);
     }
     for (int s = 0; s < k; ++s) w[s] = div_rn(w[s], sum);
+    int64_t pp[KMAX];  // all KMAX gathers of an element are issued before the sums (a serial load -> use chain per neighbour was 8 L2 round trips)
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        const int64_t p = s < k ? P[qi * k + s] : 0;
+        pp[s] = p < 0 ? pos_last : p;
+    }
     for (int e = threadIdx.x; e < d; e += 256) {
-        float acc = 0.f;
-        for (int s = 0; s < k; ++s) {
-            int64_t p = P[qi * k + s];
-            if (p < 0) p = pos_last;
-            const float prod = mul_rn(vecs[p * d + e], w[s]);
-            acc = s == 0 ? prod : add_rn(acc, prod);
-        }
+        float gv[KMAX];
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) gv[s] = vecs[pp[s] * d + e];
         const float f = feats[qi * d + e];
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s) {
+            if (s < k) {
+                const float prod = mul_rn(gv[s], w[s]);
+                acc = s == 0 ? prod : add_rn(acc, prod);
+            }
+        }
         feats[qi * d + e] = add_rn(mul_rn(acc, rate), mul_rn(omr, f));
     }
 }
@@ -1008,9 +1058,20 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
     h->prof.launch("ivf_scan", 3.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
         const size_t sm2 = SCAN_GROUPS * sizeof(TopK);
         if (d == 768 && !getenv("RVCMI_IVF_GENERIC")) {
+            static unsigned long long* tsd = nullptr;
+            const bool want_ts = getenv("RVCMI_IVF_STAMPS") != nullptr;
+            if (want_ts && !tsd) HIP_CHECK(hipMalloc(&tsd, 16 * 8));
+            if (want_ts) HIP_CHECK(hipMemsetAsync(tsd, 0, 16 * 8, st));
             hipLaunchKernelGGL((k_scan_v<6, 32, 2>), dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
                                h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(), bf ? bf->feats : nullptr,
-                               bf ? bf->rate : 0.f, bf ? bf->omr : 0.f, h->hdr.pos_last);
+                               bf ? bf->rate : 0.f, bf ? bf->omr : 0.f, h->hdr.pos_last, want_ts ? tsd : nullptr);
+            if (want_ts) {
+                HIP_CHECK(hipStreamSynchronize(st));
+                unsigned long long t[16];
+                HIP_CHECK(hipMemcpy(t, tsd, sizeof(t), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[ivf stamps] (10 ns units, block 0) assign %llu list_off %llu it0 %llu it1 %llu it2 %llu loop_end %llu barrier %llu merge+blend %llu total %llu\n",
+                        t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] ? t[4] - t[3] : 0, t[5] ? t[5] - t[4] : 0, t[6] - (t[5] ? t[5] : (t[4] ? t[4] : t[3])), t[7] - t[6], t[8] - t[7], t[8] - t[0]);
+            }
             fused = bf != nullptr;
             return;
         }

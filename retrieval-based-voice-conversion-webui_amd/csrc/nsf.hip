@@ -100,6 +100,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     if (max_B < 1 || max_T < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "max_B/max_T must be positive");
     HIP_CHECK(hipSetDevice(device));
     set_lds_limits();
+    rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
     h->cfg = *cfg;

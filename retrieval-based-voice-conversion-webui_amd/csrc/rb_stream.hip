@@ -53,6 +53,8 @@ int num_cus() {
     return v;
 }
 
+// nblocks < 0: only make sure the > 64 KB dynamic-LDS attribute is set on the current device (once per device and instantiation;
+// done at handle creation so that a first forward inside a stream capture does not have to)
 template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int NB = 2, int OCC = 1>
 void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
@@ -64,6 +66,7 @@ void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStre
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.fetch_or(bit);
     }
+    if (nblocks < 0) return;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(64 * NCO), smem, st, a);
 }
 
@@ -78,6 +81,19 @@ void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, 
 }
 
 }  // namespace
+
+void rb_stream_prepare() {
+    RbStreamArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int nj : {4, 3}) {
+        launch_t<__bf16>(256, 1, nj, a, -1, 1, 0, nullptr);
+        launch_t<_Float16>(256, 1, nj, a, -1, 1, 0, nullptr);
+    }
+    for (int nj : {8, 6}) {
+        launch_t<__bf16>(128, 3, nj, a, -1, 1, 0, nullptr);
+        launch_t<_Float16>(128, 3, nj, a, -1, 1, 0, nullptr);
+    }
+}
 
 bool rb_stream_supported(int operand, int C, int nd) {
     Geo g;
