@@ -1,7 +1,15 @@
-python -m pytest tests/test_gpu_ivf.py tests/test_gpu_glue.py -q 2>&1 | tail -3
-RVCMI_IVF_STAMPS=1 python bench.py --no-cpu-baseline --no-roofline --repeats 0 --steps 3 --warmup 1 --graph 0 2>&1 | grep "ivf stamps" | tail -2
-for i in 1 2; do python bench.py --no-cpu-baseline --repeats 0 --steps 50 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read());r=d['roofline'];print(round(d['ms_per_step'],4),{k:v for k,v in r['kernels_ms_per_step'].items() if k.startswith('ivf')})"; done
-python bench.py --stream 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print('  stream', d['hot_path']['p50_ms'], d['whole_chunk']['p50_ms'])"
-python tools/bench_ivf.py 2>&1 | tail -4
+python -m pytest tests -m gpu -q 2>&1 | tail -4
+python __graft_entry__.py smoke 2>&1 | tail -1
+python bench.py > gpurun_out/r02_bench_b1.json 2> gpurun_out/r02_bench_b1.err; tail -1 gpurun_out/r02_bench_b1.err
+python bench.py --batch 64 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_b64.json 2>/dev/null
+python bench.py --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_b16.json 2>/dev/null
+python bench.py --whole --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_whole_b16.json 2>/dev/null
+python bench.py --stream > gpurun_out/r02_bench_stream.json 2>/dev/null
+bash tools/profile.sh r02 > gpurun_out/prof_r02.log 2>&1; tail -1 gpurun_out/prof_r02.log
+python -c "
+import json
+for f in ('r02_bench_b1','r02_bench_b64','r02_bench_b16','r02_bench_whole_b16'):
+    d=json.load(open('gpurun_out/%s.json'%f)); r=d.get('roofline',{}); print(f, round(d['ms_per_step'],4), round(d['value'],1), d.get('repeats',{}).get('ms_per_step_median'), r.get('frac'), r.get('traffic'))
+d=json.load(open('gpurun_out/r02_bench_stream.json')); print('stream', d['hot_path'], d['whole_chunk']['p50_ms'], d['whole_chunk']['p99_ms'])
+d=json.load(open('gpurun_out/r02_bench_b1.json')); print(d['whole_infer']['ms_per_step'], d['whole_infer']['value'], d['gpu_torch_baseline']['fp16']['ms_per_clip'], d['gpu_torch_baseline']['fp32']['ms_per_clip'], d['cpu_baseline']['value'])
+"

@@ -51,8 +51,10 @@ def logical(name):
     if not m:
         return None
     fam = {"pair": "rb_pair", "full": "rb_full", "stream": "rb_stream"}[m.group(1)]
-    if fam == "rb_stream" and re.search(r"k_rb_streamI\w+?Li\d+ELi\d+ELi\d+ELi\d+ELi1E", name):
-        fam = "rb_stream1"
+    if fam == "rb_stream":  # template arguments <OpT, C, MI, NJ, NCO, ND, ...>: ND = 1 is the pair-level variant
+        nums = re.findall(r"Li(\d+)E", name)
+        if len(nums) >= 5 and nums[4] == "1":
+            fam = "rb_stream1"
     return "%s_c%s" % (fam, m.group(2))
 
 
