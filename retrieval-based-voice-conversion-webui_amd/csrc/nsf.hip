@@ -825,6 +825,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             int nj = 4;
             const long blocks4 = (long)((Lin + 128 * (4 / wv) - 1) / (128 * (4 / wv))) * B;
             if (blocks4 < 2048 && s.cin >= 128) nj = s.cin >= 512 ? 2 : 1;
+            else if (blocks4 < 2048 && s.cin == 64) nj = 2;  // (us at B = 1 after the staging fix: 84 / 75 / 89 for NJ 4 / 2 / 1)
             if (const char* e = getenv("RVCMI_UPS_NJ")) {
                 const int v = atoi(e);
                 if (v == 1 || v == 2 || v == 4) nj = v;
@@ -1077,7 +1078,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
     // ---- x = tanh(conv_post(leaky_relu(x)))                                    nsf.py:187-189
     const int nkk = c.n_resblock_kernels;
     h->prof.launch("conv_post", 2.0 * 7 * Cprev * (double)L * B, (double)B * L * (Cprev * nkk + 1) * 4, st, [&] {
-        const size_t smem = (size_t)(7 * Cprev + (POST_TT + 6) * (Cprev + 1)) * 4;
+        const size_t smem = (size_t)(7 * Cprev + (POST_TT + 6) * (Cprev + 4)) * 4;
         hipLaunchKernelGGL(k_post, dim3((unsigned)((L + POST_TT - 1) / POST_TT), B), dim3(256), smem, st, y[0], y[1], y[2],
                            h->post_w.as<float>(), out, (int)L, Cprev, div);
     });

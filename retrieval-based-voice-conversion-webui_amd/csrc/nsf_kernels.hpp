@@ -248,70 +248,83 @@ static __global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x,
 
 // out[b][t] = tanh(sum_{j,ci} lrelu(x[t-3+j][ci], 0.01) * Wp[j][ci]),  x = ((xa + xb) + xc) / div   (nsf.py:186-189)
 // HBM-bound: the last stage is read exactly once with coalesced float4 loads into an LDS tile whose
-// row stride C+1 makes the per-thread row walk conflict-free.
+// row stride C+4 floats keeps every row 16-byte aligned and the per-thread row walk (ds_read_b128, consecutive
+// lanes = consecutive rows, 20- or 36-word stride) conflict-free: 56 LDS reads per output instead of 224 scalar ones.
 constexpr int POST_TT = 256;  // = blockDim: one output sample per thread (a 128-row tile measured no faster)
+// Loops over time tiles (any grid.x).  Measured at B = 1 (2246 tiles, 1536 resident blocks): one tile per block 40-41 us,
+// grid = resident blocks 41 us, two tiles for every block 46 us -- the launch is not limited by its last half-empty round.
 static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ xa, const float* __restrict__ xb,
                                               const float* __restrict__ xc, const float* __restrict__ Wp /*[7][C]*/,
                                               float* __restrict__ out, int L, int C, float div) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* w = (float*)smem_raw;          // [7][C]
-    float* tile = w + 7 * C;              // [POST_TT + 6][C + 1]
+    float* tile = w + 7 * C;              // [POST_TT + 6][C + 4]
     const int b = blockIdx.y;
-    const int t0 = blockIdx.x * POST_TT;
-    const int S = C + 1;
+    const int S = C + 4;
     for (int i = threadIdx.x; i < 7 * C; i += 256) w[i] = Wp[i];
     const int C4 = C >> 2;
     const size_t boff = (size_t)b * L * C;
-    // batched, unconditional (clamped) loads: the former per-chunk `if (in range) { load; if (xb) load; if (xc) load }` loop was
-    // ~8 serial HBM round trips per thread
-    constexpr int SB = 5;
-    const int total = (POST_TT + 6) * C4;
-    for (int base = threadIdx.x; base < total; base += SB * 256) {
-        float4 va[SB], vb[SB], vc[SB];
-        size_t off[SB];
+    const int ntiles = (L + POST_TT - 1) / POST_TT;
+    for (int ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const int t0 = ti * POST_TT;
+        // batched, unconditional (clamped) loads: the former per-chunk `if (in range) { load; if (xb) load; if (xc) load }` loop
+        // was ~8 serial HBM round trips per thread
+        constexpr int SB = 5;
+        const int total = (POST_TT + 6) * C4;
+        for (int base = threadIdx.x; base < total; base += SB * 256) {
+            float4 va[SB], vb[SB], vc[SB];
+            size_t off[SB];
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int idx = min(base + u * 256, total - 1);
-            const int r = idx / C4, c4 = idx - r * C4;
-            const int tc = min(max(t0 - 3 + r, 0), L - 1);
-            off[u] = boff + (size_t)tc * C + c4 * 4;
-            va[u] = *(const float4*)(xa + off[u]);
-        }
-        if (xb) {
-#pragma unroll
-            for (int u = 0; u < SB; ++u) vb[u] = *(const float4*)(xb + off[u]);
-        }
-        if (xc) {
-#pragma unroll
-            for (int u = 0; u < SB; ++u) vc[u] = *(const float4*)(xc + off[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int idx = base + u * 256;
-            if (idx < total) {
+            for (int u = 0; u < SB; ++u) {
+                const int idx = min(base + u * 256, total - 1);
                 const int r = idx / C4, c4 = idx - r * C4;
-                const int t = t0 - 3 + r;
-                float4 v = va[u];
-                if (xb) { v.x += vb[u].x; v.y += vb[u].y; v.z += vb[u].z; v.w += vb[u].w; }
-                if (xc) { v.x += vc[u].x; v.y += vc[u].y; v.z += vc[u].z; v.w += vc[u].w; }
-                if (div != 1.f) { v.x = v.x / div; v.y = v.y / div; v.z = v.z / div; v.w = v.w / div; }
-                v.x = lrelu(v.x, 0.01f); v.y = lrelu(v.y, 0.01f); v.z = lrelu(v.z, 0.01f); v.w = lrelu(v.w, 0.01f);
-                if (t < 0 || t >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                float* d = tile + r * S + c4 * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                const int tc = min(max(t0 - 3 + r, 0), L - 1);
+                off[u] = boff + (size_t)tc * C + c4 * 4;
+                va[u] = *(const float4*)(xa + off[u]);
+            }
+            if (xb) {
+#pragma unroll
+                for (int u = 0; u < SB; ++u) vb[u] = *(const float4*)(xb + off[u]);
+            }
+            if (xc) {
+#pragma unroll
+                for (int u = 0; u < SB; ++u) vc[u] = *(const float4*)(xc + off[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = base + u * 256;
+                if (idx < total) {
+                    const int r = idx / C4, c4 = idx - r * C4;
+                    const int t = t0 - 3 + r;
+                    float4 v = va[u];
+                    if (xb) { v.x += vb[u].x; v.y += vb[u].y; v.z += vb[u].z; v.w += vb[u].w; }
+                    if (xc) { v.x += vc[u].x; v.y += vc[u].y; v.z += vc[u].z; v.w += vc[u].w; }
+                    if (div != 1.f) { v.x = v.x / div; v.y = v.y / div; v.z = v.z / div; v.w = v.w / div; }
+                    v.x = lrelu(v.x, 0.01f); v.y = lrelu(v.y, 0.01f); v.z = lrelu(v.z, 0.01f); v.w = lrelu(v.w, 0.01f);
+                    if (t < 0 || t >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(float4*)(tile + r * S + c4 * 4) = v;
+                }
             }
         }
+        __syncthreads();
+        const int t = t0 + threadIdx.x;
+        if (t < L) {
+            float acc = 0.f;
+            for (int j = 0; j < 7; ++j) {
+                const float4* row = (const float4*)(tile + (threadIdx.x + j) * S);
+                const float4* wj = (const float4*)(w + j * C);
+                for (int c = 0; c < C4; ++c) {  // same accumulation order as the scalar loop
+                    const float4 xv = row[c], wv = wj[c];
+                    acc = fmaf(xv.x, wv.x, acc);
+                    acc = fmaf(xv.y, wv.y, acc);
+                    acc = fmaf(xv.z, wv.z, acc);
+                    acc = fmaf(xv.w, wv.w, acc);
+                }
+            }
+            out[(size_t)b * L + t] = tanhf(acc);
+        }
+        __syncthreads();  // the tile is restaged by the next iteration
     }
-    __syncthreads();
-    const int t = t0 + threadIdx.x;
-    if (t >= L) return;
-    float acc = 0.f;
-    for (int j = 0; j < 7; ++j) {
-        const float* row = tile + (threadIdx.x + j) * S;
-        const float* wj = w + j * C;
-        for (int c = 0; c < C; ++c) acc = fmaf(row[c], wj[c], acc);
-    }
-    out[(size_t)b * L + t] = tanhf(acc);
 }
 
 // y = (a + b) + c   (debug tap of the stage sum only)
@@ -821,7 +834,7 @@ static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArg
         float4 lo[SB], hi[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int idx = base + u * NT;
+            const int idx = min(base + u * NT, total - 1);  // past the tile: re-request its last chunk (an L1 hit), not the neighbour's rows
             const int r = idx / C8;
             const int c8 = idx - r * C8;
             const int gr = x0 + r;
@@ -998,7 +1011,7 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
         float f[SB][8];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int idx = base + u * 256;
+            const int idx = min(base + u * 256, total - 1);  // past the tile: re-request its last chunk (an L1 hit), not the neighbour's rows
             const int r = idx / C8;
             const int c8 = idx - r * C8;
             const int gr = g0 + r;
@@ -1073,6 +1086,7 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
         const OpT* wlane = (const OpT*)a.w + a.ph_w_off[r] + (size_t)ct0 * a.ct_stride + lane * 8;
+// (a 4-group weight ring for the one-tile waves: 148 -> 200 VGPRs, 3 -> 2 blocks per CU; C_in 256 unchanged, 128 slower)
         if (!(a.dbg & 2)) conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.ct_stride, a.ntaps_p, a.ph_in_off[r] - a.lo, -1);
         if (a.nz_k1) {  // + noise_convs[i](har): one k-step, B = the row's 16-sample window (nsf.py:173-174)
             frag An[MI], Bn[NJ];

@@ -14,6 +14,7 @@
 #include "rb_stream_kernels.hpp"
 
 namespace rvcmi {
+int num_cus();
 
 namespace {
 
@@ -39,19 +40,6 @@ bool geo_for(int C, int nd, Geo& g) {
     return false;
 }
 
-int num_cus() {
-    static std::atomic<int> cached[64];
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    int v = cached[dev & 63].load();
-    if (!v) {
-        hipDeviceProp_t p;
-        HIP_CHECK(hipGetDeviceProperties(&p, dev));
-        v = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-        cached[dev & 63].store(v);
-    }
-    return v;
-}
 
 // nblocks < 0: only make sure the > 64 KB dynamic-LDS attribute is set on the current device (once per device and instantiation;
 // done at handle creation so that a first forward inside a stream capture does not have to)
@@ -81,6 +69,20 @@ void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, 
 }
 
 }  // namespace
+
+int num_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    int v = cached[dev & 63].load();
+    if (!v) {
+        hipDeviceProp_t p;
+        HIP_CHECK(hipGetDeviceProperties(&p, dev));
+        v = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+        cached[dev & 63].store(v);
+    }
+    return v;
+}
 
 void rb_stream_prepare() {
     RbStreamArgs a;

@@ -16,6 +16,8 @@ struct RbStreamDesc {  // one resblock (ND = 3: all its pairs) or one pair level
     int dil[3];
 };
 
+// CUs of the current device (cached per device).
+int num_cus();
 // Sets the per-device kernel attributes (dynamic LDS > 64 KB) of every instantiation; called from rvcmi_nsf_create.
 void rb_stream_prepare();
 // Channel counts / fusion depths the kernel is instantiated for.
