@@ -43,13 +43,13 @@ bool geo_for(int C, int nd, Geo& g) {
 
 // nblocks < 0: only make sure the > 64 KB dynamic-LDS attribute is set on the current device (once per device and instantiation;
 // done at handle creation so that a first forward inside a stream capture does not have to)
-template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int NB = 2, int OCC = 1>
+template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG = 4, int NB = 2, int OCC = 1>
 void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
-    auto kern = &k_rb_stream<OpT, C, MI, NJ, NCO, ND, 4, NB, OCC>;
+    auto kern = &k_rb_stream<OpT, C, MI, NJ, NCO, ND, KG, NB, OCC>;
     if (!(attr_done.load() & bit)) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.fetch_or(bit);
@@ -58,13 +58,22 @@ void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStre
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(64 * NCO), smem, st, a);
 }
 
+// weight ring of the C = 128 kernel: NB groups of KG k-steps; a group is requested (NB-1)*KG k-steps ahead of its use.
+// (4 groups of 2 k-steps -- the same 32 registers, 6 instead of 4 k-steps of L2 latency covered -- was measured: 47 instead
+// of 37 cycles per MFMA, the group bookkeeping comes twice as often; 0.69 vs 0.62 ms.  RVCMI_DEFINES="RS_KG128=2 RS_NB128=4".)
+#ifndef RS_KG128
+#define RS_KG128 4
+#endif
+#ifndef RS_NB128
+#define RS_NB128 2
+#endif
 template <typename OpT>
 void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
     if (C == 256 && nd == 1 && NJ == 4) return launch_inst<OpT, 256, 2, 4, 4, 1>(a, nblocks, B, smem, st);
     if (C == 256 && nd == 1 && NJ == 3) return launch_inst<OpT, 256, 2, 3, 4, 1>(a, nblocks, B, smem, st);
     if (C == 128 && nd == 3 && NJ == 8) return launch_inst<OpT, 128, 1, 8, 4, 3>(a, nblocks, B, smem, st);
     // (weight ring 3 / 4 groups deep instead of 2: 65 / 129 spilled registers, 0.70 -> 0.77 / 0.89 ms -- measured, not kept)
-    if (C == 128 && nd == 3 && NJ == 6) return launch_inst<OpT, 128, 1, 6, 4, 3>(a, nblocks, B, smem, st);
+    if (C == 128 && nd == 3 && NJ == 6) return launch_inst<OpT, 128, 1, 6, 4, 3, RS_KG128, RS_NB128>(a, nblocks, B, smem, st);
     RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: no instantiation for C=%d nd=%d", C, nd);
 }
 

@@ -289,6 +289,39 @@ def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu, mon
     assert rms(auto.cpu(), out.cpu()) <= 5e-4  # different families: last-bit fp32 differences re-round some fp16 operands
 
 
+def test_batch_64_bench_config_3_geometry(gpu, monkeypatch):
+    """BASELINE configs[2] exactly: 64 full-size voiced clips in one call (35 GB workspace, 4.7 GB stage-3 streams: element
+    offsets beyond 2^32 bytes, grid of 64 utterances).  First and last items (the ones at the ends of the address range) and
+    one in the middle are bit-equal to their single-clip results with the kernel family pinned; item 0 meets the parity bar
+    against the reference golden; the launcher's own (unpinned) choice agrees to operand rounding."""
+    import rvc_amd
+
+    free, _ = torch.cuda.mem_get_info(gpu)
+    if free < 60 * 2**30:
+        pytest.skip("needs ~40 GB of free HBM")
+    monkeypatch.setenv("RVCMI_RB_STREAM", "1")
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    w = synth.make_dec_weights(cfg, 1234)
+    B, T = 64, 1198
+    zs, fs, gs, ns = [], [], [], []
+    for b in range(B):
+        z, f0, g = synth.make_dec_inputs(cfg, 1, T, 1234 + b)
+        zs.append(z), fs.append(torch.roll(f0, 17 * b, dims=1)), gs.append(g)
+        ns.append(nsf_oracle.reference_noise(1, T, cfg.upp, 114514 + b))
+    Z, F, G, N = torch.cat(zs).to(gpu), torch.cat(fs).to(gpu), torch.cat(gs).to(gpu), torch.cat(ns).to(gpu)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T)
+    out = gen(Z, F, G, noise=N)
+    assert out.shape == (B, 1, T * cfg.upp) and torch.isfinite(out).all()
+    d = load_golden("full_v2_48k_T1198_voiced")
+    assert rms(out[0:1].cpu(), d["out"]) <= 1e-3
+    for b in (0, 41, 63):
+        one = gen(Z[b:b + 1].contiguous(), F[b:b + 1].contiguous(), G[b:b + 1].contiguous(), noise=N[b:b + 1].contiguous())
+        assert torch.equal(one[0], out[b]), "batch item %d differs from its single-clip result" % b
+    monkeypatch.delenv("RVCMI_RB_STREAM")
+    auto = gen(Z, F, G, noise=N)
+    assert rms(auto.cpu(), out.cpu()) <= 5e-4
+
+
 # ---- streaming fused ResBlock kernel (csrc/rb_stream_kernels.hpp) -------------------------------------------------------
 # At full clip size the launcher picks it by itself (the full-size tests above run it); RVCMI_RB_STREAM=1 forces it for
 # the small golden cases too (single short strips, sequence ends inside the first step), RVCMI_RS_SMALL=1 selects the
