@@ -702,6 +702,8 @@ static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
 
 // Branch-free helpers.  lrelu as max(x, slope*x) (0 < slope < 1); row masking by AND-ing the value bits so that
 // the compiler cannot turn the select into divergent control flow (it did: ~45 exec-masked blocks per publish).
+// (fmaxf costs a third VALU op per value -- hipcc canonicalises the operand it cannot prove quiet, `v_max_f32 t, v, v` -- but an
+//  inline-asm v_max_f32 in its place pins registers: rb_stream phases 3.0k -> 4.1k cycles, 13-29 spills.  Measured, not kept.)
 __device__ __forceinline__ float lrelu_max(float v, float slope) { return fmaxf(v, v * slope); }
 __device__ __forceinline__ float mask_bits(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
 
