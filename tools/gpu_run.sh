@@ -1,14 +1,15 @@
-pr() { python -c "
-import json,sys
-d=json.load(open('gpurun_out/$1.json')); k=d['roofline']['kernels_ms_per_step']
-print('$1', round(d['ms_per_step'],4), d.get('repeats',{}).get('ms_per_step_median'), {n:v for n,v in k.items() if n.startswith('rb_')})
-"; }
-python -m pytest tests/test_gpu_generator.py tests/test_gpu_dropin.py -m gpu -q -x 2>&1 | tail -2
-python bench.py --steps 50 --warmup 5 --repeats 5 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/b_main.json 2>gpurun_out/b_main.err; pr b_main; tail -2 gpurun_out/b_main.err
-RVCMI_NO_FORK=1 python bench.py --steps 50 --warmup 5 --repeats 5 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/b_nofork.json 2>/dev/null; pr b_nofork
-python bench.py --graph 0 --steps 50 --warmup 5 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline --no-roofline 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print('eager', round(d['ms_per_step'],4))"
-python bench.py --stream 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print('  stream', d['hot_path']['p50_ms'], d['whole_chunk']['p50_ms'])"
-RVCMI_NO_FORK=1 python bench.py --stream 2>/dev/null | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print('  stream nofork', d['hot_path']['p50_ms'], d['whole_chunk']['p50_ms'])"
+python -m pytest tests -m gpu -q 2>&1 | tail -4
+python __graft_entry__.py smoke 2>&1 | tail -1
+python bench.py > gpurun_out/r02_bench_b1.json 2> gpurun_out/r02_bench_b1.err; tail -1 gpurun_out/r02_bench_b1.err
+python bench.py --batch 64 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_b64.json 2>/dev/null
+python bench.py --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_b16.json 2>/dev/null
+python bench.py --whole --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_whole_b16.json 2>/dev/null
+python bench.py --stream > gpurun_out/r02_bench_stream.json 2>/dev/null
+bash tools/profile.sh r02 > gpurun_out/prof_r02.log 2>&1; tail -1 gpurun_out/prof_r02.log
+python -c "
+import json
+for f in ('r02_bench_b1','r02_bench_b64','r02_bench_b16','r02_bench_whole_b16'):
+    d=json.load(open('gpurun_out/%s.json'%f)); r=d.get('roofline',{}); print(f, round(d['ms_per_step'],4), round(d['value'],1), d.get('repeats',{}).get('ms_per_step_median'), r.get('frac'), r.get('traffic'))
+d=json.load(open('gpurun_out/r02_bench_stream.json')); print('stream', d['hot_path'], d['whole_chunk']['p50_ms'], d['whole_chunk']['p99_ms'])
+d=json.load(open('gpurun_out/r02_bench_b1.json')); print(d['whole_infer']['ms_per_step'], d['whole_infer']['value'], d['gpu_torch_baseline']['fp16']['ms_per_clip'], d['gpu_torch_baseline']['fp32']['ms_per_clip'], d['cpu_baseline']['value'])
+"
