@@ -497,7 +497,57 @@ def main():
         scan = [s for s in ivs if s["name"] == "ivf_scan"]
         if scan and scan[0]["ms"] > 0:
             roof["ivf_scan_hbm"] = {"achieved": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                    "frac": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 8e12}
+                                    "frac": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 8e12,
+                                    "bytes_model": "ntotal / nlist rows per query (lists of equal size)"}
+            if idx is not None:
+                # what the scan really walks on THIS index: i.i.d. Gaussian rows give very unequal lists and the (equally
+                # random) queries land in the big ones.  Host arithmetic on the inputs, outside every timed region.
+                import numpy as np
+
+                sizes = np.diff(np.asarray(idx["list_offsets"]))
+                asg = synth.assign_nearest(phone.reshape(-1, a.index_d).numpy(), np.asarray(idx["centroids"]))
+                rows = int(sizes[asg].sum())
+                ms1 = scan[0]["ms"] / scan[0]["launches"]
+                sb = rows * (4.0 * a.index_d + 8)
+                roof["ivf_scan_hbm"].update({
+                    "rows_per_query_model": a.index_n / max(1, len(sizes)), "rows_per_query_scanned": rows / max(1, len(asg)),
+                    "largest_list": int(sizes.max()), "scanned_bytes": sb, "scanned_GBps": sb / (ms1 * 1e-3) / 1e9,
+                    "unique_list_bytes": float(sizes[np.unique(asg)].sum()) * (4.0 * a.index_d + 8),
+                    "note": "scanned_GBps counts every row a query block reads (mostly L2 hits: many queries share a list)"})
+            if idx is not None and B == 1 and a.index_d == 768:
+                # side leg, not part of `value`: the same search on an index whose rows have cluster structure (lists of
+                # comparable size, the bytes model above holds), queries drawn from the same mixture
+                try:
+                    import numpy as np
+
+                    xr, cen = synth.make_clustered_rows(a.index_n + NQ_CLIP, a.index_d, synth.ivf_nlist(a.index_n), return_centres=True)
+                    idc = synth.make_ivf_from_rows(xr[:a.index_n], kmeans_iters=2, init=cen)  # = a converged k-means on this data
+                    ixc = rvc_amd.IVFFlatHIP.from_arrays(idc["centroids"], idc["list_offsets"], idc["ids"], idc["vecs"], device=dev).reserve(NQ_CLIP)
+                    qc = torch.from_numpy(xr[a.index_n:]).to(dev).contiguous()
+                    fb = torch.empty_like(qc)
+                    for _ in range(3):
+                        fb.copy_(qc)
+                        ixc.search_blend(fb, a.index_rate, 8)
+                    ixc.profile(True)
+                    for _ in range(10):
+                        fb.copy_(qc)
+                        ixc.search_blend(fb, a.index_rate, 8)
+                    torch.cuda.synchronize()
+                    st_c = {s_["name"]: s_ for s_ in ixc.profile_read()}
+                    ixc.profile(False)
+                    szc = np.diff(np.asarray(idc["list_offsets"]))
+                    asc = synth.assign_nearest(xr[a.index_n:], np.asarray(idc["centroids"]))
+                    rows_c = int(szc[asc].sum())
+                    sc = st_c["ivf_scan"]
+                    msc = sc["ms"] / sc["launches"]
+                    sbc = rows_c * (4.0 * a.index_d + 8)
+                    roof["ivf_clustered_index"] = {
+                        "what": "same search + blend on a 10000 x 768 index of clustered rows (synth.make_clustered_rows), 599 queries of the same mixture",
+                        "scan_us": 1e3 * msc, "coarse_us": 1e3 * st_c["ivf_coarse"]["ms"] / st_c["ivf_coarse"]["launches"],
+                        "rows_per_query_scanned": rows_c / len(asc), "largest_list": int(szc.max()), "scanned_bytes": sbc,
+                        "scanned_GBps": sbc / (msc * 1e-3) / 1e9, "frac_of_8TBps": sbc / (msc * 1e-3) / 8e12}
+                except Exception as e:  # noqa
+                    roof["ivf_clustered_index"] = {"error": str(e)[:200]}
 
     # ---- whole net_g.infer leg: retrieval -> x2 frames -> enc_p -> z_p -> flow^-1 -> decode, one graph ----
     whole = None

@@ -199,6 +199,18 @@ def make_ivf(n: int, d: int, nlist: Optional[int] = None, seed: int = 4321, kmea
     return make_ivf_from_rows(x, nlist, rng, kmeans_iters)
 
 
+def make_clustered_rows(n: int, d: int, nclusters: int, spread: float = 0.35, seed: int = 77, return_centres: bool = False):
+    """Rows with cluster structure (a mixture of `nclusters` isotropic Gaussians of std `spread` around unit-variance
+    centres): k-means on such data gives inverted lists of comparable size, as on real HuBERT features -- i.i.d. Gaussian
+    rows (`make_ivf`) have no structure in 768 dimensions and end up in a few huge lists (10000 x 768: largest list 416 rows
+    for a mean of 39, and random queries probe lists of ~300 rows on average)."""
+    rng = np.random.default_rng(seed)
+    cent = rng.standard_normal((nclusters, d), dtype=np.float32)
+    lab = rng.integers(0, nclusters, size=n)
+    x = (cent[lab] + spread * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    return (x, cent) if return_centres else x
+
+
 def make_mute_rows(feats: np.ndarray, copies: int = 40, jitter: float = 2e-3, seed: int = 5) -> np.ndarray:
     """A training-set-like matrix with the REAL HuBERT distribution of the reference's mute clip (tests/golden/mute_hubert.npz):
     the 149 rows, one exact second copy of them (exact distance ties between different ids, on top of the duplicate rows the
@@ -211,14 +223,15 @@ def make_mute_rows(feats: np.ndarray, copies: int = 40, jitter: float = 2e-3, se
     return np.ascontiguousarray(x[rng.permutation(x.shape[0])])
 
 
-def make_ivf_from_rows(x: np.ndarray, nlist: Optional[int] = None, rng=None, kmeans_iters: int = 2) -> dict:
-    """The IVF layout of `make_ivf` for a given training matrix x [n, d] (ids = row numbers, the sequential `add`)."""
+def make_ivf_from_rows(x: np.ndarray, nlist: Optional[int] = None, rng=None, kmeans_iters: int = 2, init: Optional[np.ndarray] = None) -> dict:
+    """The IVF layout of `make_ivf` for a given training matrix x [n, d] (ids = row numbers, the sequential `add`).
+    `init`: starting centroids [nlist, d] instead of sampled rows (a converged k-means on data whose clusters are known)."""
     rng = np.random.default_rng(0) if rng is None else rng
     x = np.ascontiguousarray(x, dtype=np.float32)
     n, d = x.shape
     if nlist is None:
         nlist = ivf_nlist(n)
-    cent = x[rng.choice(n, size=nlist, replace=False)].copy()
+    cent = x[rng.choice(n, size=nlist, replace=False)].copy() if init is None else np.ascontiguousarray(init, dtype=np.float32).copy()
     assign = None
     for it in range(kmeans_iters + 1):
         assign = assign_nearest(x, cent)
