@@ -303,8 +303,8 @@ def stream_mode(a):
 
         def whole():
             hbuf.copy_(hub)
-            index.search_blend(hbuf[SKIP // 2:], a.index_rate, 8, skip_if_short=True)          # rtrvc.py:167-186
-            ph = rvc_amd.glue.retrieve_blend_expand(hbuf.unsqueeze(0), None, 0.0, pitchf_all, 0.33, P_LEN)   # :221-233 (x2, protect; blend done above)
+            ph = rvc_amd.glue.retrieve_blend_expand(hbuf.unsqueeze(0), index, a.index_rate, pitchf_all, 0.33, P_LEN, realtime_guard=True,
+                                                    skip_rows=SKIP // 2)   # rtrvc.py:167-186 (search + blend of the new rows), :221-233 (x2, protect)
             wav = rvc_amd.infer_hip(net, front, ph, None, sid0, pitch_all, pitchf_all, SKIP, RET, RET)[0, 0]  # :236-247
             hold["w"] = rvc_amd.glue.sola(wav.contiguous(), sola_buf, fade_in, fade_out, blk, Ls)  # gui.py:1057-1090
 

@@ -33,11 +33,33 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+def _blend_expand_into(out: torch.Tensor, f: torch.Tensor, index, index_rate: float, pf: Optional[torch.Tensor], protect: float,
+                       realtime_guard: bool) -> None:
+    """out [p_len, d] (a contiguous row slice) <- x2(f [nq, d]), blended against ``index`` first when given, protect-mixed."""
+    nq, d = int(f.shape[0]), int(f.shape[1])
+    p_len = int(out.shape[0])
+    dev = f.device
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        if index is not None and index_rate != 0:
+            if d != index.d:
+                raise ValueError("index mistatch")  # the reference's message (pipeline.py:128)
+            index.reserve(nq)
+            _lib.check(L.rvcmi_ivf_search_blend_expand(index._h, nq, _ptr(f), float(index_rate), 8, 1 if realtime_guard else 0,
+                                                       _ptr(pf), float(protect), p_len, _ptr(out), _stream(dev)))
+        else:
+            _lib.check(L.rvcmi_glue_expand_protect(_ptr(f), nq, d, 2, _ptr(pf), float(protect), p_len, _ptr(out), _stream(dev)))
+
+
 def retrieve_blend_expand(feats: torch.Tensor, index, index_rate: float, pitchf: Optional[torch.Tensor] = None,
-                          protect: float = 0.5, p_len: Optional[int] = None, realtime_guard: bool = False) -> torch.Tensor:
+                          protect: float = 0.5, p_len: Optional[int] = None, realtime_guard: bool = False,
+                          skip_rows: int = 0) -> torch.Tensor:
     """``feats`` [1, nq, d] HuBERT features -> [1, p_len, d]: retrieval blend (when ``index`` is given and
     ``index_rate != 0``), x2 nearest interpolation, truncation to ``p_len`` and the protect mix
-    (``pitchf`` [1, >= p_len], applied when ``protect < 0.5`` as in pipeline.py:153)."""
+    (``pitchf`` [1, >= p_len], applied when ``protect < 0.5`` as in pipeline.py:153).
+
+    ``skip_rows`` > 0 is the realtime form (rtrvc.py:167-185, 221-233): only ``feats[0][skip_rows:]`` is searched and
+    blended (the rolling window's old frames keep their HuBERT features); the protect mix runs over all rows."""
     dev = _dev(feats, "feats")
     if feats.dim() != 3 or feats.shape[0] != 1:
         raise ValueError("feats must be [1, nq, d]")
@@ -50,16 +72,15 @@ def retrieve_blend_expand(feats: torch.Tensor, index, index_rate: float, pitchf:
         if pf.numel() < p_len:
             raise ValueError("pitchf has %d frames, p_len is %d" % (pf.numel(), p_len))
     out = torch.empty(p_len, d, device=dev, dtype=torch.float32)
-    L = _lib.lib()
-    with torch.cuda.device(dev):
-        if index is not None and index_rate != 0:
-            if d != index.d:
-                raise ValueError("index mistatch")  # the reference's message (pipeline.py:128)
-            index.reserve(nq)
-            _lib.check(L.rvcmi_ivf_search_blend_expand(index._h, nq, _ptr(f), float(index_rate), 8, 1 if realtime_guard else 0,
-                                                       _ptr(pf), float(protect), p_len, _ptr(out), _stream(dev)))
-        else:
-            _lib.check(L.rvcmi_glue_expand_protect(_ptr(f), nq, d, 2, _ptr(pf), float(protect), p_len, _ptr(out), _stream(dev)))
+    h = max(0, min(int(skip_rows), nq))
+    if h and index is not None and index_rate != 0:
+        # rows [0, h): un-blended (feats0 == feats in the protect mix); rows [h, nq): searched and blended
+        head = min(2 * h, p_len)
+        _blend_expand_into(out[:head], f[:h], None, 0.0, None if pf is None else pf[:head], protect, False)
+        if head < p_len:
+            _blend_expand_into(out[head:], f[h:], index, index_rate, None if pf is None else pf[head:], protect, realtime_guard)
+    else:
+        _blend_expand_into(out, f, index, index_rate, pf, protect, realtime_guard)
     return out.unsqueeze(0).to(feats.dtype)
 
 

@@ -1,0 +1,113 @@
+"""Host-side mirror of the realtime caller ``infer/lib/rtrvc.py`` ``RVC.infer`` for everything after HuBERT and the f0
+extractor (rtrvc.py:163-251): retrieval on the new frames only, pitch caches, x2 + protect, ``net_g.infer`` with
+``skip_head / return_length / return_length2``.  All tensors live on the GPU; the compute runs in the HIP library
+(``IVFFlatHIP``, ``glue``, the accelerated ``net_g``), this class only keeps the rolling state the reference keeps.
+
+    rt = RealtimeVC(net_g, index=rvc_amd.read_index(path), index_rate=0.75, device="cuda:0")
+    wav = rt.infer(hubert_feats, n_input_samples, block_frame_16k, skip_head, return_length, pitch=p, pitchf=pf)
+
+HuBERT, the f0 estimators and the optional formant resample (``torchaudio.transforms.Resample``, rtrvc.py:249-259) stay
+PyTorch, as in the reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import glue
+
+
+def f0_extractor_frame(block_frame_16k: int, method: str = "fcpe", window: int = 160) -> int:
+    """Samples of the rolling input the f0 estimator sees per block (rtrvc.py:203-207)."""
+    n = int(block_frame_16k) + 800
+    if method == "rmvpe":
+        n = 5120 * ((n - 1) // 5120 + 1) - window
+    return n
+
+
+class PitchCache:
+    """``cache_pitch`` / ``cache_pitchf`` of rtrvc.py:63-66 and their per-block update (rtrvc.py:213-217)."""
+
+    def __init__(self, device, size: int = 1024):
+        self.pitch = torch.zeros(size, device=device, dtype=torch.long)
+        self.pitchf = torch.zeros(size, device=device, dtype=torch.float32)
+
+    def update(self, pitch: torch.Tensor, pitchf: torch.Tensor, block_frame_16k: int, window: int = 160) -> None:
+        """Shift both caches left by one block and write the estimator's new frames (its first three and last one are
+        dropped) at the end."""
+        shift = int(block_frame_16k) // int(window)
+        n = int(pitch.shape[0])
+        if n < 5 or n - 4 > self.pitch.numel():
+            raise ValueError("pitch block of %d frames does not fit the cache" % n)
+        if shift > 0:
+            self.pitch[:-shift] = self.pitch[shift:].clone()
+            self.pitchf[:-shift] = self.pitchf[shift:].clone()
+        self.pitch[4 - n:] = pitch[3:-1].to(self.pitch.device, torch.long)
+        self.pitchf[4 - n:] = pitchf[3:-1].to(self.pitchf.device, torch.float32)
+
+    def window(self, p_len: int, return_length: int, return_length2: int):
+        """(pitch, pitchf) [1, p_len] handed to ``net_g.infer`` (rtrvc.py:216-219; pitchf follows the formant factor)."""
+        return self.pitch[None, -p_len:], self.pitchf[None, -p_len:] * return_length2 / return_length
+
+
+class RealtimeVC:
+    def __init__(self, net_g, index=None, index_rate: float = 0.0, device="cuda:0", if_f0: int = 1, tgt_sr: int = 48000,
+                 f0_up_key: float = 0.0, formant_shift: float = 0.0, window: int = 160):
+        self.net_g, self.index, self.index_rate = net_g, index, float(index_rate)
+        self.device = torch.device(device)
+        self.if_f0, self.tgt_sr, self.window = int(if_f0), int(tgt_sr), int(window)
+        self.f0_up_key, self.formant_shift = f0_up_key, formant_shift
+        self.cache = PitchCache(self.device)
+        self._resample = {}
+
+    # rtrvc.py:122-132
+    def set_key(self, new_key):
+        self.f0_up_key = new_key
+
+    def set_formant(self, new_formant):
+        self.formant_shift = new_formant
+
+    def set_index_rate(self, new_index_rate):
+        self.index_rate = float(new_index_rate)
+
+    def infer(self, feats: torch.Tensor, n_input_samples: int, block_frame_16k: int, skip_head: int, return_length: int,
+              pitch: Optional[torch.Tensor] = None, pitchf: Optional[torch.Tensor] = None, protect: float = 1.0,
+              sid: int = 0) -> torch.Tensor:
+        """``feats`` [1, n, d]: the HuBERT output of the whole rolling window (before its last frame is repeated,
+        rtrvc.py:163).  ``pitch`` / ``pitchf`` [m]: what the f0 estimator returned for the last
+        ``f0_extractor_frame`` samples (``None`` for a model without f0).  Returns the block's waveform [L]."""
+        if feats.dim() != 3 or feats.shape[0] != 1:
+            raise ValueError("feats must be [1, n, d]")
+        feats = torch.cat((feats, feats[:, -1:, :]), 1)                                   # rtrvc.py:163
+        p_len = int(n_input_samples) // self.window                                       # :189
+        factor = pow(2, self.formant_shift / 12)                                          # :190
+        return_length2 = int(math.ceil(return_length * factor))                           # :191
+        cache_pitch = cache_pitchf = None
+        if self.if_f0 == 1:
+            if pitch is None or pitchf is None:
+                raise ValueError("an f0 model needs the block's pitch / pitchf")
+            self.cache.update(pitch, pitchf, block_frame_16k, self.window)                # :213-217
+            cache_pitch, cache_pitchf = self.cache.window(p_len, return_length, return_length2)
+        use_index = self.index is not None and self.index_rate > 0                        # :167
+        pf = pitchf if (protect < 0.5 and pitch is not None and pitchf is not None) else None   # :224
+        phone = glue.retrieve_blend_expand(feats, self.index if use_index else None, self.index_rate if use_index else 0.0,
+                                           pf, protect if pf is not None else 1.0, p_len, realtime_guard=True,
+                                           skip_rows=int(skip_head) // 2)                  # :167-185, 221-233
+        lengths = torch.tensor([p_len], dtype=torch.long, device=self.device)
+        sid_t = torch.tensor([int(sid)], dtype=torch.long, device=self.device)
+        with torch.no_grad():
+            audio = self.net_g.infer(phone, lengths, sid_t, pitch=cache_pitch, pitchf=cache_pitchf, skip_head=skip_head,
+                                     return_length=return_length, return_length2=return_length2)   # :236-247
+        audio = audio.squeeze(1).float()
+        upp_res = int(math.floor(factor * self.tgt_sr // 100))                            # :248
+        if upp_res != self.tgt_sr // 100:                                                 # :249-259 (formant shift only)
+            try:
+                from torchaudio.transforms import Resample
+            except ImportError as e:  # pragma: no cover - torchaudio is part of every RVC install
+                raise RuntimeError("formant_shift != 0 needs torchaudio's Resample, as in rtrvc.py:251") from e
+            if upp_res not in self._resample:
+                self._resample[upp_res] = Resample(orig_freq=upp_res, new_freq=self.tgt_sr // 100, dtype=torch.float32).to(self.device)
+            audio = self._resample[upp_res](audio[:, : return_length * upp_res])
+        return audio.squeeze()

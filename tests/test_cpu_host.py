@@ -253,3 +253,31 @@ def test_bf16_operands_warn_before_anything_else():
     with pytest.warns(RuntimeWarning, match="bf16"):
         with pytest.raises(Exception):
             rvc_amd.NSFGeneratorHIP(vars(cfg), {}, device="cuda:0" if torch.cuda.is_available() else "cuda:0", operand="bf16")
+
+
+def test_realtime_pitch_cache_and_frame_arithmetic():
+    """rtrvc.py:203-219 on the host: the f0 window length per method and the rolling pitch caches."""
+    import rvc_amd
+
+    assert rvc_amd.f0_extractor_frame(4000, "fcpe") == 4800
+    assert rvc_amd.f0_extractor_frame(4000, "rmvpe") == 5120 - 160 and rvc_amd.f0_extractor_frame(5000, "rmvpe") == 2 * 5120 - 160
+    pc = rvc_amd.PitchCache("cpu")
+    cp = np.zeros(1024, dtype=np.int64)
+    cf = np.zeros(1024, dtype=np.float32)
+    rng = np.random.default_rng(0)
+    for blk in range(6):
+        n = int(rng.integers(20, 60))
+        pitch = torch.from_numpy(rng.integers(1, 255, size=n))
+        pitchf = torch.from_numpy(rng.uniform(50, 800, size=n).astype(np.float32))
+        block = int(rng.choice([1600, 4000, 8000]))
+        pc.update(pitch, pitchf, block)
+        shift = block // 160
+        cp[:-shift] = cp[shift:].copy()
+        cf[:-shift] = cf[shift:].copy()
+        cp[4 - n:] = pitch.numpy()[3:-1]
+        cf[4 - n:] = pitchf.numpy()[3:-1]
+        assert np.array_equal(pc.pitch.numpy(), cp) and np.array_equal(pc.pitchf.numpy(), cf)
+    p, f = pc.window(100, 25, 29)
+    assert p.shape == (1, 100) and np.allclose(f[0].numpy(), cf[-100:] * 29 / 25)
+    with pytest.raises(ValueError):
+        pc.update(torch.zeros(3, dtype=torch.long), torch.zeros(3), 1600)

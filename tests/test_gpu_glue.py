@@ -96,6 +96,86 @@ def test_retrieve_blend_expand_matches_pipeline_expression(use_index, protect, p
         assert torch.equal(got, ref), "max abs diff %.3e" % (got - ref).abs().max()
 
 
+@pytest.mark.parametrize("skip_rows,protect", [(20, 0.33), (45, 0.5), (0, 0.2)])
+def test_realtime_partial_blend_expand_protect(skip_rows, protect, gpu):
+    """rtrvc.py:167-185 + 221-233: only feats[0][skip_head // 2:] is searched and blended; x2 and the protect mix cover all
+    rows (feats0 = the un-blended clone)."""
+    import rvc_amd
+
+    nq, d_, p_len = 60, 256, 117
+    idx = synth.make_ivf(3000, d_, seed=11)
+    feats = 0.5 * torch.randn(1, nq, d_, generator=torch.Generator().manual_seed(3))
+    pitchf = synth.make_f0(1, 2 * nq)
+    hip = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=gpu)
+    got = rvc_amd.glue.retrieve_blend_expand(feats.to(gpu), hip, 0.75, pitchf.to(gpu), protect, p_len, realtime_guard=True,
+                                             skip_rows=skip_rows).cpu()
+    blended = feats.clone()
+    blended[0, skip_rows:] = torch.from_numpy(ivf_oracle.search_blend(idx, feats[0, skip_rows:].numpy(), 0.75))
+    ref = glue_oracle.expand_protect(blended, feats, pitchf, protect, p_len)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() <= 2e-6, "max abs diff %.3e" % (got - ref).abs().max()
+    assert torch.equal(got[0, :2 * skip_rows], glue_oracle.expand_protect(feats, feats, pitchf, protect, p_len)[0, :2 * skip_rows])
+
+
+def test_realtime_vc_block_loop(gpu):
+    """RealtimeVC (the rtrvc.py RVC.infer mirror) over three blocks of a rolling window: the phone / pitch / pitchf it hands
+    to net_g.infer are the reference's expressions (rtrvc.py:163, 189-191, 209-233) evaluated literally."""
+    import rvc_amd
+
+    d_, win = 256, 160
+    idx = synth.make_ivf(3000, d_, seed=11)
+    hip = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=gpu)
+    seen = {}
+
+    class Net:  # records what infer receives, returns a dummy block
+        def infer(self, phone, lengths, sid, pitch=None, pitchf=None, skip_head=None, return_length=None, return_length2=None):
+            seen.update(phone=phone.cpu(), lengths=lengths.cpu(), pitch=pitch.cpu(), pitchf=pitchf.cpu(), skip_head=skip_head,
+                        return_length=return_length, return_length2=return_length2)
+            return torch.zeros(1, 1, return_length * 480, device=phone.device)
+
+    rt = rvc_amd.RealtimeVC(Net(), index=hip, index_rate=0.75, device=gpu, tgt_sr=48000)
+    n_samples, block16k, skip_head, ret_len = 160 * 118, 4000, 40, 25
+    p_len = n_samples // win
+    cp = np.zeros(1024, dtype=np.int64)
+    cf = np.zeros(1024, dtype=np.float32)
+    g = torch.Generator().manual_seed(5)
+    for blk in range(3):
+        feats = 0.5 * torch.randn(1, 59, d_, generator=g)
+        m = p_len
+        pitchf = synth.make_f0(1, m + 7)[0, blk:blk + m].contiguous()
+        pitch = synth.make_pitch(pitchf[None])[0]
+        wav = rt.infer(feats.to(gpu), n_samples, block16k, skip_head, ret_len, pitch=pitch.to(gpu), pitchf=pitchf.to(gpu), protect=0.33)
+        assert wav.shape == (ret_len * 480,)
+        # literal rtrvc.py:209-219
+        shift = block16k // win
+        cp[:-shift] = cp[shift:].copy()
+        cf[:-shift] = cf[shift:].copy()
+        cp[4 - m:] = pitch.numpy()[3:-1]
+        cf[4 - m:] = pitchf.numpy()[3:-1]
+        assert np.array_equal(seen["pitch"][0].numpy(), cp[-p_len:]), "pitch window"
+        assert np.allclose(seen["pitchf"][0].numpy(), cf[-p_len:] * ret_len / ret_len, rtol=1e-6, atol=0), "pitchf window"  # (x * rl2) / rl on the device
+        assert seen["skip_head"] == skip_head and seen["return_length"] == ret_len and seen["return_length2"] == ret_len
+        assert int(seen["lengths"][0]) == p_len
+        f2 = torch.cat((feats, feats[:, -1:]), 1)
+        blended = f2.clone()
+        blended[0, skip_head // 2:] = torch.from_numpy(ivf_oracle.search_blend(idx, f2[0, skip_head // 2:].numpy(), 0.75))
+        ref = glue_oracle.expand_protect(blended, f2, pitchf[None], 0.33, p_len)
+        assert seen["phone"].shape == ref.shape, (seen["phone"].shape, ref.shape)
+        assert (seen["phone"] - ref).abs().max() <= 2e-6, "phone: max abs diff %.3e" % (seen["phone"] - ref).abs().max()
+    rt.set_formant(2.0)  # rtrvc.py:190-191, 218-219: the decoder is asked for ceil(return_length * 2^(2/12)) frames
+    try:
+        rt.infer(feats.to(gpu), n_samples, block16k, skip_head, ret_len, pitch=pitch.to(gpu), pitchf=pitchf.to(gpu))
+    except RuntimeError as e:  # torchaudio (the reference's own resampler, rtrvc.py:251) is not installed in this image
+        assert "torchaudio" in str(e)
+    cp[:-shift] = cp[shift:].copy()
+    cf[:-shift] = cf[shift:].copy()
+    cp[4 - m:] = pitch.numpy()[3:-1]
+    cf[4 - m:] = pitchf.numpy()[3:-1]
+    rl2 = int(np.ceil(ret_len * 2 ** (2.0 / 12)))
+    assert seen["return_length2"] == rl2
+    assert np.allclose(seen["pitchf"][0].numpy(), cf[-p_len:] * rl2 / ret_len, rtol=1e-6)
+
+
 def test_scale_int16_range(gpu):
     import rvc_amd
 
