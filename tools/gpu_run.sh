@@ -1,10 +1,8 @@
-python -m pytest tests/test_gpu_ivf.py tests/test_gpu_glue.py -m gpu -q -x 2>&1 | tail -3
-pr() { python -c "
-import json,sys
-d=json.load(open('gpurun_out/$1.json')); k=d['roofline']['kernels_ms_per_step']
-print('$1', round(d['ms_per_step'],4), d.get('repeats',{}).get('ms_per_step_median'), {n:v for n,v in k.items() if n.startswith('ivf')}, d['roofline'].get('ivf_clustered_index',{}).get('scan_us'))
-"; }
-python bench.py --steps 50 --warmup 5 --repeats 5 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/b_main.json 2>/dev/null; pr b_main
-RVCMI_IVF_NOCHUNK=1 python bench.py --steps 50 --warmup 5 --repeats 5 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/b_nochunk.json 2>/dev/null; pr b_nochunk
-python bench.py --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/b_16.json 2>/dev/null; pr b_16
-RVCMI_IVF_NOCHUNK=1 python bench.py --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/b_16n.json 2>/dev/null; pr b_16n
+python bench.py > gpurun_out/r02_bench_b1.json 2> gpurun_out/r02_bench_b1.err; tail -1 gpurun_out/r02_bench_b1.err
+python -c "
+import json
+d=json.load(open('gpurun_out/r02_bench_b1.json')); r=d['roofline']
+print(round(d['ms_per_step'],4), round(d['value'],1), d['repeats']['ms_per_step_median'], r['frac'], r['kernels_ms_per_step'])
+print(d['whole_infer']['ms_per_step'], d['gpu_torch_baseline']['fp16']['ms_per_clip'], d['cpu_baseline']['value'])
+"
+rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -i "sclk\|power\|temp" | head -8
