@@ -1,8 +1,15 @@
+python -m pytest tests -m gpu -q 2>&1 | tail -4
+python __graft_entry__.py smoke 2>&1 | tail -1
 python bench.py > gpurun_out/r02_bench_b1.json 2> gpurun_out/r02_bench_b1.err; tail -1 gpurun_out/r02_bench_b1.err
+python bench.py --batch 64 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_b64.json 2>/dev/null
+python bench.py --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_b16.json 2>/dev/null
+python bench.py --whole --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline > gpurun_out/r02_bench_whole_b16.json 2>/dev/null
+python bench.py --stream > gpurun_out/r02_bench_stream.json 2>/dev/null
+bash tools/profile.sh r02 > gpurun_out/prof_r02.log 2>&1; tail -1 gpurun_out/prof_r02.log
 python -c "
 import json
-d=json.load(open('gpurun_out/r02_bench_b1.json')); r=d['roofline']
-print(round(d['ms_per_step'],4), round(d['value'],1), d['repeats']['ms_per_step_median'], r['frac'], r['kernels_ms_per_step'])
-print(d['whole_infer']['ms_per_step'], d['gpu_torch_baseline']['fp16']['ms_per_clip'], d['cpu_baseline']['value'])
+for f in ('r02_bench_b1','r02_bench_b64','r02_bench_b16','r02_bench_whole_b16'):
+    d=json.load(open('gpurun_out/%s.json'%f)); r=d.get('roofline',{}); print(f, round(d['ms_per_step'],4), round(d['value'],1), d.get('repeats',{}).get('ms_per_step_median'), r.get('frac'), r.get('traffic'))
+d=json.load(open('gpurun_out/r02_bench_stream.json')); print('stream', d['hot_path'], d['whole_chunk']['p50_ms'], d['whole_chunk']['p99_ms'])
+d=json.load(open('gpurun_out/r02_bench_b1.json')); print(d['whole_infer']['ms_per_step'], d['whole_infer']['value'], d['gpu_torch_baseline']['fp16']['ms_per_clip'], d['gpu_torch_baseline']['fp32']['ms_per_clip'], d['cpu_baseline']['value'])
 "
-rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -i "sclk\|power\|temp" | head -8
