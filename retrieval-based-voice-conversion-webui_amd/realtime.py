@@ -61,6 +61,13 @@ class RealtimeVC:
         self.f0_up_key, self.formant_shift = f0_up_key, formant_shift
         self.cache = PitchCache(self.device)
         self._resample = {}
+        self._consts = {}
+
+    def _const(self, v: int) -> torch.Tensor:
+        t = self._consts.get(v)
+        if t is None:
+            t = self._consts[v] = torch.tensor([v], dtype=torch.long, device=self.device)
+        return t
 
     # rtrvc.py:122-132
     def set_key(self, new_key):
@@ -95,8 +102,7 @@ class RealtimeVC:
         phone = glue.retrieve_blend_expand(feats, self.index if use_index else None, self.index_rate if use_index else 0.0,
                                            pf, protect if pf is not None else 1.0, p_len, realtime_guard=True,
                                            skip_rows=int(skip_head) // 2)                  # :167-185, 221-233
-        lengths = torch.tensor([p_len], dtype=torch.long, device=self.device)
-        sid_t = torch.tensor([int(sid)], dtype=torch.long, device=self.device)
+        lengths, sid_t = self._const(p_len), self._const(int(sid))   # cached: no host-to-device copy per block
         with torch.no_grad():
             audio = self.net_g.infer(phone, lengths, sid_t, pitch=cache_pitch, pitchf=cache_pitchf, skip_head=skip_head,
                                      return_length=return_length, return_length2=return_length2)   # :236-247
