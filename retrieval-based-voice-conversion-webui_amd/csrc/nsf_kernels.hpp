@@ -1240,8 +1240,51 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
         rowmask[jt] = (tg >= 0 && tg < a.L) ? 0xffffffffu : 0u;
     }
 
-    // ---- load x straight into the accumulator layout (clamped addresses: unconditional loads) -----------
+    // ---- load x into the accumulator layout ---------------------------------------------------------------
+    // A D-layout global access touches 32 rows x 32 bytes per instruction and costs ~54 cycles of the CU's address path
+    // (measured); with one block per CU nothing overlaps it.  TIO: the tile is read as whole rows
+    // (1 KB contiguous per instruction) into the not-yet-used operand regions of LDS and picked up from there in D layout
+    // (row stride C*4 + 16 bytes: 16 consecutive rows hit 16 different 16-byte bank groups); the store goes the same way back.
+#ifndef RBF_TIO
+#define RBF_TIO 1
+#endif
+    constexpr bool TIO = (C % 32 == 0) && (RBF_TIO != 0);
+    constexpr int TS = C * 4 + 16;
+    constexpr int C4 = C / 4;
+    static_assert(!TIO || (size_t)R * TS <= (size_t)(XROWS + HROWS) * STRIDE, "transposition tile must fit the X | H regions");
+    static_assert(!TIO || (R * C4) % NT == 0, "whole batches of row chunks");
     f32x16 xacc[MI][NJ];
+    if constexpr (TIO) {
+        constexpr int PER = R * C4 / NT;
+        float4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = (int)threadIdx.x + u * NT;
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int tg = tg0 + row;
+            const int tgc = min(max(tg, 0), a.L - 1);
+            v[u] = *(const float4*)(src + (size_t)tgc * C + c4 * 4);
+            if (tg < 0 || tg >= a.L) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows outside the utterance read as zero
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = (int)threadIdx.x + u * NT;
+            const int row = idx / C4, c4 = idx - row * C4;
+            *(float4*)(smem + (size_t)row * TS + c4 * 16) = v[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 q = *(const f32x4*)(smem + (size_t)(slab + jt * 32 + (lane & 31)) * TS + (mi * 32 + 8 * g + half4) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] = q[e];
+                }
+        __syncthreads();  // the guard zeroing and the first publish below overwrite the tile
+    } else
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1349,7 +1392,28 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
     stamp();  // 10: all pairs done
 
     // ---- store the valid centre of the tile ---------------------------------------------------------------
-    if (!(a.dbg & 16)) {
+    if constexpr (TIO) {
+        __syncthreads();  // every wave is done with the operand tiles
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 q = {xacc[mi][jt][4 * g + 0], xacc[mi][jt][4 * g + 1], xacc[mi][jt][4 * g + 2], xacc[mi][jt][4 * g + 3]};
+                    *(f32x4*)(smem + (size_t)(slab + jt * 32 + (lane & 31)) * TS + (mi * 32 + 8 * g + half4) * 4) = q;
+                }
+        __syncthreads();
+        if (!(a.dbg & 16)) {
+            const int nrow = min(R - 2 * J.HL, a.L - (tg0 + J.HL));  // valid rows of this tile that lie inside the utterance
+            const int tot = nrow * C4;
+            for (int i = threadIdx.x; i < tot; i += NT) {
+                const int r = i / C4, c4 = i - r * C4;
+                const int row = J.HL + r;
+                *(float4*)(dst + (size_t)(tg0 + row) * C + c4 * 4) = *(const float4*)(smem + (size_t)row * TS + c4 * 16);
+            }
+        }
+    } else if (!(a.dbg & 16)) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
