@@ -43,11 +43,16 @@ def parse():
     p.add_argument("--steps", type=int, default=100)
     p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--repeats", type=int, default=10, help="extra repetitions of the K-step loop for the median / spread report")
-    p.add_argument("--batch", type=int, default=1, help="clips per rank per step (BASELINE config 2 = 1, config 3 = 64)")
+    p.add_argument("--batch", type=int, default=None, help="clips per rank per step (default 1 = BASELINE configs[1]; 64 = configs[2])")
+    p.add_argument("--config", type=int, default=None, choices=[1, 2, 3],
+                   help="BASELINE configs[N] preset: 1 = one clip, 10000x768 index; 2 = 64 clips, one GPU; 3 = 64 clips PER RANK against a "
+                        "1M x 256 index built on rank 0 and broadcast once over RCCL (configs[3] is 512 clips on 8 GPUs)")
     p.add_argument("--operand", default="fp16", choices=["fp16", "bf16", "fp32"])
     p.add_argument("--frames", type=int, default=T_CLIP)
-    p.add_argument("--index-n", type=int, default=10000)
-    p.add_argument("--index-d", type=int, default=768)
+    p.add_argument("--index-n", type=int, default=None)
+    p.add_argument("--index-d", type=int, default=None)
+    p.add_argument("--dist-selftest", action="store_true",
+                   help="CPU/gloo dry run of the multi-rank skeleton (self-launch, rendezvous, blob broadcast, rank agreement); no GPU work")
     p.add_argument("--index-rate", type=float, default=0.75)
     p.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     p.add_argument("--whole", action="store_true",
@@ -58,7 +63,74 @@ def parse():
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--stream", action="store_true",
                    help="BASELINE configs[4]: realtime chunks (v1/40k generator, T=31 frames -> n_res, 16 queries); prints p50 latency")
-    return p.parse_args()
+    a = p.parse_args()
+    preset = {None: (1, 10000, 768), 1: (1, 10000, 768), 2: (64, 10000, 768), 3: (64, 1000000, 256)}[a.config]
+    a.batch = preset[0] if a.batch is None else a.batch
+    a.index_n = preset[1] if a.index_n is None else a.index_n
+    a.index_d = preset[2] if a.index_d is None else a.index_d
+    return a
+
+
+def ensure_world(a):
+    """``--gpus N`` MEANS N ranks.  Under a launcher (WORLD_SIZE set) the two must agree; without one and N > 1 this process
+    replaces itself with ``python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>`` (one rank per GPU,
+    rendezvous on 127.0.0.1); with fewer than N GPUs visible it exits non-zero.  It never silently measures one GPU."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != a.gpus:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to report a mislabelled run" % (a.gpus, ws))
+        return
+    if a.gpus <= 1:
+        return
+    if not a.dist_selftest:
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < a.gpus:
+            raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible; not running a smaller job under that label" % (a.gpus, ndev))
+    from rvc_amd.dist import torchrun_argv
+
+    argv = torchrun_argv(os.path.abspath(__file__), sys.argv[1:], a.gpus)
+    print("[bench] self-launching %d ranks: %s" % (a.gpus, " ".join(argv)), file=sys.stderr)
+    sys.stderr.flush()
+    os.execv(argv[0], argv)
+
+
+def dist_selftest(a):
+    """The multi-rank skeleton of main() without GPU work, on gloo: rendezvous, one broadcast of a blob only rank 0 knows,
+    every rank checks it received rank 0's bytes, contiguous shards cover the clip list, max-over-ranks timing."""
+    import hashlib
+
+    import torch.distributed as dist
+    from rvc_amd.dist import broadcast_bytes, shard_range
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist.init_process_group(backend="gloo")
+    blob = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(4321)
+        blob = torch.randint(0, 256, (1 << 20,), dtype=torch.uint8, generator=g)
+    dist.barrier()
+    t0 = time.perf_counter()
+    got = broadcast_bytes(blob, src=0, device=torch.device("cpu"))
+    t_b = time.perf_counter() - t0
+    h = torch.tensor(list(hashlib.sha256(got.numpy().tobytes()).digest()), dtype=torch.int64)
+    h0 = h.clone()
+    dist.broadcast(h0, src=0)
+    ok = torch.tensor([int(bool((h == h0).all()))])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    clips = 64 * world + 3
+    lo, hi = shard_range(clips, rank, world)
+    cover = torch.zeros(clips, dtype=torch.int64)
+    cover[lo:hi] = 1
+    dist.all_reduce(cover)
+    tt = torch.tensor([t_b], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "index_blob_bytes": int(got.numel()),
+                          "index_broadcast_s": float(tt.item()), "ranks_agree": bool(ok.item()), "shards_cover": bool((cover == 1).all())}))
+    dist.barrier()
+    dist.destroy_process_group()
+    if not bool(ok.item()) or not bool((cover == 1).all()):
+        raise SystemExit(3)
 
 
 def _reference_generator(cfg, w):
@@ -320,6 +392,9 @@ def main():
         return torch_gpu_baseline_worker(a)
     if a.stream:
         return stream_mode(a)
+    ensure_world(a)
+    if a.dist_selftest:
+        return dist_selftest(a)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -344,10 +419,16 @@ def main():
 
     # ---- index: built on rank 0, ONE RCCL broadcast of the packed blob ----------
     idx = None
-    t_bcast = 0.0
+    t_bcast, blob_bytes, ranks_equal = 0.0, None, None
+    big_index = a.index_n > 200000  # configs[3]: 1M x 256 -- trained on the GPU (rvcmi_ivf_build), numpy k-means would take minutes
     if rank == 0:
-        idx = synth.make_ivf(a.index_n, a.index_d, seed=4321, kmeans_iters=1)
-        index = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=dev)
+        if big_index:
+            rows = synth.make_clustered_rows(a.index_n, a.index_d, synth.ivf_nlist(a.index_n), seed=4321)
+            index = rvc_amd.IVFFlatHIP.train(rows, nlist=synth.ivf_nlist(a.index_n), niter=2, seed=4321, device=dev)
+            del rows
+        else:
+            idx = synth.make_ivf(a.index_n, a.index_d, seed=4321, kmeans_iters=1)
+            index = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=dev)
     else:
         index = None
     if use_dist:
@@ -357,7 +438,18 @@ def main():
         index = rvc_amd.dist.broadcast_index(index, src=0, device=dev)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
+        tb = torch.tensor([t_bcast], device=dev, dtype=torch.float64)
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        t_bcast = float(tb.item())
+    blob_bytes = int(index.blob().numel())
     index.reserve(B * NQ_CLIP)
+    if use_dist:
+        # every rank searches the SAME seeded queries on ITS copy of the index; (distances, ids) must be bit-identical to rank 0's
+        qv = synth.make_phone(1, 64, a.index_d, seed=999)[0].to(dev).contiguous()
+        Dv, Iv = index.search(qv, 8)
+        ranks_equal = rvc_amd.dist.ranks_agree(Dv.contiguous()) and rvc_amd.dist.ranks_agree(Iv.contiguous())
+        if not ranks_equal:
+            raise SystemExit("bench.py: rank %d's first search differs from rank 0's after the index broadcast" % rank)
 
     gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=dev, operand=a.operand, max_B=B, max_T=T)
     zd, f0d, gd, nd = z.to(dev), f0.to(dev), g.to(dev), noise.to(dev)
@@ -598,7 +690,7 @@ def main():
             print("[bench] whole-infer leg failed: %s" % e, file=sys.stderr)
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and idx is not None:
         cpu = cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, a.index_rate)
     tgpu = None
     if rank == 0 and world == 1 and not a.no_gpu_torch_baseline and not a.no_cpu_baseline:
@@ -612,15 +704,18 @@ def main():
                       (" + enc_p + flow (whole net_g.infer)" if a.whole else ""),
             "value": value, "unit": "x real-time (audio-sec/wall-sec), whole job",
             "per_gpu": value / world,
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "n_gpus": dist.get_world_size() if use_dist else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.operand + " MFMA operands, fp32 accumulate/residual; fp64 IVF distances" if a.operand != "fp32" else "fp32",
             "data": "synthetic (seeded weights, features, f0, noise, index; no checkpoints offline)",
             "config": {"workload": "BASELINE configs[%d]: v2/48k, %d x 10 s clip(s) per GPU, T=%d frames, 599 queries/clip, "
                                    "IVF %dx%d nlist=%d nprobe=1 k=8 index_rate=%.2f" % (
-                                       1 if B == 1 else 2, B, T, a.index_n, a.index_d, index.nlist, a.index_rate),
+                                       (a.config if a.config else (1 if B == 1 else 2)), B, T, a.index_n, a.index_d, index.nlist, a.index_rate),
                        "clips_per_gpu_per_step": B, "hipgraph": graph is not None,
-                       "index_broadcast_s": t_bcast if use_dist else None},
+                       "index_broadcast_s": t_bcast if use_dist else None, "index_blob_bytes": blob_bytes,
+                       "index_broadcast_GBps": (blob_bytes / t_bcast / 1e9) if (use_dist and t_bcast > 0) else None,
+                       "ranks_first_search_equal": ranks_equal,
+                       "launcher": "torch.distributed.run, one rank per GPU, RCCL" if use_dist else "single process"},
         }
         if roof is not None:
             line["roofline"] = roof

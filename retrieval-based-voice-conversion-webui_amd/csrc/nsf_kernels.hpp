@@ -560,7 +560,17 @@ __device__ __forceinline__ void conv_run(f32x16 (&acc)[MI][NJ], typename Op<OpT>
     int gn = min(NB - 1, NG - 1);
 
     frag Bf[2][NJ];
+#ifndef RVCMI_KLOOP_V1
+    // first k-step's B fragments, in ASCENDING tile order like every later k-step (the waitcnt pass merges the loop entry
+    // with the back edge: a different order here makes it wait for lgkmcnt(0) at the head of every group)
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        Bf[0][jt] = *(const frag*)(gb + koff(0) + jt * 32 * STRIDE);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     readB(Bf[0], gb, 0);
+#endif
     for (int grp = 0; grp < NG; grp += NB) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -569,6 +579,29 @@ __device__ __forceinline__ void conv_run(f32x16 (&acc)[MI][NJ], typename Op<OpT>
                 const char* gbn;
                 if constexpr (CC >= KGROUP) gbn = (gi + 1 == GPT) ? gb - (GPT - 1) * KGROUP * 32 + dS : gb + KGROUP * 32;
                 else gbn = gb + TPG * dS;
+#ifndef RVCMI_KLOOP_V1
+                // Slot i of a k-step = MFMA i, then (i < NJ) the ds_read of the NEXT k-step's B fragment of time tile i, then
+                // (last MI slots) one weight load of group g+NB-1.  The order is pinned with sched_barrier: left to the
+                // scheduler, the reads that cross a group boundary came out in DESCENDING tile order, so the first MFMA of
+                // every group waited for the LAST read issued (s_waitcnt lgkmcnt(0): a full LDS round trip, ~120 cycles per
+                // 24 MFMAs = the 37 instead of 32 cycles per MFMA measured in round 2).
+#pragma unroll
+                for (int k = 0; k < KGROUP; ++k) {
+                    const char* nbp = (k + 1 < KGROUP) ? gb + koff(k + 1) : gbn + koff(0);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int jt = 0; jt < NJ; ++jt) {
+                            constexpr int NS = MI * NJ;
+                            const int i = mi * NJ + jt;
+                            acc[mi][jt] = Op<OpT>::mfma(A[u][k][mi], Bf[k & 1][jt], acc[mi][jt]);
+                            if (i < NJ) Bf[(k + 1) & 1][i] = *(const frag*)(nbp + i * 32 * STRIDE);
+                            if (i >= NS - MI)
+                                A[(u + NB - 1) % NB][k][i - (NS - MI)] = *(const frag*)(an + (size_t)(i - (NS - MI)) * ct_stride + k * 512);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+#else
 #pragma unroll
                 for (int k = 0; k < KGROUP; ++k) {
                     // next k-step's B fragments (first k-step of the next group at the group boundary; past the very
@@ -590,6 +623,7 @@ __device__ __forceinline__ void conv_run(f32x16 (&acc)[MI][NJ], typename Op<OpT>
                         else if (i < NJ + MI) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
                     }
                 }
+#endif
                 gb = gbn;
                 if constexpr (CC >= KGROUP) gi = (gi + 1 == GPT) ? 0 : gi + 1;
                 if (gn < NG - 1) {

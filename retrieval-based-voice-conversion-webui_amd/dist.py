@@ -10,6 +10,32 @@ import torch
 import torch.distributed as dist
 
 
+def torchrun_argv(script: str, script_args: List[str], nproc: int, master_port: Optional[int] = None) -> List[str]:
+    """The command that runs ``script`` as ``nproc`` ranks of ONE node, one per GPU (what a batch driver or ``bench.py --gpus N``
+    exec's when it was started without a launcher): ``python -m torch.distributed.run`` with the rendezvous pinned to 127.0.0.1
+    (container hostnames need not resolve) on a free port."""
+    import socket
+    import sys
+
+    if master_port is None:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            master_port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % int(nproc),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(master_port)), script] + list(script_args)
+
+
+def ranks_agree(t: torch.Tensor, src: int = 0, group=None) -> bool:
+    """True on every rank iff every rank's ``t`` is bit-identical to ``src``'s (one broadcast + one MIN all-reduce).
+    Used after the index broadcast: the same seeded queries must return the same (distances, ids) everywhere."""
+    ref = t.clone()
+    dist.broadcast(ref, src=src, group=group)
+    same = (ref.view(torch.uint8) == t.view(torch.uint8)).all() if t.numel() else torch.tensor(True, device=t.device)
+    ok = same.to(torch.int32).reshape(1).clone()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    return bool(ok.item())
+
+
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous split of ``n_items`` utterances: the first ``n_items % world`` ranks take one extra."""
     base, rem = divmod(n_items, world)

@@ -120,6 +120,72 @@ def test_multi_rank_broadcast_and_sharding_gloo():
     mp.spawn(_gloo_worker, args=(2, _free_port(), 67), nprocs=2, join=True)
 
 
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_launches_that_many_ranks_gloo():
+    """`bench.py --gpus 2` without a launcher must become 2 ranks (here: the gloo dry run of the same skeleton); the line's
+    n_gpus is the process group's world size, the blob is the one rank 0 made, the shards cover the clip list."""
+    import json
+
+    r = _run_bench(["--gpus", "2", "--dist-selftest"])
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_agree"] and d["shards_cover"] and d["index_blob_bytes"] == 1 << 20
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+
+
+def test_bench_refuses_a_mislabelled_multi_gpu_run():
+    """Fewer GPUs than --gpus, or a launcher whose WORLD_SIZE disagrees with --gpus: non-zero exit, no JSON line."""
+    r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])  # no GPU in the build container; 1 GPU on the test box
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("2+ GPUs visible: the real launch would run")
+    assert r.returncode != 0 and "--gpus 2 requested but only" in r.stderr and "{" not in r.stdout
+    r = _run_bench(["--gpus", "2", "--dist-selftest"], {"WORLD_SIZE": "4", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and "{" not in r.stdout
+
+
+def test_torchrun_argv_and_ranks_agree_helpers():
+    from rvc_amd.dist import torchrun_argv
+
+    av = torchrun_argv("/x/bench.py", ["--gpus", "8"], 8, master_port=29511)
+    assert av[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in av and av[-3:] == ["/x/bench.py", "--gpus", "8"]
+    assert av[av.index("--master-addr") + 1] == "127.0.0.1" and av[av.index("--master-port") + 1] == "29511"
+
+
+def _agree_worker(rank, world, port):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rvc_amd.dist import ranks_agree
+
+    same = torch.arange(40, dtype=torch.float32)
+    assert ranks_agree(same)
+    diff = same.clone()
+    if rank == 1:
+        diff[7] = float(np.nextafter(np.float32(7.0), np.float32(8.0)))  # one ulp on one rank must be seen by EVERY rank
+    assert not ranks_agree(diff)
+    assert ranks_agree(torch.arange(9, dtype=torch.int64))
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_detects_a_one_ulp_difference_gloo():
+    import torch.multiprocessing as mp
+
+    mp.spawn(_agree_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 def test_reference_module_introspection_when_reference_is_present():
     """config_from_reference / _plain_state_dict against the REAL reference classes (skipped on the GPU box)."""
     ref = os.environ.get("RVC_REFERENCE", "/root/reference")

@@ -9,16 +9,16 @@ using namespace rvcmi;
 #ifndef VARIANT
 #define VARIANT 0
 #endif
-template <int C, int MI, int NJ, int KG, int NB>
+template <int C, int MI, int NJ, int KG, int NB, bool SHARED = false>
 __global__ void __launch_bounds__(256, 1) kloop(const _Float16* w, long ct, int k_p, int dil, int reps, int dbg, float* out,
                                                 unsigned long long* ticks) {
     using TL = Tile<C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int rows = 4 * 32 * NJ + 64;
+    const int rows = (SHARED ? 1 : 4) * 32 * NJ + 64;  // SHARED: all waves read the same rows (k_rb_stream: waves split channels)
     for (int i = threadIdx.x; i < rows * TL::STRIDE / 4; i += 256) ((float*)smem)[i] = 0.001f * (i % 97);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const char* xl = smem + (size_t)(wave * 32 * NJ + (lane & 31)) * TL::STRIDE + (lane >> 5) * 16;
+    const char* xl = smem + (size_t)((SHARED ? 0 : wave) * 32 * NJ + (lane & 31)) * TL::STRIDE + (lane >> 5) * 16;
     f32x16 acc[MI][NJ];
     for (int mi = 0; mi < MI; ++mi) for (int jt = 0; jt < NJ; ++jt) for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
     typename Op<_Float16>::frag A[NB][KG][MI];
@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256, 1) kloop(const _Float16* w, long ct, int 
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (lane == 0) ticks[blockIdx.x * 4 + wave] = t1 - t0;
 }
-template <int C, int MI, int NJ, int KG, int NB>
+template <int C, int MI, int NJ, int KG, int NB, bool SHARED = false>
 void run(int k, int dil, int dbg) {
     using TL = Tile<C>;
     const int CC = C / 16;
@@ -47,11 +47,11 @@ void run(int k, int dil, int dbg) {
     const int blocks = 256, reps = 200;
     hipMalloc(&w, hw.size() * 2); hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     hipMalloc(&out, blocks * 256 * 4); hipMalloc(&ticks, blocks * 4 * 8);
-    const size_t smem = (size_t)(4 * 32 * NJ + 64) * TL::STRIDE;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&kloop<C, MI, NJ, KG, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB>), dim3(blocks), dim3(256), smem, 0, w, ct, k_p, dil, 2, dbg, out, ticks);
+    const size_t smem = (size_t)((SHARED ? 1 : 4) * 32 * NJ + 64) * TL::STRIDE;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&kloop<C, MI, NJ, KG, NB, SHARED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB, SHARED>), dim3(blocks), dim3(256), smem, 0, w, ct, k_p, dil, 2, dbg, out, ticks);
     hipDeviceSynchronize();
-    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB>), dim3(blocks), dim3(256), smem, 0, w, ct, k_p, dil, reps, dbg, out, ticks);
+    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB, SHARED>), dim3(blocks), dim3(256), smem, 0, w, ct, k_p, dil, reps, dbg, out, ticks);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(blocks * 4);
     hipMemcpy(h.data(), ticks, h.size() * 8, hipMemcpyDeviceToHost);
@@ -62,8 +62,16 @@ void run(int k, int dil, int dbg) {
     hipFree(w); hipFree(out); hipFree(ticks);
 }
 int main() {
-    for (int dbg : {0, 64, 128, 192}) run<64, 2, 3, 4, 3>(7, 3, dbg);
-    for (int dbg : {0, 192}) run<32, 1, 6, 4, 3>(7, 3, dbg);
-    for (int dbg : {0, 192}) run<128, 2, 4, 4, 2>(7, 3, dbg);
+#ifdef RVCMI_KLOOP_V1
+    printf("K loop V1 (round 2: scheduler-ordered reads)\n");
+#else
+    printf("K loop V2 (pinned slot order)\n");
+#endif
+    for (int k : {11, 7, 3}) run<128, 1, 6, 4, 2, true>(k, k == 3 ? 1 : 5, 0);   // k_rb_stream<128>
+    run<256, 2, 3, 4, 2, true>(7, 3, 0);                                        // k_rb_stream<256> (B >= 16)
+    run<256, 2, 4, 4, 2>(7, 3, 0);                                              // k_rb_pair<256>
+    for (int k : {11, 3}) run<64, 2, 2, 4, 2>(k, 3, 0);                         // k_rb_full<64>
+    for (int k : {11, 3}) run<32, 1, 3, 4, 3>(k, 3, 0);                         // k_rb_full<32>
+    run<128, 2, 4, 4, 2>(7, 3, 0);
     return 0;
 }
