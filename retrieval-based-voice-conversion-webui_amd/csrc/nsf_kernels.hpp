@@ -595,7 +595,13 @@ __device__ __forceinline__ void conv_run(f32x16 (&acc)[MI][NJ], typename Op<OpT>
                             constexpr int NS = MI * NJ;
                             const int i = mi * NJ + jt;
                             acc[mi][jt] = Op<OpT>::mfma(A[u][k][mi], Bf[k & 1][jt], acc[mi][jt]);
+#ifdef RVCMI_KLOOP_ABLATE  // tools/ubench/kloop.hip only: 1 = no weight loads, 2 = no B reads inside the loop
+                            if (!(RVCMI_KLOOP_ABLATE & 2))
+#endif
                             if (i < NJ) Bf[(k + 1) & 1][i] = *(const frag*)(nbp + i * 32 * STRIDE);
+#ifdef RVCMI_KLOOP_ABLATE
+                            if (!(RVCMI_KLOOP_ABLATE & 1))
+#endif
                             if (i >= NS - MI)
                                 A[(u + NB - 1) % NB][k][i - (NS - MI)] = *(const frag*)(an + (size_t)(i - (NS - MI)) * ct_stride + k * 512);
                             __builtin_amdgcn_sched_barrier(0);

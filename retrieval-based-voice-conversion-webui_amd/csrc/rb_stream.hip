@@ -12,6 +12,7 @@
 #include "common.hpp"
 #include "rb_stream.hpp"
 #include "rb_stream_kernels.hpp"
+#include "rb_stream2_kernels.hpp"
 
 namespace rvcmi {
 int num_cus();
@@ -19,8 +20,20 @@ int num_cus();
 namespace {
 
 struct Geo {
-    int MI, NJ, NCO, bpc;  // bpc = blocks per CU (one wave per SIMD: NCO * bpc = 4)
+    int MI, NJ, NCO, bpc;  // bpc = blocks per CU (k_rb_stream: one wave per SIMD, NCO * bpc = 4)
+    int ver;               // 1 = k_rb_stream, 2 = k_rb_stream2 (two blocks per CU, swizzled 256-byte rows)
+    double c0;             // planning: a block's time is steps x (k + c0) units
 };
+// k_rb_stream2 (two blocks per CU) is parity-green but measured SLOWER than k_rb_stream at B = 1 (0.75 vs 0.62 ms):
+// opt-in for A/B runs (RVCMI_RS_V2=1, read once)
+bool use_v2() {
+    static const bool v = []() { const char* e = getenv("RVCMI_RS_V2"); return e && e[0] == '1'; }();
+    return v;
+}
+double plan_c0(double dflt) {
+    static const double v = []() { const char* e = getenv("RVCMI_RS_C0"); return e ? atof(e) : -1.0; }();
+    return v >= 0 ? v : dflt;
+}
 // Time tiles per wave: 6 (R = 192 rows per step) for the one-tile-of-channels waves, 3 (R = 96) for C = 256: everything
 // stays in registers.  The larger alternatives 8 / 4 spill 100-400 registers per step (outside the K loops) and measured
 // slower (C = 128: 0.88 vs 0.76 ms per clip); RVCMI_RS_SMALL=0 selects them for A/B runs.
@@ -30,8 +43,9 @@ bool small_tiles() {
 }
 bool geo_for(int C, int nd, Geo& g) {
     const bool sm = small_tiles();
-    if (C == 256 && nd == 1) { g = {2, sm ? 3 : 4, 4, 1}; return true; }
-    if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1}; return true; }
+    if (C == 256 && nd == 1) { g = {2, sm ? 3 : 4, 4, 1, 1, 4.4}; return true; }
+    if (C == 128 && nd == 3 && use_v2()) { g = {1, 3, 4, 2, 2, plan_c0(1.0)}; return true; }
+    if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1, 1, 4.4}; return true; }
     // (C = 128 pair by pair with TWO blocks per CU -- NJ = 4, 225 registers, 0 spills -- was measured: both waves of a SIMD sit in
     //  their K loops at the same time (72 cycles per MFMA per wave), the phases overlap no better than in the one-wave design
     //  (MFMA pipe 66 % busy in both) and three launches move 3x the bytes: 0.82 vs 0.71 ms on the same box.  Not kept.)
@@ -58,6 +72,21 @@ void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStre
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(64 * NCO), smem, st, a);
 }
 
+template <typename OpT, int NJ, int ND>
+void launch_inst2(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    auto kern = &k_rb_stream2<OpT, NJ, ND>;
+    if (!(attr_done.load() & bit)) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_done.fetch_or(bit);
+    }
+    if (nblocks < 0) return;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(256), smem, st, a);
+}
+
 // weight ring of the C = 128 kernel: NB groups of KG k-steps; a group is requested (NB-1)*KG k-steps ahead of its use.
 // (4 groups of 2 k-steps -- the same 32 registers, 6 instead of 4 k-steps of L2 latency covered -- was measured: 47 instead
 // of 37 cycles per MFMA, the group bookkeeping comes twice as often; 0.69 vs 0.62 ms.  RVCMI_DEFINES="RS_KG128=2 RS_NB128=4".)
@@ -68,7 +97,8 @@ void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStre
 #define RS_NB128 2
 #endif
 template <typename OpT>
-void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
+void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st, int ver = 1) {
+    if (ver == 2 && C == 128 && nd == 3 && NJ == 3) return launch_inst2<OpT, 3, 3>(a, nblocks, B, smem, st);
     if (C == 256 && nd == 1 && NJ == 4) return launch_inst<OpT, 256, 2, 4, 4, 1>(a, nblocks, B, smem, st);
     if (C == 256 && nd == 1 && NJ == 3) return launch_inst<OpT, 256, 2, 3, 4, 1>(a, nblocks, B, smem, st);
     if (C == 128 && nd == 3 && NJ == 8) return launch_inst<OpT, 128, 1, 8, 4, 3>(a, nblocks, B, smem, st);
@@ -104,6 +134,8 @@ void rb_stream_prepare() {
         launch_t<__bf16>(128, 3, nj, a, -1, 1, 0, nullptr);
         launch_t<_Float16>(128, 3, nj, a, -1, 1, 0, nullptr);
     }
+    launch_t<__bf16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
+    launch_t<_Float16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
 }
 
 bool rb_stream_supported(int operand, int C, int nd) {
@@ -145,7 +177,8 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
             J.b2[m] = d.b2[m];
             J.dil[m] = d.dil[m];
             const int p1 = d.dil[m] * (d.k - 1) / 2;
-            if (p1 + p2 > 32 || 2 * p2 > RS_HROW || 32 + p1 - p2 > RS_HEAD - RS_HROW || p1 + p2 + d.dil[m] - 32 > RS_SLACK)
+            if (p1 + p2 > 32 || 2 * p2 > RS_HROW || p1 + p2 + d.dil[m] - 32 > (g.ver == 2 ? RS2_SLACK : RS_SLACK) ||
+                32 + p1 - p2 > (g.ver == 2 ? RS2_HEAD : RS_HEAD - RS_HROW))
                 return false;  // halo larger than the 32-row lag / the head room of the tile: not this kernel
             warm[j] += p1;
             J.sx_off[m] = sx;
@@ -177,7 +210,7 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
             auto tcost = [&](int j, int n) {
                 const int rows = (L + n - 1) / n;
                 const int steps = (rows + warm[j] + R - 1) / R;
-                return steps * (jobs[j].k + 4.4);
+                return steps * (jobs[j].k + g.c0);
             };
             // With a large batch an utterance gets only a handful of blocks, too few to split in proportion to the three
             // costs (B = 64: 4 blocks as 2+1+1 = 75 % balance).  Strips are cheap (156 warm-up rows each), so also try
@@ -227,11 +260,19 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
         min_steps = std::min(min_steps, steps);
     }
     a.side_rows = side_rows;
+    if (g.ver == 2) {  // dev knobs (read once): RVCMI_RS_SKEW = units of 1024 cycles per (k + 3), RVCMI_RS_PRIO = 1
+        static const int skew = []() { const char* e = getenv("RVCMI_RS_SKEW"); return e ? atoi(e) : 2; }();
+        static const int prio = []() { const char* e = getenv("RVCMI_RS_PRIO"); return e ? atoi(e) : 0; }();
+        a.skew = skew;
+        a.flags = prio & 1;
+    }
     // auto mode: only where the persistent walk measured faster than the tile kernels -- C = 128 (whole resblocks) from 4 steps
     // per block; C = 256 (pair level) only with long strips (large batches).
     if (!force && min_steps < (C == 128 ? 4 : 8)) return false;
-    const size_t smem = (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
-    if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large (C=%d)", smem, C);
+    const size_t smem = g.ver == 2 ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
+                                   : (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
+    if (smem > (size_t)160 * 1024 / g.bpc)
+        RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large for %d block(s) per CU (C=%d)", smem, g.bpc, C);
     if (dry_run) return true;
     // dev only: RVCMI_RS_STAMPS=1 prints the per-phase cycle breakdown of every launch (synchronises; never set it in a timed run)
     static const bool want_stamps = getenv("RVCMI_RS_STAMPS") && getenv("RVCMI_RS_STAMPS")[0] == '1';
@@ -242,8 +283,8 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
         HIP_CHECK(hipMemsetAsync(ts, 0, nts * 8, st));
         a.ts = ts;
     }
-    if (operand == RVCMI_OPERAND_BF16) launch_t<__bf16>(C, nd, g.NJ, a, nblocks, B, smem, st);
-    else launch_t<_Float16>(C, nd, g.NJ, a, nblocks, B, smem, st);
+    if (operand == RVCMI_OPERAND_BF16) launch_t<__bf16>(C, nd, g.NJ, a, nblocks, B, smem, st, g.ver);
+    else launch_t<_Float16>(C, nd, g.NJ, a, nblocks, B, smem, st, g.ver);
     if (want_stamps) {
         HIP_CHECK(hipStreamSynchronize(st));
         std::vector<unsigned long long> h(nts);

@@ -50,6 +50,8 @@ struct RbStreamArgs {
     int L;
     long bstride;
     int side_rows;  // rows of the side area (max over jobs)
+    int skew;       // k_rb_stream2: the second block of a CU starts `skew * (k + 3)` x 1024 cycles late (0 = together)
+    int flags;      // k_rb_stream2: bit 0 = raise the wave priority inside the K loops
     unsigned long long* ts;  // dev only (RVCMI_RS_STAMPS=1): per-wave cycle sums per phase, [block][wave][16]
 };
 

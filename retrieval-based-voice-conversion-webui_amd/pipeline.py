@@ -29,3 +29,192 @@ def retrieve_blend(feats: torch.Tensor, index: IVFFlatHIP, index_rate: float, k:
         flat = flat.clone()  # the reference builds a new tensor; keep the caller's feats0 copy valid
     index.search_blend(flat, float(index_rate), k, skip_if_short=realtime_guard)
     return flat.reshape(shape).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Device-resident ``Pipeline.vc`` / ``Pipeline.pipeline`` (infer/modules/vc/pipeline.py:76-184, 186-360)
+# ------------------------------------------------------------------------------------------------------------------------
+# ``install()`` binds ``vc_hip`` / ``pipeline_hip`` as the ``vc`` / ``pipeline`` methods of the reference's own ``Pipeline``
+# class (whose ``__init__`` state -- x_pad, window, t_pad*, is_half, device, f0_gen -- they read), so an unmodified
+# ``VC.vc_single`` runs them.  HuBERT stays the caller's ``model`` on PyTorch-ROCm; from its output on nothing visits the host:
+# search + blend + x2 + protect mix in one launch (rvcmi_ivf_search_blend_expand), ``net_g.infer`` on the HIP front + generator,
+# segments concatenated, ``change_rms`` and the int16-range scaling on the device, ONE copy to the host at the very end
+# (the API returns a numpy array).  Host work that remains is the reference's own input preparation on the 16 kHz waveform
+# (high-pass ``filtfilt``, the quiet-point search that chooses the cut positions) and estimators other than RMVPE.
+
+def _ref_module(self):
+    import sys
+
+    return sys.modules[type(self).__module__]
+
+
+def _is_hip_index(index) -> bool:
+    return isinstance(index, IVFFlatHIP)
+
+
+def vc_device(self, model, net_g, sid, audio0, pitch, pitchf, times, index, index_rate, version, protect) -> torch.Tensor:
+    """``Pipeline.vc`` up to (not including) its final ``.data.cpu().float().numpy()``: returns the converted segment as a
+    1-D device tensor.  ``audio0``: numpy or tensor (16 kHz segment, padded); ``index``: an ``IVFFlatHIP`` or None."""
+    from time import time
+
+    from . import glue
+
+    dev = torch.device(self.device)
+    feats = torch.as_tensor(audio0)
+    feats = feats.half() if self.is_half else feats.float()
+    if feats.dim() == 2:  # double channels (pipeline.py:98-99)
+        feats = feats.mean(-1)
+    assert feats.dim() == 1, feats.dim()
+    feats = feats.view(1, -1)
+    padding_mask = torch.zeros(feats.shape, dtype=torch.bool, device=dev)
+    t0 = time()
+    with torch.no_grad():
+        logits = model.extract_features(source=feats.to(dev), padding_mask=padding_mask, output_layer=9 if version == "v1" else 12)
+        feats = model.final_proj(logits[0]) if version == "v1" else logits[0]
+    use_f0 = pitch is not None and pitchf is not None
+    nq = int(feats.shape[1])
+    p_len = min(int(audio0.shape[0]) // self.window, 2 * nq)  # pipeline.py:146-151
+    if use_f0:
+        pitch, pitchf = pitch[:, :p_len], pitchf[:, :p_len]
+    use_index = index is not None and index_rate != 0
+    feats = glue.retrieve_blend_expand(feats, index if use_index else None, float(index_rate), pitchf if use_f0 else None,
+                                       float(protect) if use_f0 else 0.5, p_len)
+    t1 = time()
+    plen_t = torch.tensor([p_len], device=dev).long()
+    with torch.no_grad():
+        audio1 = net_g.infer(feats, plen_t, sid, pitch=pitch, pitchf=pitchf)[0, 0] if use_f0 else net_g.infer(feats, plen_t, sid)[0, 0]
+    t2 = time()
+    times[0] += t1 - t0
+    times[2] += t2 - t1
+    return audio1.data
+
+
+def vc_hip(self, model, net_g, sid, audio0, pitch, pitchf, times, index, big_npy, index_rate, version, protect):
+    """Drop-in ``Pipeline.vc`` (same arguments, same numpy return).  An index object that is not ours (a real faiss index
+    the HIP reader could not serve) is handed to the reference's own ``vc``."""
+    if index is not None and not _is_hip_index(index):
+        orig = getattr(vc_hip, "_rvcmi_original", None)
+        if orig is None:
+            raise TypeError("Pipeline.vc: index is a %s, not an IVFFlatHIP, and no reference vc is bound" % type(index).__name__)
+        return orig(self, model, net_g, sid, audio0, pitch, pitchf, times, index, big_npy, index_rate, version, protect)
+    use_index = index is not None and big_npy is not None and index_rate != 0  # the reference's guard, pipeline.py:113-117
+    out = vc_device(self, model, net_g, sid, audio0, pitch, pitchf, times, index if use_index else None, index_rate, version, protect)
+    return out.cpu().float().numpy()
+
+
+def _cut_points(self, audio, audio_pad_w):
+    """pipeline.py:219-232: where a long input is cut -- the quietest sample (|x| summed over one window) within
+    +-t_query of every multiple of t_center.  numpy float64 like the reference (same sums, same first-minimum rule)."""
+    import numpy as np
+
+    opt_ts = []
+    if audio_pad_w.shape[0] > self.t_max:
+        audio_sum = np.zeros_like(audio)
+        for i in range(self.window):
+            audio_sum += np.abs(audio_pad_w[i: i - self.window])
+        for t in range(self.t_center, audio.shape[0], self.t_center):
+            seg = audio_sum[t - self.t_query: t + self.t_query]
+            opt_ts.append(t - self.t_query + int(np.where(seg == seg.min())[0][0]))
+    return opt_ts
+
+
+def _rmvpe_on_device(self, audio_pad, p_len, f0_up_key, filter_radius):
+    """RMVPE salience on PyTorch-ROCm (the reference's own mel extractor + network), decoded by ``rvcmi_glue_rmvpe_f0``
+    (rvc/f0/rmvpe.py:119-164, f0.py:31-78, gen.py:10-41) without visiting the host.  None when this f0_gen has no torch RMVPE."""
+    from . import glue
+
+    gen = self.f0_gen
+    if not hasattr(gen, "rmvpe"):
+        try:
+            from rvc.f0.rmvpe import RMVPE
+
+            gen.rmvpe = RMVPE("%s/rmvpe.pt" % gen.rmvpe_root, is_half=gen.is_half, device=gen.device)
+        except Exception:  # noqa  (no checkpoint / onnx-only build: the reference path decides what to do)
+            return None
+    r = gen.rmvpe
+    if not (hasattr(r, "mel_extractor") and hasattr(r, "_mel2hidden")) or "privateuseone" in str(getattr(r, "device", "")):
+        return None
+    wav = torch.as_tensor(audio_pad)
+    with torch.no_grad():
+        mel = r.mel_extractor(wav.float().to(r.device).unsqueeze(0), center=True)
+        hidden = r._mel2hidden(mel)
+    return glue.rmvpe_f0(hidden.squeeze(0).float(), p_len, int(f0_up_key), 0.03 if filter_radius is None else float(filter_radius))
+
+
+def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr,
+                 resample_sr, rms_mix_rate, version, protect, f0_file=None):
+    """Drop-in ``Pipeline.pipeline``: same arguments, same numpy return (float array scaled to the int16 range)."""
+    import os
+    import traceback
+    from time import time
+
+    import numpy as np
+
+    from . import glue, ivf
+
+    ref = _ref_module(self)
+    dev = torch.device(self.device)
+    index = None
+    if file_index != "" and os.path.exists(file_index) and index_rate != 0:
+        try:
+            index = ref.faiss.read_index(file_index)  # install() made this the HIP reader; big_npy is never materialised
+            if not _is_hip_index(index):
+                index = ivf.read_index(file_index, device=dev)
+        except Exception:  # noqa: the reference prints and converts without an index (pipeline.py:216-218)
+            traceback.print_exc()
+            index = None
+    audio = ref.signal.filtfilt(ref.bh, ref.ah, audio)
+    opt_ts = _cut_points(self, audio, np.pad(audio, (self.window // 2, self.window // 2), mode="reflect"))
+    t1 = time()
+    audio_pad = np.pad(audio, (self.t_pad, self.t_pad), mode="reflect")
+    p_len = audio_pad.shape[0] // self.window
+    inp_f0 = None
+    if hasattr(f0_file, "name"):
+        try:
+            with open(f0_file.name, "r") as f:
+                lines = f.read().strip("\n").split("\n")
+            if lines and lines[0]:
+                inp_f0 = np.array([[float(v) for v in ln.split(",")] for ln in lines], dtype="float32")
+        except Exception:  # noqa
+            traceback.print_exc()
+    sid = torch.tensor(sid, device=dev).unsqueeze(0).long()
+    pitch = pitchf = None
+    if if_f0:
+        got = None
+        if if_f0 == 1 and f0_method == "rmvpe" and inp_f0 is None:
+            got = _rmvpe_on_device(self, audio_pad, p_len, f0_up_key, filter_radius)
+        if got is not None:
+            pitch, pitchf = got[0][:, :p_len].long(), got[1][:, :p_len].float()
+        else:
+            if if_f0 == 1:
+                pitch, pitchf = self.f0_gen.calculate(audio_pad, p_len, f0_up_key, f0_method, filter_radius, inp_f0)
+            else:
+                pitch, pitchf = f0_method  # pipeline.py:268-269: a precomputed (coarse, Hz) pair
+            pitch = torch.as_tensor(np.asarray(pitch)[:p_len], device=dev).unsqueeze(0).long()
+            pitchf = torch.as_tensor(np.asarray(pitchf)[:p_len].astype(np.float32), device=dev).unsqueeze(0).float()
+    times[1] += time() - t1
+    w = self.window
+    segs, s, t = [], 0, None
+
+    def convert(a0, lo, hi):
+        pt = pitch[:, lo:hi] if if_f0 else None
+        pf = pitchf[:, lo:hi] if if_f0 else None
+        o = vc_device(self, model, net_g, sid, a0, pt, pf, times, index, index_rate, version, protect)
+        segs.append(o[self.t_pad_tgt: o.shape[0] - self.t_pad_tgt].float())
+
+    for t in opt_ts:
+        t = t // w * w
+        convert(audio_pad[s: t + self.t_pad2 + w], s // w, (t + self.t_pad2) // w)
+        s = t
+    convert(audio_pad[t:], (t // w) if t is not None else 0, None)
+    audio_opt = torch.cat(segs).contiguous()
+    if rms_mix_rate != 1:
+        a16 = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32), device=dev)
+        audio_opt = glue.change_rms(a16, 16000, audio_opt, int(tgt_sr), float(rms_mix_rate))
+    if tgt_sr != resample_sr >= 16000:
+        # librosa's soxr resampler has no device twin (and no offline oracle): this one option goes through the host like the
+        # reference (pipeline.py:351-354) and comes back for the scaling
+        host = ref.librosa.resample(audio_opt.cpu().numpy(), orig_sr=tgt_sr, target_sr=resample_sr)
+        audio_opt = torch.as_tensor(host, device=dev).float().contiguous()
+    glue.scale_int16_range(audio_opt)
+    return audio_opt.cpu().numpy()

@@ -259,3 +259,65 @@ def test_real_hubert_rows_tie_semantics_and_the_faiss_validator(tmp_path, capsys
         assert "quantizer fourcc is b'IxXX'" in capsys.readouterr().out
     finally:
         sys.argv = old
+
+
+# ---- what faiss' own fp32 arithmetic would return (oracle/ivf_faisslike.py): the unpinned retrieval risk, quantified -------
+
+def test_faisslike_fp32_kernels_agree_with_exact_distances_to_fp32_rounding():
+    from oracle import ivf_faisslike as fl
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(768, dtype=np.float32)
+    y = rng.standard_normal((200, 768), dtype=np.float32)
+    exact = ((y.astype(np.float64) - x.astype(np.float64)) ** 2).sum(1)
+    for name, v in fl.VARIANTS.items():
+        got = fl.l2sqr_fp32(x, y, **v).astype(np.float64)
+        bound = (2e-5 if v["lanes"] == 1 else 2e-6)  # one accumulator: ~d ulps; 8+ lanes: an order of magnitude better
+        assert np.max(np.abs(got - exact) / exact) < bound, name
+    # lane structure is really what it says: 8 lanes == sum over the 8 interleaved partial sums in the epilogue's order
+    a = (y[:1] - x).astype(np.float32)
+    lanes = np.zeros(8, np.float32)
+    for s_ in range(96):
+        lanes = (lanes + (a[0, 8 * s_:8 * s_ + 8] * a[0, 8 * s_:8 * s_ + 8]).astype(np.float32)).astype(np.float32)
+    lo = (lanes[:4] + lanes[4:]).astype(np.float32)
+    want = np.float32(np.float32(lo[0] + lo[1]) + np.float32(lo[2] + lo[3]))
+    assert fl.l2sqr_fp32(x, y[:1], lanes=8, fma=False)[0] == want
+
+
+def test_faisslike_search_vs_exact_on_the_bench_index_and_on_real_hubert_rows():
+    """On bench.py's index (10000 x 768, 599 queries) every fp32 variant returns the SAME top-1 and the same top-8 set as the
+    exact answer the HIP path reproduces.  On the real mute.npy rows (near-duplicate features, exact duplicate rows) the
+    fp32 BLAS expansion of faiss' coarse quantizer picks another list for some queries: there faiss' own answer depends on
+    its build, and 'bit-exact to faiss' is not a well-defined target -- the flips are all coarse flips, none inside a list."""
+    from oracle import ivf_faisslike as fl
+
+    idx = synth.make_ivf(10000, 768, seed=4321, kmeans_iters=1)
+    q = synth.make_phone(1, 599, 768)[0].numpy()
+    exact = ivf_oracle.search(idx, q, 8)
+    lists = ivf_oracle.coarse_assign(idx, q, 1)[:, 0]
+    for v in ("avx8", "avx32_fma"):
+        c = fl.compare(exact, lists, fl.search_faisslike(idx, q, 8, v))
+        assert c["top1_flips"] == 0 and c["top8_set_flips"] == 0 and c["coarse_list_flips"] == 0, (v, c)
+        assert c["max_rel_dD_same_list"] < 1e-6
+    feats = load_golden("mute_hubert")["f256"]
+    x = synth.make_mute_rows(feats)
+    idm = synth.make_ivf_from_rows(x)
+    qq = np.concatenate([feats, (feats[:60] + np.float32(1e-3)).astype(np.float32)])
+    exact = ivf_oracle.search(idm, qq, 8)
+    lists = ivf_oracle.coarse_assign(idm, qq, 1)[:, 0]
+    c = fl.compare(exact, lists, fl.search_faisslike(idm, qq, 8, "avx8"))
+    assert c["top1_flips_same_list"] == 0 and c["top8_set_flips_same_list"] == 0  # inside the probed list fp32 changes nothing
+    assert c["top1_flips"] == c["coarse_list_flips"]                              # every flip is a coarse-quantizer flip
+    # with the direct-difference coarse path (nq < 20) the expansion's cancellation error is gone and so are most flips
+    c16 = fl.compare((exact[0][:16], exact[1][:16]), lists[:16], fl.search_faisslike(idm, qq[:16], 8, "avx8"))
+    assert c16["coarse_list_flips"] <= 1
+
+
+def test_committed_faisslike_report_has_every_case():
+    import json
+
+    rep = json.load(open(os.path.join(ROOT, "profiles", "r03_faisslike_flips.json")))
+    names = set(rep["cases"])
+    assert {"baseline_10000x768_iid_599q", "stress_1000000x256_clustered_599q", "mute_hubert_768_real_rows_with_exact_duplicates"} <= names
+    base = rep["cases"]["baseline_10000x768_iid_599q"]["variants"]
+    assert all(v["top1_flips"] == 0 for v in base.values())

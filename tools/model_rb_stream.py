@@ -67,6 +67,90 @@ def run_strip(x, W1, B1, W2, B2, k, dils, S0, S1, R, out):
         out[rows[ok]] = xin[ok]
 
 
+HEAD2 = 52     # k_rb_stream2: X and H share the rows of M; new rows at HEAD2, histories in front
+SLACK2 = 3
+
+
+def run_strip2(x, W1, B1, W2, B2, k, dils, S0, S1, R, out, swizzle=True):
+    """k_rb_stream2 (csrc/rb_stream2_kernels.hpp): same strip walk, but H is published over X in place, no tail is copied
+    (a publish writes its last rows twice: tile + history buffer; the history is restored in front of the new rows by the
+    same wave, reads before its own dual writes), rows are 256 B with the 16-byte chunk c of the row of time t stored at
+    chunk c ^ (t & 15).  `swizzle` models that storage permutation on a 16-chunk row (C = 16 * 8 channels in the kernel;
+    here a chunk = C // 16 channels) through the same address expressions as the kernel."""
+    L, C = x.shape
+    assert C % 16 == 0
+    cw = C // 16
+    nd = len(dils)
+    p2 = (k - 1) // 2
+    p1 = [d * (k - 1) // 2 for d in dils]
+    Hx = [32 + p - p2 for p in p1]
+    assert max(Hx) <= HEAD2 and R % 16 == 0
+    HL = sum(p1) + nd * p2
+    r0 = S0 - HL
+    nsteps = -(-(S1 - r0 + 32 * nd) // R)
+    MROWS = HEAD2 + R + SLACK2
+    M = np.zeros((MROWS, C), np.float32)          # STORAGE order (swizzled chunks)
+    sideX = [np.zeros((Hx[m], C), np.float32) for m in range(nd)]
+    sideH = [np.zeros((2 * p2, C), np.float32) for m in range(nd)]
+    carry = [np.zeros((32, C), np.float32) for m in range(nd)]
+
+    def store_rows(buf, row0, vals, t0):
+        """publish: logical rows `vals` whose first row has time t0 -> storage rows row0.. of buf"""
+        for i in range(vals.shape[0]):
+            key = (t0 + i) & 15 if swizzle else 0
+            for c in range(16):
+                pos = c ^ key
+                buf[row0 + i, pos * cw:(pos + 1) * cw] = vals[i, c * cw:(c + 1) * cw]
+
+    def load_rows(buf, row0, n, t0):
+        """what the K loop reads: storage rows -> logical rows (reader knows the time of each row)"""
+        o = np.empty((n, C), np.float32)
+        for i in range(n):
+            key = (t0 + i) & 15 if swizzle else 0
+            for c in range(16):
+                pos = c ^ key
+                o[i, c * cw:(c + 1) * cw] = buf[row0 + i, pos * cw:(pos + 1) * cw]
+        return o
+
+    for i in range(nsteps):
+        rows = r0 + i * R + np.arange(R)
+        xin = np.where(((rows >= 0) & (rows < L))[:, None], x[np.clip(rows, 0, L - 1)], 0).astype(np.float32)
+        for m in range(nd):
+            wm = r0 - 32 * m + i * R
+            assert (wm - r0) % 16 == 0
+            # phase A: restore reads (raw rows, no re-swizzle), publish, restore writes, dual write of the tail
+            hist = sideX[m].copy()
+            rows = wm + np.arange(R)
+            xp = np.where(((rows >= 0) & (rows < L))[:, None], lrelu(xin), 0).astype(np.float32)
+            store_rows(M, HEAD2, xp, r0)                       # kernel key: (r0 + lrow) & 15  (wm == r0 mod 16)
+            M[HEAD2 - Hx[m]:HEAD2] = hist
+            store_rows(sideX[m], 0, xp[R - Hx[m]:], r0 + R - Hx[m])
+            res = np.concatenate([carry[m], xin[:R - 32]])
+            carry[m] = xin[R - 32:].copy()
+            # conv1: the lane whose output row is q reads storage row HEAD2 - Hx + q + j*dil, time key (r0 - Hx + q + j*dil)
+            Xl = load_rows(M, HEAD2 - Hx[m], Hx[m] + R, r0 - Hx[m])
+            h = np.tile(B1[m][None, :], (R, 1)).astype(np.float32)
+            for j in range(k):
+                h += Xl[j * dils[m]: j * dils[m] + R] @ W1[m][:, :, j].T
+            # phase B: H published over X in place
+            hist = sideH[m].copy()
+            am = wm - 32 + p2
+            rows = am + np.arange(R)
+            hp = np.where(((rows >= 0) & (rows < L))[:, None], lrelu(h), 0).astype(np.float32)
+            store_rows(M, HEAD2, hp, r0 + p2)                  # kernel key: (r0 + p2 + lrow) & 15
+            M[HEAD2 - 2 * p2:HEAD2] = hist
+            store_rows(sideH[m], 0, hp[R - 2 * p2:], r0 + p2 + R - 2 * p2)
+            Hl = load_rows(M, HEAD2 - 2 * p2, 2 * p2 + R, r0 - p2)  # kernel key at tap 0: (r0 - p2 + lrow) & 15
+            acc = (res + B2[m][None, :]).astype(np.float32)
+            for j in range(k):
+                acc += Hl[j: j + R] @ W2[m][:, :, j].T
+            xin = acc
+        wout = r0 - 32 * nd + i * R
+        rows = wout + np.arange(R)
+        ok = (rows >= S0) & (rows < S1)
+        out[rows[ok]] = xin[ok]
+
+
 def reference(x, W1, B1, W2, B2, k, dils):
     t = torch.from_numpy(x.T[None].copy())
     for m, d in enumerate(dils):
@@ -98,6 +182,24 @@ def main():
                 err = np.abs(out - ref).max()
                 assert np.isfinite(out).all() and err < 2e-4, (k, dils, L, R, strips, err)
     print("streaming ResBlock schedule == direct ResBlock1 on every case")
+    C = 16
+    for k in (3, 7, 11):
+        for dils in ([1, 3, 5], [5], [3, 5]):
+            for (L, R, strips) in ((1000, 96, 1), (1000, 96, 3), (777, 96, 2), (300, 96, 1), (90, 96, 2), (1001, 96, 7)):
+                nd = len(dils)
+                W1 = [rng.standard_normal((C, C, k), dtype=np.float32) / np.float32(np.sqrt(C * k)) for _ in range(nd)]
+                W2 = [rng.standard_normal((C, C, k), dtype=np.float32) / np.float32(np.sqrt(C * k)) for _ in range(nd)]
+                B1 = [(rng.standard_normal(C, dtype=np.float32) * np.float32(0.1)).astype(np.float32) for _ in range(nd)]
+                B2 = [(rng.standard_normal(C, dtype=np.float32) * np.float32(0.1)).astype(np.float32) for _ in range(nd)]
+                x = rng.standard_normal((L, C), dtype=np.float32)
+                out = np.full((L, C), np.nan, np.float32)
+                sl = -(-L // strips)
+                for s in range(strips):
+                    run_strip2(x, W1, B1, W2, B2, k, dils, s * sl, min(L, (s + 1) * sl), R, out)
+                ref = reference(x, W1, B1, W2, B2, k, dils)
+                err = np.abs(out - ref).max()
+                assert np.isfinite(out).all() and err < 2e-4, ("v2", k, dils, L, R, strips, err)
+    print("k_rb_stream2 schedule (shared X/H rows, dual-written histories, time-keyed swizzle) == direct ResBlock1 on every case")
 
 
 if __name__ == "__main__":
