@@ -247,6 +247,111 @@ def infer_full_case(name: str, T: int, skip_head=None, return_length=None, retur
         name, o.pow(2).mean().sqrt().item(), err, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
 
 
+def front_full_case(name: str = "bigfront_v2_B1_T1198_z", T: int = 1198, seed: int = 1234):
+    """enc_p + z_p + flow^-1 of the REFERENCE modules at the benchmark size (one 10 s clip: T = 1198, global attention over all
+    frames): only ``z * mask`` is stored (0.9 MB); phone / pitch / noise are regenerated from the seeds by the test."""
+    cfg, fcfg = CONFIGS["v2_48k"], FrontConfig()
+    wf = synth.make_front_weights(fcfg, seed)
+    net = build_reference_net(cfg, fcfg, synth.make_dec_weights(cfg, seed), wf)
+    phone = synth.make_phone(1, T, 768, seed)
+    pitch = synth.make_pitch(synth.make_f0(1, T))
+    lengths, sid = torch.tensor([T]), torch.tensor([3])
+    with torch.no_grad():
+        g = net.emb_g(sid).unsqueeze(-1)
+        m_p, logs_p, x_mask = net.enc_p(phone, pitch, lengths, None)
+        noise = torch.randn(m_p.shape, generator=torch.Generator().manual_seed(seed + 9))
+        z = net.flow((m_p + torch.exp(logs_p) * noise * 0.66666) * x_mask, x_mask, g=g, reverse=True)
+        z2, m1, _ = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, noise, None, {})
+    err = (z2 - z).abs().max().item()
+    assert err < 5e-5, "%s: front oracle deviates from the reference by %g" % (name, err)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), seed=seed, T=T, sid=sid.numpy(), weights_sha256=synth.weights_sha256(wf),
+                        z=(z * x_mask).numpy(), oracle_max_abs_dev=err)
+    print("%-28s z rms %.3f  oracle-vs-reference max dev %.2e  (%d KB)" % (
+        name, z.pow(2).mean().sqrt().item(), err, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
+def import_reference_pipeline():
+    """The REAL ``infer.modules.vc.pipeline`` of the reference.  Its module-level imports of faiss / librosa and numba's ``jit``
+    (rvc/f0/gen.py) are not installable offline and are NOT used by the code paths exercised here (no index file, rms_mix_rate 1,
+    no resample, precomputed f0): they are replaced by empty stand-ins for the import only."""
+    import types
+
+    for name in ("faiss", "librosa", "numba"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "numba":
+                m.jit = lambda *a, **k: (lambda f: f)
+            sys.modules[name] = m
+    sys.path.insert(0, REF)
+    os.environ.setdefault("rmvpe_root", "/nonexistent")
+    import importlib.util
+
+    # by file: the package's __init__ would pull in the WebUI's audio I/O stack (av, ffmpeg), which this path never touches
+    spec = importlib.util.spec_from_file_location("rvc_reference_pipeline", os.path.join(REF, "infer", "modules", "vc", "pipeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+PIPE_CFG = dict(x_pad=1, x_query=1, x_center=1, x_max=1, is_half=False)
+
+
+def pipeline_case(name: str = "pipeline_v2_48k_3seg", n_audio: int = 38400, seed: int = 1234, protect: float = 0.33):
+    """The reference's own ``Pipeline.pipeline`` (pipeline.py:186-360) -- high-pass, cut points, three ``Pipeline.vc`` calls
+    (x2 interpolation, protect mix, ``net_g.infer`` of the reference synthesizer with seeded weights), concatenation, int16-range
+    scaling -- with a seeded stand-in for HuBERT (oracle/synth.py FakeHubert), a precomputed f0 track (if_f0 = 2) and no
+    index.  Stored: the returned waveform, the per-call frame counts, the sha256 of the injected noise and of the weights."""
+    import hashlib
+    import types
+
+    pl = import_reference_pipeline()
+    cfg, fcfg = CONFIGS["v2_48k"], FrontConfig()
+    wd, wf = synth.make_dec_weights(cfg, seed), synth.make_front_weights(fcfg, seed)
+    net = build_reference_net(cfg, fcfg, wd, wf)
+    config = types.SimpleNamespace(device=torch.device("cpu"), **PIPE_CFG)
+    pipe = pl.Pipeline(cfg.sr, config)
+    audio = synth.make_audio16k(n_audio, seed)
+    p_len_all = (n_audio + 2 * pipe.t_pad) // pipe.window
+    pitchf = synth.make_f0(1, p_len_all)[0]
+    pitch = synth.make_pitch(pitchf)
+    lens, raw = [], []
+    orig_infer, orig_vc = net.infer, pl.Pipeline.vc
+
+    def infer_spy(phone, lengths, *a, **k):
+        lens.append(int(phone.shape[1]))
+        return orig_infer(phone, lengths, *a, **k)
+
+    def vc_spy(self, *a, **k):
+        o = orig_vc(self, *a, **k)
+        raw.append(o.copy())
+        return o
+
+    net.infer = infer_spy
+    pl.Pipeline.vc = vc_spy
+    try:
+        torch.manual_seed(114514)
+        times = [0, 0, 0]
+        out = pipe.pipeline(synth.FakeHubert(768, seed), net, 3, audio.copy(), times, 0, (pitch.numpy(), pitchf.numpy()), "", 0.75, 2, 3,
+                            cfg.sr, 0, 1, "v2", protect)
+    finally:
+        pl.Pipeline.vc = orig_vc
+    assert len(lens) == 3, lens
+    h = hashlib.sha256()
+    for nz, nd in synth.infer_noise(lens, cfg.upp):
+        h.update(nz.numpy().tobytes())
+        h.update(nd.numpy().tobytes())
+    cat = np.concatenate([r[pipe.t_pad_tgt:-pipe.t_pad_tgt] for r in raw])
+    scale = 32768.0 / max(1.0, float(np.abs(cat).max()) / 0.99)
+    assert np.allclose(cat * scale, out, rtol=1e-6, atol=1e-3)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), seed=seed, n_audio=n_audio, protect=protect, sid=3, out=out.astype(np.float32),
+                        seg_frames=np.array(lens), seg0_raw_len=raw[0].shape[0], scale=scale, noise_sha256=h.hexdigest(),
+                        front_sha256=synth.weights_sha256(wf), dec_sha256=synth.weights_sha256(wd),
+                        **{"cfg_" + k: v for k, v in PIPE_CFG.items()})
+    print("%-28s out rms %.1f (int16 range), segments %s, scale %.1f  (%d KB)" % (
+        name, float(np.sqrt(np.mean(out.astype(np.float64) ** 2))), lens, scale, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
 def glue_case(name: str = "glue_f0"):
     """The f0 chain of the REFERENCE itself -- RMVPE._to_local_average_cents/_decode (rvc/f0/rmvpe.py:119-164),
     F0Predictor._resize_f0/_interpolate_f0 (rvc/f0/f0.py:31-78), post_process (rvc/f0/gen.py:10-41, numba stubbed to a
@@ -349,6 +454,9 @@ def main():
         return dec_full_case()
     if os.environ.get("GOLDEN_ONLY_MUTE"):
         return mute_case()
+    if os.environ.get("GOLDEN_ONLY_PIPELINE"):
+        pipeline_case()
+        return front_full_case()
     mute_case()
     main_front()
     if os.environ.get("GOLDEN_ONLY_FRONT"):
@@ -364,6 +472,8 @@ def main():
     dec_case("dec_v1_40k_nres_down_T31", "v1_40k", 1, 31, n_res=26)
     infer_case()
     dec_full_case()
+    pipeline_case()
+    front_full_case()
 
 
 if __name__ == "__main__":

@@ -291,3 +291,49 @@ def make_legacy_checkpoint(cfg: GenConfig, version: str = "v2", seed: int = 1234
     cpt = OrderedDict(weight=weight, config=config, f0=1 if cfg.use_f0 else 0, version=version,
                       info="synthetic", sr={32000: "32k", 40000: "40k", 48000: "48k"}[cfg.sr])
     return cpt, expect
+
+
+# ----------------------------------------------------------------------------------------------
+# Stand-ins at the Pipeline.vc / Pipeline.pipeline boundary (infer/modules/vc/pipeline.py:76-360)
+# ----------------------------------------------------------------------------------------------
+
+class FakeHubert:
+    """Stands in for the fairseq HuBERT (not installable offline) as ``Pipeline.vc`` calls it (pipeline.py:103-110):
+    ``extract_features(source=, padding_mask=, output_layer=)`` -> ``(feats [1, n, d],)`` with the conv stack's frame count
+    ``n = (len - 400) // 320 + 1`` and seeded features (a function of ``seed`` and ``n`` only), on the caller's device."""
+
+    def __init__(self, d: int = 768, seed: int = 1234):
+        self.d, self.seed, self.calls = d, seed, 0
+
+    def extract_features(self, source, padding_mask, output_layer):
+        assert source.dim() == 2 and source.shape[0] == 1 and padding_mask.shape == source.shape and output_layer in (9, 12)
+        n = (int(source.shape[1]) - 400) // 320 + 1
+        self.calls += 1
+        return (make_phone(1, n, self.d, self.seed + n).to(source.device, source.dtype),)
+
+    def final_proj(self, x):  # v1 only (768 -> 256)
+        return x[..., :256]
+
+
+def make_audio16k(n: int, seed: int = 1234) -> np.ndarray:
+    """A 16 kHz float32 test signal with loud and quiet stretches (so that the quiet-point search of pipeline.py:219-232 has
+    distinct minima): a chirp under a slow envelope plus a little noise."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    env = 0.55 + 0.45 * np.sin(2 * np.pi * 0.9 * t + 0.3)
+    x = 0.3 * env * np.sin(2 * np.pi * (180.0 * t + 40.0 * t * t)) + 0.01 * rng.standard_normal(n)
+    return x.astype(np.float32)
+
+
+def infer_noise(lengths, upp: int, seed: int = 114514):
+    """The draws of consecutive ``net_g.infer`` calls from ONE CPU generator seeded like the reference seeds nothing but the
+    tests do (``torch.manual_seed(seed)``): per call ``randn(1, 192, T)`` (z_p, synthesizers.py:182), ``rand(1, 1, 1)`` and
+    ``randn(1, T * upp, 1)`` (sine source, generators.py:170-193) -> list of (noise_zp [1,192,T], noise_dec [1, T*upp])."""
+    gen = torch.Generator().manual_seed(seed)
+    out = []
+    for T in lengths:
+        nz = torch.randn(1, 192, int(T), generator=gen)
+        torch.rand(1, 1, 1, generator=gen)
+        nd = torch.randn(1, int(T) * upp, 1, generator=gen).squeeze(-1)
+        out.append((nz, nd))
+    return out

@@ -12,6 +12,12 @@ rebinds the two names the reference resolves its hot path through:
   every other attribute is forwarded to the real ``faiss`` module when one is installed (index training in web.py keeps
   working), and raises a clear error when it is not.
 
+* ``Pipeline.vc`` / ``Pipeline.pipeline`` (infer/modules/vc/pipeline.py:76,186) and ``RVC.infer`` (infer/lib/rtrvc.py:134): replaced
+  ON THE REFERENCE'S OWN CLASSES by the device-resident versions (``rvc_amd.pipeline.vc_hip`` / ``pipeline_hip``,
+  ``rvc_amd.realtime.rvc_infer_hip``), so the unmodified ``VC.vc_single`` and the realtime GUI loop keep the HuBERT features on
+  the GPU through retrieval, x2, protect mix, ``net_g.infer``, RMS mix and int16 scaling (one copy to the host at the end).
+  The originals stay reachable (an index object the HIP reader cannot serve is handed back to them).
+
 Nothing of the reference is edited; ``uninstall()`` restores the original bindings.
 """
 from __future__ import annotations
@@ -28,6 +34,7 @@ from . import synthesizer as _syn
 
 _state: dict = {}
 _LOADER_USERS = ("infer.modules.vc.modules", "infer.modules.vc.hash", "infer.lib.rtrvc")
+_PIPELINE_MODULE, _RTRVC_MODULE = "infer.modules.vc.pipeline", "infer.lib.rtrvc"
 _FAISS_USERS = ("infer.modules.vc.pipeline", "infer.lib.rtrvc")
 
 
@@ -41,7 +48,16 @@ class _FaissShim(types.ModuleType):
         self.__dict__["__doc__"] = "rvc_amd faiss shim (read_index -> IVFFlatHIP); other names forwarded to the real faiss"
 
     def read_index(self, path, *a, **k):
-        return _ivf.read_index(path, device=self._rvcmi_device)
+        dev = self._rvcmi_device
+        if dev is None:  # the process's current GPU (the reference passes config.device to the loader, not to faiss)
+            dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        try:
+            return _ivf.read_index(path, device=dev)
+        except Exception:  # an index kind the HIP reader does not serve (not IVF-Flat / L2, hashed direct map ...)
+            real = self.__dict__.get("_rvcmi_real")
+            if real is None:
+                raise
+            return real.read_index(path, *a, **k)  # real faiss can: the rebound vc / infer hand such an index to the reference code
 
     def write_index(self, index, path):
         if isinstance(index, _ivf.IVFFlatHIP):
@@ -56,8 +72,43 @@ class _FaissShim(types.ModuleType):
         return getattr(real, name)
 
 
-def install(operand: str = "fp16", front: bool = True, device="cuda:0", patch_faiss: bool = True) -> None:
-    """Route the reference's loader and index reader through the HIP path (idempotent)."""
+def _rebind_methods(rebound) -> None:
+    """``Pipeline.vc`` / ``Pipeline.pipeline`` / ``RVC.infer`` -> the device-resident versions.  The modules are imported here
+    (after the faiss name has been taken care of) when the checkout provides them; a checkout without them is left alone."""
+    from . import pipeline as _pl
+    from . import realtime as _rt
+
+    def grab(modname):
+        mod = sys.modules.get(modname)
+        if mod is None:
+            try:
+                mod = importlib.import_module(modname)
+            except Exception:  # noqa  (a trimmed checkout, or one whose optional dependencies are missing)
+                return None
+        return mod
+
+    mod = grab(_PIPELINE_MODULE)
+    cls = getattr(mod, "Pipeline", None) if mod is not None else None
+    if cls is not None:
+        for name, new in (("vc", _pl.vc_hip), ("pipeline", _pl.pipeline_hip)):
+            old = cls.__dict__.get(name)
+            if old is not None and old is not new:
+                if name == "vc":
+                    _pl.vc_hip._rvcmi_original = old
+                setattr(cls, name, new)
+                rebound.append((cls, name, old))
+    mod = grab(_RTRVC_MODULE)
+    cls = getattr(mod, "RVC", None) if mod is not None else None
+    if cls is not None:
+        old = cls.__dict__.get("infer")
+        if old is not None and old is not _rt.rvc_infer_hip:
+            _rt.rvc_infer_hip._rvcmi_original = old
+            cls.infer = _rt.rvc_infer_hip
+            rebound.append((cls, "infer", old))
+
+
+def install(operand: str = "fp16", front: bool = True, device=None, patch_faiss: bool = True, patch_pipeline: bool = True) -> None:
+    """Route the reference's loader, index reader and conversion methods through the HIP path (idempotent)."""
     if _state.get("installed"):
         return
     import rvc.synthesizer as rs  # the reference package must be importable: this IS the plug-in boundary
@@ -73,6 +124,23 @@ def install(operand: str = "fp16", front: bool = True, device="cuda:0", patch_fa
     get_synthesizer._rvcmi_original = ref_get
     load_synthesizer._rvcmi_original = ref_load
     rebound = []
+    # TorchScript export (rvc/synthesizer.py:38-64, used by rtrvc.py set_jit_model) scripts the REFERENCE modules: it resolves
+    # ``load_synthesizer`` at call time, so it gets the original loader back for the duration of the call.
+    ref_export = getattr(rs, "synthesizer_jit_export", None)
+    if ref_export is not None:
+        def synthesizer_jit_export(*a, **k):
+            cur = rs.load_synthesizer
+            rs.load_synthesizer = ref_load
+            try:
+                return ref_export(*a, **k)
+            finally:
+                rs.load_synthesizer = cur
+
+        synthesizer_jit_export._rvcmi_original = ref_export
+        for mod in [rs] + [sys.modules[m] for m in _LOADER_USERS if m in sys.modules]:
+            if getattr(mod, "synthesizer_jit_export", None) is ref_export:
+                mod.synthesizer_jit_export = synthesizer_jit_export
+                rebound.append((mod, "synthesizer_jit_export", ref_export))
     for mod in [rs] + [sys.modules[m] for m in _LOADER_USERS if m in sys.modules]:
         for name, old, new in (("get_synthesizer", ref_get, get_synthesizer), ("load_synthesizer", ref_load, load_synthesizer)):
             if getattr(mod, name, None) is old:
@@ -94,6 +162,8 @@ def install(operand: str = "fp16", front: bool = True, device="cuda:0", patch_fa
             if mod is not None and hasattr(mod, "faiss"):
                 rebound.append((mod, "faiss", mod.faiss))
                 mod.faiss = shim
+    if patch_pipeline:
+        _rebind_methods(rebound)
 
 
 def uninstall() -> None:

@@ -117,3 +117,38 @@ class RealtimeVC:
                 self._resample[upp_res] = Resample(orig_freq=upp_res, new_freq=self.tgt_sr // 100, dtype=torch.float32).to(self.device)
             audio = self._resample[upp_res](audio[:, : return_length * upp_res])
         return audio.squeeze()
+
+
+def rvc_infer_hip(self, input_wav: torch.Tensor, block_frame_16k, skip_head, return_length, f0method, protect: float = 1.0):
+    """Drop-in ``RVC.infer`` (infer/lib/rtrvc.py:134-260; bound by ``rvc_amd.install()``): HuBERT and the f0 estimator are the
+    object's own PyTorch modules, everything after them runs on the device through a ``RealtimeVC`` that lives on the object.
+    A precomputed ``(pitch, pitchf)`` tuple or an index object that is not ours goes to the reference's own method."""
+    from .ivf import IVFFlatHIP
+
+    index = getattr(self, "index", None)
+    if isinstance(f0method, tuple) or (index is not None and not isinstance(index, IVFFlatHIP)):
+        orig = getattr(rvc_infer_hip, "_rvcmi_original", None)
+        if orig is None:
+            raise TypeError("RVC.infer: unsupported arguments for the HIP path and no reference method is bound")
+        return orig(self, input_wav, block_frame_16k, skip_head, return_length, f0method, protect)
+    rt = getattr(self, "_rvcmi_rt", None)
+    if rt is None or rt.net_g is not self.net_g:
+        rt = self._rvcmi_rt = RealtimeVC(self.net_g, index=index, index_rate=self.index_rate, device=self.device, if_f0=self.if_f0,
+                                         tgt_sr=self.tgt_sr, f0_up_key=self.f0_up_key, formant_shift=self.formant_shift,
+                                         window=self.window)
+    rt.index, rt.index_rate = index, float(self.index_rate)      # set_index_rate / set_key / set_formant act on the RVC object
+    rt.f0_up_key, rt.formant_shift = self.f0_up_key, self.formant_shift
+    with torch.no_grad():                                           # rtrvc.py:142-162
+        feats = input_wav.half() if self.is_half else input_wav.float()
+        feats = feats.to(self.device)
+        if feats.dim() == 2:
+            feats = feats.mean(-1)
+        feats = feats.view(1, -1)
+        mask = torch.zeros(feats.shape, dtype=torch.bool, device=feats.device)
+        logits = self.hubert.extract_features(source=feats, padding_mask=mask, output_layer=9 if self.version == "v1" else 12)
+        feats = self.hubert.final_proj(logits[0]) if self.version == "v1" else logits[0]
+    pitch = pitchf = None
+    if self.if_f0 == 1:                                             # rtrvc.py:203-212
+        n = f0_extractor_frame(block_frame_16k, f0method, self.window)
+        pitch, pitchf = self._get_f0(input_wav[-n:], self.f0_up_key - self.formant_shift, method=f0method)
+    return rt.infer(feats, int(input_wav.shape[0]), block_frame_16k, skip_head, return_length, pitch=pitch, pitchf=pitchf, protect=protect)

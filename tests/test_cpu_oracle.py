@@ -321,3 +321,18 @@ def test_committed_faisslike_report_has_every_case():
     assert {"baseline_10000x768_iid_599q", "stress_1000000x256_clustered_599q", "mute_hubert_768_real_rows_with_exact_duplicates"} <= names
     base = rep["cases"]["baseline_10000x768_iid_599q"]["variants"]
     assert all(v["top1_flips"] == 0 for v in base.values())
+
+
+def test_front_oracle_matches_the_reference_modules_at_benchmark_size():
+    """oracle/front_oracle.py == the reference's enc_p + flow^-1 at T = 1198 (fixture written by the reference modules)."""
+    d = load_golden("bigfront_v2_B1_T1198_z")
+    seed, T = int(d["seed"]), int(d["T"])
+    fcfg = FrontConfig()
+    wf = synth.make_front_weights(fcfg, seed)
+    assert synth.weights_sha256(wf) == str(d["weights_sha256"])
+    phone = synth.make_phone(1, T, 768, seed)
+    pitch = synth.make_pitch(synth.make_f0(1, T))
+    noise = torch.randn(1, 192, T, generator=torch.Generator().manual_seed(seed + 9))
+    with torch.no_grad():
+        z, m1, _ = front_oracle.infer_front(fcfg, wf, phone, pitch, torch.tensor([T]), torch.from_numpy(d["sid"]), noise)
+    assert np.abs((z * m1).numpy() - d["z"]).max() < 5e-5
