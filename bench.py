@@ -125,8 +125,8 @@ def dist_selftest(a):
     tt = torch.tensor([t_b], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"selftest": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "index_blob_bytes": int(got.numel()),
-                          "index_broadcast_s": float(tt.item()), "ranks_agree": bool(ok.item()), "shards_cover": bool((cover == 1).all())}))
+        emit({"selftest": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "index_blob_bytes": int(got.numel()),
+                          "index_broadcast_s": float(tt.item()), "ranks_agree": bool(ok.item()), "shards_cover": bool((cover == 1).all())})
     dist.barrier()
     dist.destroy_process_group()
     if not bool(ok.item()) or not bool((cover == 1).all()):
@@ -383,16 +383,33 @@ def stream_mode(a):
         st2, cap2 = _time_chunks(whole, graph=bool(a.graph))
         assert torch.isfinite(hold["w"]).all()
         line["whole_chunk"] = dict(st2, what="retrieval (16 rows, guarded) + x2 + protect + enc_p(282) + flow(56) + decode(31) + SOLA", hipgraph=cap2)
-    print(json.dumps(line))
+    emit(line)
+
+
+_REAL_STDOUT = None
+
+
+def emit(line: dict) -> None:
+    """THE one JSON line, on the process's real stdout."""
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
 
 
 def main():
+    global _REAL_STDOUT
     a = parse()
     if a.torch_gpu_baseline_worker:
         return torch_gpu_baseline_worker(a)
+    if not a.stream:
+        ensure_world(a)  # may replace this process with the N-rank launcher (before fd 1 is touched)
+    if _REAL_STDOUT is None:
+        # libraries write banners to fd 1 (RCCL prints its version block at the first communicator): keep stdout for the JSON line
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     if a.stream:
         return stream_mode(a)
-    ensure_world(a)
     if a.dist_selftest:
         return dist_selftest(a)
     rank = int(os.environ.get("RANK", "0"))
@@ -727,7 +744,7 @@ def main():
             line["gpu_torch_baseline"] = tgpu
         if rep_stats is not None:
             line["repeats"] = rep_stats
-        print(json.dumps(line))
+        emit(line)
     if use_dist:
         dist.barrier()  # the other ranks wait for rank 0's untimed roofline / whole-infer legs before tearing RCCL down
         dist.destroy_process_group()

@@ -24,10 +24,15 @@ struct Geo {
     int ver;               // 1 = k_rb_stream, 2 = k_rb_stream2 (two blocks per CU, swizzled 256-byte rows)
     double c0;             // planning: a block's time is steps x (k + c0) units
 };
-// k_rb_stream2 (two blocks per CU) is parity-green but measured SLOWER than k_rb_stream at B = 1 (0.75 vs 0.62 ms):
-// opt-in for A/B runs (RVCMI_RS_V2=1, read once)
-bool use_v2() {
-    static const bool v = []() { const char* e = getenv("RVCMI_RS_V2"); return e && e[0] == '1'; }();
+// k_rb_stream2 (two blocks per CU): every strip pays the same warm-up rows but a step is half as long, so it needs LONG strips
+// to win.  RVCMI_RS_V2 (dev, read once): unset / "auto" = from `RVCMI_RS_V2_STEPS` steps per block on (default
+// 24: large batches), "1" = whenever supported, "0" = never.
+int v2_mode() {
+    static const int v = []() { const char* e = getenv("RVCMI_RS_V2"); return !e ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)); }();
+    return v;
+}
+int v2_min_steps() {
+    static const int v = []() { const char* e = getenv("RVCMI_RS_V2_STEPS"); return e ? atoi(e) : 24; }();
     return v;
 }
 double plan_c0(double dflt) {
@@ -41,10 +46,11 @@ bool small_tiles() {
     const char* e = getenv("RVCMI_RS_SMALL");
     return !(e && e[0] == '0');
 }
-bool geo_for(int C, int nd, Geo& g) {
+bool geo_for(int C, int nd, Geo& g, int ver = 1) {
     const bool sm = small_tiles();
     if (C == 256 && nd == 1) { g = {2, sm ? 3 : 4, 4, 1, 1, 4.4}; return true; }
-    if (C == 128 && nd == 3 && use_v2()) { g = {1, 3, 4, 2, 2, plan_c0(1.0)}; return true; }
+    // k_rb_stream2: measured cycles per pair-step 46.2k / 32.9k / 20.0k for k = 11 / 7 / 3 => time ~ steps x (k + 3.1)
+    if (C == 128 && nd == 3 && ver == 2) { g = {1, 3, 4, 2, 2, plan_c0(3.1)}; return true; }
     if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1, 1, 4.4}; return true; }
     // (C = 128 pair by pair with TWO blocks per CU -- NJ = 4, 225 registers, 0 spills -- was measured: both waves of a SIMD sit in
     //  their K loops at the same time (72 cycles per MFMA per wave), the phases overlap no better than in the one-wave design
@@ -143,10 +149,24 @@ bool rb_stream_supported(int operand, int C, int nd) {
     return operand != RVCMI_OPERAND_F32 && geo_for(C, nd, g);
 }
 
+static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B,
+                       long bstride, hipStream_t st, bool dry_run);
+
 bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B, long bstride, bool force,
                       hipStream_t st, bool dry_run) {
     Geo g;
-    if (operand == RVCMI_OPERAND_F32 || !geo_for(C, nd, g) || njobs < 1 || njobs > 3) return false;
+    if (operand == RVCMI_OPERAND_F32 || njobs < 1 || njobs > 3) return false;
+    if (v2_mode() && geo_for(C, nd, g, 2) && g.ver == 2 &&
+        launch_geo(g, v2_mode() == 1 ? (force ? 0 : 4) : v2_min_steps(), operand, C, nd, jobs, njobs, L, B, bstride, st, dry_run))
+        return true;
+    if (!geo_for(C, nd, g)) return false;
+    // auto mode: only where the persistent walk measured faster than the tile kernels -- C = 128 (whole resblocks) from 4 steps
+    // per block; C = 256 (pair level) only with long strips (large batches).
+    return launch_geo(g, force ? 0 : (C == 128 ? 4 : 8), operand, C, nd, jobs, njobs, L, B, bstride, st, dry_run);
+}
+
+static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B,
+                       long bstride, hipStream_t st, bool dry_run) {
     const int R = 32 * g.NJ;
     RbStreamArgs a;
     memset(&a, 0, sizeof(a));
@@ -266,9 +286,7 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
         a.skew = skew;
         a.flags = prio & 1;
     }
-    // auto mode: only where the persistent walk measured faster than the tile kernels -- C = 128 (whole resblocks) from 4 steps
-    // per block; C = 256 (pair level) only with long strips (large batches).
-    if (!force && min_steps < (C == 128 ? 4 : 8)) return false;
+    if (min_steps < min_steps_required) return false;
     const size_t smem = g.ver == 2 ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
                                    : (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
     if (smem > (size_t)160 * 1024 / g.bpc)
