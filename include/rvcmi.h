@@ -142,6 +142,12 @@ typedef struct {
     double bytes;      /* algorithmic bytes moved to/from global memory                        */
 } rvcmi_kernel_stat;
 int rvcmi_nsf_profile_enable(rvcmi_nsf* h, int enable);
+/* Development / test options of ONE handle (kernel-family forcing, tile heights, phase stamps, timing ablations).  A handle
+ * reads the environment variables RVCMI_<KEY> exactly once, when it is created; afterwards only this call changes an option
+ * (value NaN = back to the default).  The forward / search paths never read the environment.  Keys: see the option comments
+ * of the handle structs in csrc/nsf.hip, csrc/rb_stream.hpp, csrc/front.hip, csrc/ivf.hip.  Not part of the reference's
+ * surface; product code does not call these. */
+int rvcmi_nsf_set_option(rvcmi_nsf* h, const char* key, double value);
 int rvcmi_nsf_profile_read(rvcmi_nsf* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset);
 
 /* ------------------------------------------------------------------------------------------- */
@@ -199,6 +205,7 @@ int rvcmi_front_debug_forward(rvcmi_front* h, int B, int T, const float* phone_d
                               const int64_t* lengths_dev, const float* g_dev, const float* noise_dev, int flow_head,
                               const char* what, float* out_host, size_t capacity_floats, int64_t shape_out[3],
                               void* stream);
+int rvcmi_front_set_option(rvcmi_front* h, const char* key, double value);
 int rvcmi_front_profile_enable(rvcmi_front* h, int enable);
 int rvcmi_front_profile_read(rvcmi_front* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset);
 
@@ -279,6 +286,7 @@ int rvcmi_ivf_create_from_blob(void* dev_ptr, size_t bytes, int device, int take
                                rvcmi_ivf** out);
 
 /* Per-phase HIP-event timing for bench.py (coarse / scan / blend), same contract as the nsf one. */
+int rvcmi_ivf_set_option(rvcmi_ivf* h, const char* key, double value);
 int rvcmi_ivf_profile_enable(rvcmi_ivf* h, int enable);
 int rvcmi_ivf_profile_read(rvcmi_ivf* h, rvcmi_kernel_stat* stats, int capacity, int* n, int reset);
 
@@ -321,6 +329,14 @@ int rvcmi_glue_scale_int16_range(float* audio_dev, int64_t n, float* scratch_dev
 int rvcmi_glue_sola(const float* infer_wav_dev, int64_t n, float* sola_buffer_dev, int Lb, int Ls,
                     const float* fade_in_dev, const float* fade_out_dev, int block_frame, float* out_block_dev,
                     int* offset_out_dev, void* stream);
+
+/* The formant-shift resample of the realtime path (rtrvc.py:248-259, torchaudio.transforms.Resample(orig_freq = upp_res,
+ * new_freq = tgt_sr / 100)): out[j * new + p] = sum_{k < K} kernel[p][k] * xpad[j * orig + k], xpad = x with `width` zeros in
+ * front and zeros behind; orig / new already divided by their gcd; kernel_dev [new][K] (K = 2 * width + orig) is torchaudio's
+ * windowed-sinc table (rvc_amd.realtime.sinc_resample_kernel restates its published formula: hann window, lowpass_filter_width 6,
+ * rolloff 0.99).  n_out = ceil(new * n / orig) for the whole signal.  PARITY UNPINNED: torchaudio is not installable offline. */
+int rvcmi_glue_resample_poly(const float* x_dev, int64_t n, const float* kernel_dev, int orig, int new_, int K, int width,
+                             float* out_dev, int64_t n_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -172,3 +172,32 @@ def sola(infer_wav: torch.Tensor, sola_buffer: torch.Tensor, fade_in: torch.Tens
     infer_wav[:Lb] += sola_buffer * fade_out
     new_buf = infer_wav[block_frame: block_frame + Lb].clone()
     return infer_wav[:block_frame].clone(), new_buf, sola_offset
+
+
+def sinc_resample(x: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> np.ndarray:
+    """PARITY UNPINNED (torchaudio is not installable offline).  ``torchaudio.transforms.Resample(orig_freq, new_freq,
+    dtype=float32)`` (rtrvc.py:251-259) restated independently of the product from torchaudio's published
+    ``_get_sinc_resample_kernel`` / ``_apply_sinc_resample_kernel``: hann-windowed sinc table in float32, zero padding
+    ``(width, width + orig)``, strided correlation, ``ceil(new * n / orig)`` samples.  The sums run in float64."""
+    import math
+
+    g = math.gcd(int(orig_freq), int(new_freq))
+    of, nf = int(orig_freq) // g, int(new_freq) // g
+    base = np.float32(min(of, nf) * rolloff)
+    width = int(math.ceil(lowpass_filter_width * of / (min(of, nf) * rolloff)))
+    idx = (np.arange(-width, width + of, dtype=np.float32) / np.float32(of))[None, :]
+    t = (np.arange(0, -nf, -1, dtype=np.float32) / np.float32(nf))[:, None] + idx
+    t = np.clip((t * base).astype(np.float32), -lowpass_filter_width, lowpass_filter_width).astype(np.float32)
+    window = (np.cos((t * np.float32(math.pi) / np.float32(lowpass_filter_width) / np.float32(2)).astype(np.float32)) ** 2).astype(np.float32)
+    tp = (t * np.float32(math.pi)).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sinc = np.where(tp == 0, np.float32(1), (np.sin(tp) / tp).astype(np.float32))
+    kern = (sinc * window * np.float32(base / np.float32(of))).astype(np.float32)          # [nf, K]
+    x = np.asarray(x, dtype=np.float32)
+    n = x.shape[-1]
+    xp = np.concatenate([np.zeros(width, np.float32), x, np.zeros(width + of, np.float32)])
+    K = kern.shape[1]
+    nblk = (xp.shape[0] - K) // of + 1
+    frames = np.lib.stride_tricks.sliding_window_view(xp, K)[::of][:nblk]             # [nblk, K]
+    out = (frames.astype(np.float64) @ kern.astype(np.float64).T).reshape(-1)            # [nblk * nf], phase fastest
+    return out[: -(-nf * n // of)].astype(np.float32)

@@ -66,6 +66,7 @@ SYMBOLS = [
     ("rvcmi_nsf_workspace_bytes", C.c_size_t, [_P]),
     ("rvcmi_nsf_debug_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_char_p, _P, C.c_size_t,
                                           C.POINTER(C.c_int64), _P]),
+    ("rvcmi_nsf_set_option", C.c_int, [_P, C.c_char_p, C.c_double]),
     ("rvcmi_nsf_profile_enable", C.c_int, [_P, C.c_int]),
     ("rvcmi_nsf_profile_read", C.c_int, [_P, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int), C.c_int]),
     ("rvcmi_front_create", C.c_int, [C.POINTER(FrontConfig), C.POINTER(Tensor), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
@@ -74,6 +75,7 @@ SYMBOLS = [
     ("rvcmi_front_workspace_bytes", C.c_size_t, [_P]),
     ("rvcmi_front_debug_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_char_p, _P, C.c_size_t,
                                             C.POINTER(C.c_int64), _P]),
+    ("rvcmi_front_set_option", C.c_int, [_P, C.c_char_p, C.c_double]),
     ("rvcmi_front_profile_enable", C.c_int, [_P, C.c_int]),
     ("rvcmi_front_profile_read", C.c_int, [_P, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int), C.c_int]),
     ("rvcmi_ivf_create_from_file", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
@@ -95,6 +97,7 @@ SYMBOLS = [
     ("rvcmi_ivf_centroids", C.c_int, [_P, _P]),
     ("rvcmi_ivf_blob_copy", C.c_int, [_P, _P, C.c_size_t, _P]),
     ("rvcmi_ivf_create_from_blob", C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("rvcmi_ivf_set_option", C.c_int, [_P, C.c_char_p, C.c_double]),
     ("rvcmi_ivf_profile_enable", C.c_int, [_P, C.c_int]),
     ("rvcmi_ivf_profile_read", C.c_int, [_P, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int), C.c_int]),
     ("rvcmi_glue_expand_protect", C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, C.c_float, C.c_int64, _P, _P]),
@@ -102,6 +105,7 @@ SYMBOLS = [
     ("rvcmi_glue_f0_post", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     ("rvcmi_glue_change_rms", C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, C.c_float, _P, _P]),
     ("rvcmi_glue_scale_int16_range", C.c_int, [_P, C.c_int64, _P, _P]),
+    ("rvcmi_glue_resample_poly", C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
     ("rvcmi_glue_sola", C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
 ]
 
@@ -168,6 +172,11 @@ def check(rc: int) -> None:
     if rc != 0:
         msg = lib().rvcmi_last_error()
         raise RvcmiError("rvcmi error %d: %s" % (rc, msg.decode(errors="replace") if msg else "?"))
+
+
+def set_option(fn, handle, key: str, value) -> None:
+    """Dev / test option of one handle (include/rvcmi.h rvcmi_*_set_option); ``value=None`` restores the default."""
+    check(fn(handle, key.encode(), float("nan") if value is None else float(value)))
 
 
 def read_stats(read_fn, handle, reset: bool = True) -> List[dict]:

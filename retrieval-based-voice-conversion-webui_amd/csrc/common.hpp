@@ -5,7 +5,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <string>
 #include <vector>
@@ -86,6 +88,30 @@ struct DevBuf {
             o.bytes = 0;
         }
         return *this;
+    }
+};
+
+// Dev / test options of a handle: a small key -> number table, filled ONCE at handle creation from the environment
+// (RVCMI_<KEY>) and changed afterwards only through rvcmi_{nsf,front,ivf}_set_option.  The forward / search paths read the
+// table; nothing on them calls getenv.  Keys are listed next to the handles that honour them.
+struct Options {
+    std::map<std::string, double> v;
+    void load_env(std::initializer_list<const char*> keys) {
+        for (const char* k : keys) {
+            const std::string e = std::string("RVCMI_") + k;
+            if (const char* sv = getenv(e.c_str())) v[k] = atof(sv);
+        }
+    }
+    bool has(const char* k) const { return v.find(k) != v.end(); }
+    double get(const char* k, double dflt) const {
+        auto it = v.find(k);
+        return it == v.end() ? dflt : it->second;
+    }
+    int geti(const char* k, int dflt) const { return (int)get(k, (double)dflt); }
+    bool on(const char* k) const { return get(k, 0.0) != 0.0; }
+    void set(const char* k, double val) {
+        if (val != val) v.erase(k);  // NaN: back to the default
+        else v[k] = val;
     }
 };
 

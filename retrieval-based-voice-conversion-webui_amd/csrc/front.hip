@@ -42,6 +42,9 @@ struct rvcmi_front {
     DevBuf X, X2, QK, KF, VT, A, F, ZP, Ha, Hb, SK, GC;  // QK: q [B][T][H]; KF / VT: k / v tiles in fragment order
     size_t ws_bytes = 0;
     Profiler prof;
+    // dev / test options (common.hpp Options): FR_NJ (1 / 2: time-tile height), FR_NO_FFN_FUSION, FR_STAMPS (prints; syncs).
+    // Read from RVCMI_<KEY> once, in rvcmi_front_create; changed afterwards only through rvcmi_front_set_option.
+    rvcmi::Options opt;
 };
 
 namespace {
@@ -70,9 +73,9 @@ static void ensure_dyn_lds(const void* kern, std::atomic<unsigned long long>& do
 
 // Time-tile height: 64 rows (NJ = 2) when that still gives every CU a block, else 32 rows -- at B = 1 a 10 s clip is
 // only 38 tiles of 32 frames, and one tile's MFMA work on one CU is the latency floor of a launch.
-static int pick_nj(int B, int T) {
-    if (const char* e = getenv("RVCMI_FR_NJ")) {  // tests force the large-batch tile height on small inputs
-        const int v = atoi(e);
+static int pick_nj(const rvcmi_front* h, int B, int T) {
+    if (h->opt.has("FR_NJ")) {  // tests force the large-batch tile height on small inputs
+        const int v = h->opt.geti("FR_NJ", 0);
         if (v == 1 || v == 2) return v;
     }
     return (long)B * ((T + 63) / 64) >= 192 ? 2 : 1;
@@ -101,7 +104,7 @@ void launch_conv_nj(rvcmi_front* h, const char* name, FrConvArgs a, const ConvLa
 }
 template <typename OpT, int CIN, int MI, int NW, int EPI>
 void launch_conv(rvcmi_front* h, const char* name, const FrConvArgs& a, const ConvLayer& L, int B, hipStream_t st) {
-    if (pick_nj(B, a.T) == 1) launch_conv_nj<OpT, CIN, MI, NW, EPI, 1>(h, name, a, L, B, st);
+    if (pick_nj(h, B, a.T) == 1) launch_conv_nj<OpT, CIN, MI, NW, EPI, 1>(h, name, a, L, B, st);
     else launch_conv_nj<OpT, CIN, MI, NW, EPI, 2>(h, name, a, L, B, st);
 }
 
@@ -123,8 +126,9 @@ void launch_wn_nj(rvcmi_front* h, FrWnArgs a, const ConvLayer& Lin, const ConvLa
     ensure_dyn_lds(reinterpret_cast<const void*>(kern), attr_done);
     const double flops = (Lin.flops_per_pos + Lrs.flops_per_pos) * (double)a.T * B;
     static unsigned long long* stamps = nullptr;  // dev only
-    if (getenv("RVCMI_FR_STAMPS") && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 64 * 8));
-    a.stamps = getenv("RVCMI_FR_STAMPS") ? stamps : nullptr;
+    const bool want_stamps = h->opt.on("FR_STAMPS");
+    if (want_stamps && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 64 * 8));
+    a.stamps = want_stamps ? stamps : nullptr;
     h->prof.launch(LAST ? "flow_wn_last" : "flow_wn", flops, 0.0, st, [&] {
         hipLaunchKernelGGL(kern, dim3((a.T + TT - 1) / TT, B), dim3(64 * (H / 32)), smem, st, a);
     });
@@ -140,7 +144,7 @@ void launch_wn_nj(rvcmi_front* h, FrWnArgs a, const ConvLayer& Lin, const ConvLa
 }
 template <typename OpT, bool LAST>
 void launch_wn(rvcmi_front* h, const FrWnArgs& a, const ConvLayer& Lin, const ConvLayer& Lrs, int B, hipStream_t st) {
-    if (pick_nj(B, a.T) == 1) launch_wn_nj<OpT, LAST, 1>(h, a, Lin, Lrs, B, st);
+    if (pick_nj(h, B, a.T) == 1) launch_wn_nj<OpT, LAST, 1>(h, a, Lin, Lrs, B, st);
     else launch_wn_nj<OpT, LAST, 2>(h, a, Lin, Lrs, B, st);
 }
 
@@ -168,7 +172,7 @@ void launch_ffn_nj(rvcmi_front* h, FrFfnArgs a, const ConvLayer& L1, const ConvL
 }
 template <typename OpT>
 void launch_ffn(rvcmi_front* h, const FrFfnArgs& a, const ConvLayer& L1, const ConvLayer& L2, int B, hipStream_t st) {
-    if (pick_nj(B, a.T) == 1) launch_ffn_nj<OpT, 1>(h, a, L1, L2, B, st);
+    if (pick_nj(h, B, a.T) == 1) launch_ffn_nj<OpT, 1>(h, a, L1, L2, B, st);
     else launch_ffn_nj<OpT, 2>(h, a, L1, L2, B, st);
 }
 
@@ -218,8 +222,9 @@ void front_forward_t(rvcmi_front* h, int B, int T, const float* phone, const lon
             a.T = T; a.Tp = Tp; a.H = H; a.ws = c.window_size;
             const double flops = 4.0 * (double)T * T * H * B;
             static unsigned long long* stamps = nullptr;  // dev only
-            if (getenv("RVCMI_FR_STAMPS") && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 256 * 8));
-            a.stamps = getenv("RVCMI_FR_STAMPS") ? stamps : nullptr;
+            const bool want_stamps = h->opt.on("FR_STAMPS");
+            if (want_stamps && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 256 * 8));
+            a.stamps = want_stamps ? stamps : nullptr;
             h->prof.launch("enc_attn", flops, 0.0, st, [&] {
                 if (c.window_size <= 10) hipLaunchKernelGGL((k_fr_attn<OpT, 96, 21>), dim3((T + 31) / 32, c.n_heads, B), dim3(256), 0, st, a);
                 else hipLaunchKernelGGL((k_fr_attn<OpT, 96, 31>), dim3((T + 31) / 32, c.n_heads, B), dim3(256), 0, st, a);
@@ -243,7 +248,7 @@ void front_forward_t(rvcmi_front* h, int B, int T, const float* phone, const lon
             if (i == 0) tap_copy(tr, "attn0", X, B, T, H, st);
             if (tr && tr->done) return;
         }
-        if (c.kernel_size <= 5 && !getenv("RVCMI_FR_NO_FFN_FUSION")) {
+        if (c.kernel_size <= 5 && !h->opt.on("FR_NO_FFN_FUSION")) {
             // FFN + residual + LayerNorm in one launch; reads X (with a halo) and writes the other stream buffer
             FrFfnArgs a = {};
             a.x = X; a.xo = X2; a.bstride = (long)T * H; a.T = T; a.len = lengths;
@@ -377,6 +382,7 @@ rvcmi_front* front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* wei
     WeightMap wm;
     for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
     std::unique_ptr<rvcmi_front> h(new rvcmi_front);
+    h->opt.load_env({"FR_NJ", "FR_NO_FFN_FUSION", "FR_STAMPS"});
     h->cfg = c;
     h->device = device;
     h->max_B = max_B;
@@ -554,6 +560,12 @@ int rvcmi_front_debug_forward(rvcmi_front* h, int B, int T, const float* phone, 
         tr.shape = shape_out;
         front_forward(h, B, T, phone, pitch, lengths, g, noise, flow_head, nullptr, (hipStream_t)stream, &tr);
         if (!tr.done) RVCMI_FAIL(RVCMI_ERR_INVALID, "tap '%s' was not produced", what);
+    });
+}
+int rvcmi_front_set_option(rvcmi_front* h, const char* key, double value) {
+    return guarded([&] {
+        if (!h || !key) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        h->opt.set(key, value);
     });
 }
 int rvcmi_front_profile_enable(rvcmi_front* h, int enable) {

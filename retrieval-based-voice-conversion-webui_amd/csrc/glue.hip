@@ -99,6 +99,17 @@ int rvcmi_glue_sola(const float* infer_wav, int64_t n, float* sola_buffer, int L
     });
 }
 
+int rvcmi_glue_resample_poly(const float* x, int64_t n, const float* kernel, int orig, int new_, int K, int width, float* out, int64_t n_out,
+                             void* stream) {
+    return guarded([&] {
+        if (!x || !kernel || !out || n < 1 || orig < 1 || new_ < 1 || K < 1 || width < 0 || n_out < 0) RVCMI_FAIL(RVCMI_ERR_INVALID, "resample: bad argument");
+        if (n_out == 0) return;
+        hipLaunchKernelGGL(k_resample_poly, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, kernel, orig, new_, K,
+                           width, out, n_out);
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
 int rvcmi_glue_change_rms(const float* data1, int64_t n1, int sr1, float* data2, int64_t n2, int sr2, float rate, float* scratch,
                           void* stream) {
     return guarded([&] {

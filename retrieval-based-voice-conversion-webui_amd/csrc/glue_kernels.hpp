@@ -362,4 +362,26 @@ static __global__ void __launch_bounds__(256) k_change_rms(float* __restrict__ d
     data2[t] = mul_rn(data2[t], mul_rn(powf(r1, e1), powf(r2, e2)));
 }
 
+// Polyphase FIR resampling as torchaudio.transforms.Resample applies it (rtrvc.py:248-259: the formant-shifted block comes out
+// of the generator at upp_res samples per 10 ms and is brought back to tgt_sr/100): out[j*nf + p] = sum_k w[p][k] * xpad[j*of + k],
+// xpad = x padded with `width` zeros in front (and zeros behind), k < K = 2*width + of.  One thread per output sample, fp32,
+// taps added in ascending k (torchaudio's F.conv1d leaves the order to the backend).  HBM/latency-bound: n_out * K MACs,
+// K ~ 430 for the 423 -> 400 ratio of a +1 semitone shift at 40 kHz; the 400 x 437 coefficient table stays in L2.
+static __global__ void __launch_bounds__(256) k_resample_poly(const float* __restrict__ x, int64_t n, const float* __restrict__ w, int of, int nf,
+                                                       int K, int width, float* __restrict__ out, int64_t n_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    const int64_t j = i / nf;
+    const int p = (int)(i - j * nf);
+    const float* wp = w + (size_t)p * K;
+    const int64_t base = j * of - width;  // index of tap 0 in the unpadded signal
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int64_t t = base + k;
+        const float xv = (t >= 0 && t < n) ? x[t] : 0.f;
+        acc = fmaf(wp[k], xv, acc);
+    }
+    out[i] = acc;
+}
+
 }  // namespace rvcmi

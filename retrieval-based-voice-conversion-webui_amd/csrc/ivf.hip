@@ -734,6 +734,10 @@ struct rvcmi_ivf {
     DevBuf assign, P, Dtmp, Itmp, flag, cdist, cscore;
     int64_t cap_chunk = 0;  // queries per coarse-score chunk (bounds the nq x nlist fp32 scratch)
     Profiler prof;
+    // dev / test options (common.hpp Options): IVF_COARSE_F64 (brute-force fp64 coarse quantizer), IVF_GENERIC (any-d scan kernel),
+    // IVF_STAMPS (prints; syncs), IVF_DBG.  Read from RVCMI_<KEY> once at handle creation; later only rvcmi_ivf_set_option.
+    rvcmi::Options opt;
+    rvcmi_ivf() { opt.load_env({"IVF_COARSE_F64", "IVF_GENERIC", "IVF_STAMPS", "IVF_DBG"}); }
     const float* centroids() const { return (const float*)(blob + hdr.off_centroids); }
     const float4* centroids_t() const { return (const float4*)(blob + hdr.off_centroids_t); }
     const float* cnorm() const { return (const float*)(blob + hdr.off_cnorm); }
@@ -1017,7 +1021,7 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
     const int np = (int)std::min<int64_t>(b.nprobe, b.nlist);
     HIP_CHECK(hipMemsetAsync(h->flag.p, 0, 4, st));
     const double cflops = 3.0 * (double)nq * b.nlist * d;
-    if (np == 1 && !getenv("RVCMI_IVF_COARSE_F64")) {
+    if (np == 1 && !h->opt.on("IVF_COARSE_F64")) {
         // fp32 MFMA prefilter + fp64 verification (exactly the fp64 argmin; see k_coarse_pick)
         h->prof.launch("ivf_coarse", 2.0 * (double)nq * b.nlist * d, (double)nq * d * 4 + (double)b.nlist * d * 4 + 2.0 * nq * b.nlist * 4, st, [&] {
             if (h->cap_chunk <= 0 || !h->cscore.p) RVCMI_FAIL(RVCMI_ERR_INVALID, "coarse score scratch not reserved");
@@ -1057,9 +1061,9 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
     const size_t smem = align_up((size_t)d * 4, 16) + SCAN_GROUPS * sizeof(TopK);
     h->prof.launch("ivf_scan", 3.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
         const size_t sm2 = SCAN_GROUPS * sizeof(TopK);
-        if (d == 768 && !getenv("RVCMI_IVF_GENERIC")) {
+        if (d == 768 && !h->opt.on("IVF_GENERIC")) {
             static unsigned long long* tsd = nullptr;
-            const bool want_ts = getenv("RVCMI_IVF_STAMPS") != nullptr;
+            const bool want_ts = h->opt.on("IVF_STAMPS");
             if (want_ts && !tsd) HIP_CHECK(hipMalloc(&tsd, 16 * 8));
             if (want_ts) HIP_CHECK(hipMemsetAsync(tsd, 0, 16 * 8, st));
             hipLaunchKernelGGL((k_scan_v<6, 32, 2>), dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
@@ -1075,7 +1079,7 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
             fused = bf != nullptr;
             return;
         }
-        if (d == 256 && !getenv("RVCMI_IVF_GENERIC")) {
+        if (d == 256 && !h->opt.on("IVF_GENERIC")) {
             hipLaunchKernelGGL((k_scan_v<4, 16, 2>), dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
                                h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(), bf ? bf->feats : nullptr,
                                bf ? bf->rate : 0.f, bf ? bf->omr : 0.f, h->hdr.pos_last);
@@ -1084,7 +1088,7 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
         }
         hipLaunchKernelGGL(k_scan, dim3((unsigned)nq), dim3(256), smem, st, q, h->assign.as<int64_t>(), np,
                            h->list_off(), h->ids(), h->vecs(), nq, d, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(),
-                           getenv("RVCMI_IVF_DBG") ? atoi(getenv("RVCMI_IVF_DBG")) : 0);
+                           h->opt.geti("IVF_DBG", 0));
     });
     HIP_CHECK(hipGetLastError());
     return fused;
@@ -1354,6 +1358,12 @@ int rvcmi_ivf_create_from_blob(void* dev_ptr, size_t bytes, int device, int take
         h->blob = (char*)dev_ptr;
         h->owns_blob = take_ownership != 0;
         *out = h.release();
+    });
+}
+int rvcmi_ivf_set_option(rvcmi_ivf* h, const char* key, double value) {
+    return guarded([&] {
+        if (!h || !key) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        h->opt.set(key, value);
     });
 }
 int rvcmi_ivf_profile_enable(rvcmi_ivf* h, int enable) {

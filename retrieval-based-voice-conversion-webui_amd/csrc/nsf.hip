@@ -78,6 +78,10 @@ struct rvcmi_nsf {
     DevBuf P, X0, Ya[RVCMI_MAX_RB], Yb[RVCMI_MAX_RB], H, NZ, har, har2, x2, phase, condv, dbg;
     size_t ws_bytes = 0;
     Profiler prof;
+    // dev / test options (common.hpp Options): RB_STREAM (absent = auto, 1 = streaming resblock kernels whenever supported, 0 = never),
+    // NO_RBFULL, RB_ORDER (1 = resblock-major pair launches), UPS_NJ, NB (weight-ring depth of k_rb_full), DBG (timing-ablation bit
+    // mask: results are WRONG when non-zero) and the rb_stream keys (rb_stream.hpp).  Read from RVCMI_<KEY> once, in rvcmi_nsf_create.
+    rvcmi::Options opt;
 };
 
 namespace rvcmi {
@@ -103,6 +107,8 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "RB_ORDER", "UPS_NJ", "NB", "DBG"});
+    rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
     h->max_B = max_B;
@@ -471,27 +477,26 @@ template <> struct RbFullGeom<64> { static constexpr int MI = 2, NJ = 3, KG = 4,
 template <> struct RbFullGeom<32> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC, NWV = RBF32_NWV; };
 template <> struct RbFullGeom<16> { static constexpr int MI = 1, NJ = RBF32_NJ, KG = 4, OCC = RBF32_OCC, NWV = RBF32_NWV; };
 static int rbf_rows(int C) { return C == 64 ? RbFullGeom<64>::NWV * 32 * RbFullGeom<64>::NJ : RBF32_NWV * 32 * RBF32_NJ; }
-static int rbf_nb(int dflt) {  // weight-prefetch depth (register buffers); RVCMI_NB overrides for A/B experiments
-    const char* e = getenv("RVCMI_NB");
-    const int v = e ? atoi(e) : dflt;
+static int rbf_nb(const Options& opt, int dflt) {  // weight-prefetch depth (register buffers); option NB overrides for A/B experiments
+    const int v = opt.geti("NB", dflt);
     return v < 2 ? 2 : (v > 4 ? 4 : v);
 }
 template <typename OpT, int C>
-static void launch_rbf_inst(const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
+static void launch_rbf_inst(const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st, const Options& opt) {
     using G = RbFullGeom<C>;
     constexpr int R = G::NWV * 32 * G::NJ;
     const size_t smem = (size_t)(R + 2 * RBF_G + R + 2 * RBF_G2) * Tile<C>::STRIDE + 3 * 2 * 32 * G::MI * 4 + 512;  // + bias vectors + dev phase stamps
-    const int nb = rbf_nb(G::NWV == 8 ? 2 : 3);  // the 8-wave geometry has 256 registers per wave: a 2-deep ring fits without spills
+    const int nb = rbf_nb(opt, G::NWV == 8 ? 2 : 3);  // the 8-wave geometry has 256 registers per wave: a 2-deep ring fits without spills
     if (nb == 2) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 2, G::OCC, G::NWV>), dim3(tiles, nj, B), dim3(64 * G::NWV), smem, st, ra);
     else if (nb == 3) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 3, G::OCC, G::NWV>), dim3(tiles, nj, B), dim3(64 * G::NWV), smem, st, ra);
     else hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 4, G::OCC, G::NWV>), dim3(tiles, nj, B), dim3(64 * G::NWV), smem, st, ra);
 }
 template <typename OpT>
-static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
+static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st, const Options& opt) {
     switch (C) {
-        case 64: return launch_rbf_inst<OpT, 64>(ra, tiles, nj, B, st);
-        case 32: return launch_rbf_inst<OpT, 32>(ra, tiles, nj, B, st);
-        case 16: return launch_rbf_inst<OpT, 16>(ra, tiles, nj, B, st);
+        case 64: return launch_rbf_inst<OpT, 64>(ra, tiles, nj, B, st, opt);
+        case 32: return launch_rbf_inst<OpT, 32>(ra, tiles, nj, B, st, opt);
+        case 16: return launch_rbf_inst<OpT, 16>(ra, tiles, nj, B, st, opt);
         default: RVCMI_FAIL(RVCMI_ERR_INVALID, "fused resblock: unsupported channel count %d", C);
     }
 }
@@ -507,16 +512,16 @@ static void set_lds_rbf() {
 }
 
 // Fill the common part of ConvArgs for `L` and launch it in the handle's operand mode.
-// RVCMI_RB_STREAM: unset = auto (streaming kernel when the strips are long enough), 1 = always when supported, 0 = never.
-static int rb_stream_mode() {
-    const char* e = getenv("RVCMI_RB_STREAM");
-    if (!e || !e[0]) return 2;
-    return e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2);
+// option RB_STREAM: absent = auto (streaming kernel when the strips are long enough), 1 = always when supported, 0 = never.
+static int rb_stream_mode(const rvcmi_nsf* h) {
+    if (!h->opt.has("RB_STREAM")) return 2;
+    const int v = h->opt.geti("RB_STREAM", 2);
+    return v == 0 ? 0 : (v == 1 ? 1 : 2);
 }
 
 // Whole resblocks of a stage on the streaming kernel (ND = 3).  Fills src[j] with the output streams on success.
 static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int L, int B, int nk, const float** src, hipStream_t st) {
-    const int mode = rb_stream_mode();
+    const int mode = rb_stream_mode(h);
     if (mode == 0 || op == RVCMI_OPERAND_F32 || nk > 3) return false;
     for (int j = 0; j < nk; ++j)
         if (s.rb[j].size() != 3) return false;
@@ -551,8 +556,8 @@ static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int 
     }
     char nm[48];
     snprintf(nm, sizeof(nm), "rb_stream_c%d", C);
-    if (!rb_stream_launch(op, C, 3, sd, nk, L, B, (long)L * C, mode == 1, st, true)) return false;
-    h->prof.launch(nm, flops, bytes, st, [&] { rb_stream_launch(op, C, 3, sd, nk, L, B, (long)L * C, mode == 1, st); });
+    if (!rb_stream_launch(op, C, 3, sd, nk, L, B, (long)L * C, mode == 1, st, h->opt, true)) return false;
+    h->prof.launch(nm, flops, bytes, st, [&] { rb_stream_launch(op, C, 3, sd, nk, L, B, (long)L * C, mode == 1, st, h->opt); });
     HIP_CHECK(hipGetLastError());
     for (int j = 0; j < nk; ++j) src[j] = h->Ya[j].as<float>();
     return true;
@@ -609,11 +614,8 @@ static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const 
     HIP_CHECK(hipGetLastError());
 }
 
-// RVCMI_DBG: timing-ablation bit mask forwarded to the kernels (results are WRONG when non-zero; bench/dev only).
-static int dbg_flags() {
-    const char* e = getenv("RVCMI_DBG");
-    return e ? atoi(e) : 0;
-}
+// option DBG: timing-ablation bit mask forwarded to the kernels (results are WRONG when non-zero; bench/dev only).
+static int dbg_flags(const rvcmi_nsf* h) { return h->opt.geti("DBG", 0); }
 
 static ConvArgs base_args() {
     ConvArgs a;
@@ -763,7 +765,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             const ConvLayer& U = s.up;
             UpsArgs ua;
             memset(&ua, 0, sizeof(ua));
-            ua.dbg = dbg_flags();
+            ua.dbg = dbg_flags(h);
             ua.in_a = y[0];
             ua.in_b = y[1];
             ua.in_c = y[2];
@@ -826,8 +828,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             const long blocks4 = (long)((Lin + 128 * (4 / wv) - 1) / (128 * (4 / wv))) * B;
             if (blocks4 < 2048 && s.cin >= 128) nj = s.cin >= 512 ? 2 : 1;
             else if (blocks4 < 2048 && s.cin == 64) nj = 2;  // (us at B = 1 after the staging fix: 84 / 75 / 89 for NJ 4 / 2 / 1)
-            if (const char* e = getenv("RVCMI_UPS_NJ")) {
-                const int v = atoi(e);
+            if (h->opt.has("UPS_NJ")) {
+                const int v = h->opt.geti("UPS_NJ", nj);
                 if (v == 1 || v == 2 || v == 4) nj = v;
             }
             const int TQ = 32 * nj * (4 / wv);
@@ -886,14 +888,14 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 }
         } else if (try_rb_stream_full(h, s, op, C, (int)L, B, nk, src, st)) {
             // streaming fused resblocks (rb_stream_kernels.hpp): persistent blocks walk strips of the time axis
-        } else if (C <= 64 && maxnd <= 3 && !getenv("RVCMI_NO_RBFULL")) {
+        } else if (C <= 64 && maxnd <= 3 && !h->opt.on("NO_RBFULL")) {
             // whole resblocks fused (x resident in registers): ONE launch for the stage   residuals.py:68-85
             snprintf(nm, sizeof(nm), "rb_full_c%d", C);
             RbFullArgs ra;
             memset(&ra, 0, sizeof(ra));
             ra.L = (int)L;
             ra.bstride = L * C;
-            ra.dbg = dbg_flags();
+            ra.dbg = dbg_flags(h);
             const int R = rbf_rows(C);
             int order[RVCMI_MAX_RB];
             for (int j = 0; j < nk; ++j) order[j] = j;
@@ -939,8 +941,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 ra.ts = h->dbg.as<unsigned long long>();
             }
             h->prof.launch(nm, flops, bytes, st, [&] {
-                if (op == RVCMI_OPERAND_BF16) launch_rbf_t<__bf16>(C, ra, max_tiles, nk, B, st);
-                else launch_rbf_t<_Float16>(C, ra, max_tiles, nk, B, st);
+                if (op == RVCMI_OPERAND_BF16) launch_rbf_t<__bf16>(C, ra, max_tiles, nk, B, st, h->opt);
+                else launch_rbf_t<_Float16>(C, ra, max_tiles, nk, B, st, h->opt);
             });
             HIP_CHECK(hipGetLastError());
             if (ra.dbg & 32) {  // dev only: per-phase cycle breakdown, averaged per resblock kernel size
@@ -967,9 +969,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             // Launch order.  Level-major (one launch = pair level m of all resblocks) maximises the grid; resblock-major
             // (one launch = one pair of ONE resblock, chains run back to back) keeps a chain's src+dst (2 x L*C*4 B) inside
             // the 256 MB Infinity Cache when L*C*4*6 does not fit -- chosen per stage by working-set size.
-            const char* ord = getenv("RVCMI_RB_ORDER");
             const double ws_level = 6.0 * (double)B * L * C * 4;
-            const bool jmajor = ord ? (ord[0] == 'j') : false;
+            const bool jmajor = h->opt.on("RB_ORDER");
             (void)ws_level;
             const size_t npass = jmajor ? (size_t)nk * maxnd : maxnd;
             for (size_t pass = 0; pass < npass; ++pass) {
@@ -979,7 +980,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 memset(&ra, 0, sizeof(ra));
                 ra.L = (int)L;
                 ra.bstride = L * C;
-                ra.dbg = dbg_flags();
+                ra.dbg = dbg_flags(h);
                 int nj = 0, max_tiles = 0, max_rows = 0;
                 double flops = 0, bytes = 0;
                 // heaviest kernel size first so that the long blocks are dispatched first
@@ -1025,7 +1026,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     ra.ts = h->dbg.as<unsigned long long>();
                 }
                 bool streamed = false;
-                if (rb_stream_mode() != 0 && rb_stream_supported(op, C, 1)) {
+                if (rb_stream_mode(h) != 0 && rb_stream_supported(op, C, 1)) {
                     RbStreamDesc sd[RVCMI_MAX_RB];
                     for (int q = 0; q < nj; ++q) {
                         const RbJob& J = ra.job[q];
@@ -1035,9 +1036,9 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     }
                     char nms[48];
                     snprintf(nms, sizeof(nms), "rb_stream1_c%d", C);
-                    const bool force = rb_stream_mode() == 1;
-                    if (rb_stream_launch(op, C, 1, sd, nj, (int)L, B, L * C, force, st, true))
-                        h->prof.launch(nms, flops, bytes, st, [&] { streamed = rb_stream_launch(op, C, 1, sd, nj, (int)L, B, L * C, force, st); });
+                    const bool force = rb_stream_mode(h) == 1;
+                    if (rb_stream_launch(op, C, 1, sd, nj, (int)L, B, L * C, force, st, h->opt, true))
+                        h->prof.launch(nms, flops, bytes, st, [&] { streamed = rb_stream_launch(op, C, 1, sd, nj, (int)L, B, L * C, force, st, h->opt); });
                 }
                 if (!streamed) h->prof.launch(nm, flops, bytes, st, [&] { launch_rb_pair(op, C, ra, max_tiles, nj, B, max_rows, st); });
                 if ((ra.dbg & 32) && m == 0) {  // dev only: per-phase cycles of pair level 0, per kernel size
@@ -1122,6 +1123,12 @@ int rvcmi_nsf_debug_forward(rvcmi_nsf* h, int B, int T, const float* x, const fl
     });
 }
 
+int rvcmi_nsf_set_option(rvcmi_nsf* h, const char* key, double value) {
+    return guarded([&] {
+        if (!h || !key) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        h->opt.set(key, value);
+    });
+}
 int rvcmi_nsf_profile_enable(rvcmi_nsf* h, int enable) {
     return guarded([&] {
         if (!h) RVCMI_FAIL(RVCMI_ERR_INVALID, "null handle");

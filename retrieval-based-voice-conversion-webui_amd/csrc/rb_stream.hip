@@ -25,32 +25,13 @@ struct Geo {
     double c0;             // planning: a block's time is steps x (k + c0) units
 };
 // k_rb_stream2 (two blocks per CU): every strip pays the same warm-up rows but a step is half as long, so it needs LONG strips
-// to win.  RVCMI_RS_V2 (dev, read once): unset / "auto" = from `RVCMI_RS_V2_STEPS` steps per block on (default
-// 24: large batches), "1" = whenever supported, "0" = never.
-int v2_mode() {
-    static const int v = []() { const char* e = getenv("RVCMI_RS_V2"); return !e ? 2 : (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : 2)); }();
-    return v;
-}
-int v2_min_steps() {
-    static const int v = []() { const char* e = getenv("RVCMI_RS_V2_STEPS"); return e ? atoi(e) : 24; }();
-    return v;
-}
-double plan_c0(double dflt) {
-    static const double v = []() { const char* e = getenv("RVCMI_RS_C0"); return e ? atof(e) : -1.0; }();
-    return v >= 0 ? v : dflt;
-}
-// Time tiles per wave: 6 (R = 192 rows per step) for the one-tile-of-channels waves, 3 (R = 96) for C = 256: everything
-// stays in registers.  The larger alternatives 8 / 4 spill 100-400 registers per step (outside the K loops) and measured
-// slower (C = 128: 0.88 vs 0.76 ms per clip); RVCMI_RS_SMALL=0 selects them for A/B runs.
-bool small_tiles() {
-    const char* e = getenv("RVCMI_RS_SMALL");
-    return !(e && e[0] == '0');
-}
-bool geo_for(int C, int nd, Geo& g, int ver = 1) {
-    const bool sm = small_tiles();
+// to win.  Measured (r3g): B = 1 0.82 vs 0.72 ms, B = 16 0.640 vs 0.623, B = 64 0.606 vs 0.628 ms per clip -- it only
+// pays at B = 64.  Option RS_V2: 0 (default) = never, 1 = whenever supported, 2 = from RS_V2_STEPS (default 150) steps per block on.
+bool geo_for(int C, int nd, Geo& g, const Options& opt, int ver = 1) {
+    const bool sm = opt.geti("RS_SMALL", 1) != 0;
     if (C == 256 && nd == 1) { g = {2, sm ? 3 : 4, 4, 1, 1, 4.4}; return true; }
     // k_rb_stream2: measured cycles per pair-step 46.2k / 32.9k / 20.0k for k = 11 / 7 / 3 => time ~ steps x (k + 3.1)
-    if (C == 128 && nd == 3 && ver == 2) { g = {1, 3, 4, 2, 2, plan_c0(3.1)}; return true; }
+    if (C == 128 && nd == 3 && ver == 2) { g = {1, 3, 4, 2, 2, opt.get("RS_C0", 3.1)}; return true; }
     if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1, 1, 4.4}; return true; }
     // (C = 128 pair by pair with TWO blocks per CU -- NJ = 4, 225 registers, 0 spills -- was measured: both waves of a SIMD sit in
     //  their K loops at the same time (72 cycles per MFMA per wave), the phases overlap no better than in the one-wave design
@@ -146,27 +127,28 @@ void rb_stream_prepare() {
 
 bool rb_stream_supported(int operand, int C, int nd) {
     Geo g;
-    return operand != RVCMI_OPERAND_F32 && geo_for(C, nd, g);
+    return operand != RVCMI_OPERAND_F32 && geo_for(C, nd, g, Options());
 }
 
 static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B,
-                       long bstride, hipStream_t st, bool dry_run);
+                       long bstride, hipStream_t st, const Options& opt, bool dry_run);
 
 bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B, long bstride, bool force,
-                      hipStream_t st, bool dry_run) {
+                      hipStream_t st, const Options& opt, bool dry_run) {
     Geo g;
     if (operand == RVCMI_OPERAND_F32 || njobs < 1 || njobs > 3) return false;
-    if (v2_mode() && geo_for(C, nd, g, 2) && g.ver == 2 &&
-        launch_geo(g, v2_mode() == 1 ? (force ? 0 : 4) : v2_min_steps(), operand, C, nd, jobs, njobs, L, B, bstride, st, dry_run))
+    const int v2 = opt.geti("RS_V2", 0);
+    if (v2 && geo_for(C, nd, g, opt, 2) && g.ver == 2 &&
+        launch_geo(g, v2 == 1 ? (force ? 0 : 4) : opt.geti("RS_V2_STEPS", 150), operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
         return true;
-    if (!geo_for(C, nd, g)) return false;
+    if (!geo_for(C, nd, g, opt)) return false;
     // auto mode: only where the persistent walk measured faster than the tile kernels -- C = 128 (whole resblocks) from 4 steps
     // per block; C = 256 (pair level) only with long strips (large batches).
-    return launch_geo(g, force ? 0 : (C == 128 ? 4 : 8), operand, C, nd, jobs, njobs, L, B, bstride, st, dry_run);
+    return launch_geo(g, force ? 0 : (C == 128 ? 4 : 8), operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run);
 }
 
 static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B,
-                       long bstride, hipStream_t st, bool dry_run) {
+                       long bstride, hipStream_t st, const Options& opt, bool dry_run) {
     const int R = 32 * g.NJ;
     RbStreamArgs a;
     memset(&a, 0, sizeof(a));
@@ -280,11 +262,9 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
         min_steps = std::min(min_steps, steps);
     }
     a.side_rows = side_rows;
-    if (g.ver == 2) {  // dev knobs (read once): RVCMI_RS_SKEW = units of 1024 cycles per (k + 3), RVCMI_RS_PRIO = 1
-        static const int skew = []() { const char* e = getenv("RVCMI_RS_SKEW"); return e ? atoi(e) : 2; }();
-        static const int prio = []() { const char* e = getenv("RVCMI_RS_PRIO"); return e ? atoi(e) : 0; }();
-        a.skew = skew;
-        a.flags = prio & 1;
+    if (g.ver == 2) {  // RS_SKEW = units of 1024 cycles per (k + 3), RS_PRIO = 1: s_setprio inside the K loops
+        a.skew = opt.geti("RS_SKEW", 2);
+        a.flags = opt.geti("RS_PRIO", 0) & 1;
     }
     if (min_steps < min_steps_required) return false;
     const size_t smem = g.ver == 2 ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
@@ -292,8 +272,8 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
     if (smem > (size_t)160 * 1024 / g.bpc)
         RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large for %d block(s) per CU (C=%d)", smem, g.bpc, C);
     if (dry_run) return true;
-    // dev only: RVCMI_RS_STAMPS=1 prints the per-phase cycle breakdown of every launch (synchronises; never set it in a timed run)
-    static const bool want_stamps = getenv("RVCMI_RS_STAMPS") && getenv("RVCMI_RS_STAMPS")[0] == '1';
+    // dev only: option RS_STAMPS prints the per-phase cycle breakdown of every launch (synchronises; never set it in a timed run)
+    const bool want_stamps = opt.on("RS_STAMPS");
     unsigned long long* ts = nullptr;
     const size_t nts = (size_t)nblocks * B * g.NCO * 16;
     if (want_stamps) {

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "common.hpp"
+
 namespace rvcmi {
 
 struct RbStreamDesc {  // one resblock (ND = 3: all its pairs) or one pair level of it (ND = 1)
@@ -22,10 +24,15 @@ int num_cus();
 void rb_stream_prepare();
 // Channel counts / fusion depths the kernel is instantiated for.
 bool rb_stream_supported(int operand, int C, int nd);
+// Option keys read from `opt` (dev / tests): RS_SMALL (0 = the larger time tiles), RS_V2 (0 never / 1 whenever supported /
+// 2 by strip length from RS_V2_STEPS on), RS_C0 (planning constant), RS_SKEW, RS_PRIO, RS_STAMPS (print phase stamps; syncs).
+inline void rb_stream_load_env(Options& opt) {
+    opt.load_env({"RS_SMALL", "RS_V2", "RS_V2_STEPS", "RS_C0", "RS_SKEW", "RS_PRIO", "RS_STAMPS"});
+}
 // Plans strips for `B` utterances of `L` rows and launches ONE kernel covering all `njobs` resblocks.  Returns false
 // (nothing launched) when the strips would be too short for the persistent walk to pay and `force` is not set.
 // `dry_run`: plan only (same return value), launch nothing.
 bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B, long bstride, bool force,
-                      hipStream_t st, bool dry_run = false);
+                      hipStream_t st, const Options& opt, bool dry_run = false);
 
 }  // namespace rvcmi

@@ -83,6 +83,8 @@ class FrontHIP(torch.nn.Module):
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(_lib.lib().rvcmi_front_create(C.byref(cs), arr, len(names), idx, B, T, C.byref(h)))
         self._handle, self._max_B, self._max_T = h, B, T
+        for k, v in getattr(self, "_options", {}).items():
+            _lib.set_option(_lib.lib().rvcmi_front_set_option, self._handle, k, v)
 
     def _destroy(self) -> None:
         if getattr(self, "_handle", None):
@@ -157,6 +159,16 @@ class FrontHIP(torch.nn.Module):
     def debug_tap(self, what: str, phone, pitch, lengths, g, flow_head: int = 0, noise=None) -> torch.Tensor:
         """Internal stage, channels-last [B, T', 192] on the host (see rvcmi_front_debug_forward)."""
         return self._run(phone, pitch, lengths, g, noise, flow_head, tap=what)
+
+    def set_option(self, key: str, value=None) -> None:
+        """Dev / test option of this handle (``rvcmi_front_set_option``: ``FR_NJ``, ``FR_NO_FFN_FUSION``); ``None`` = default."""
+        if not hasattr(self, "_options"):
+            self._options = {}
+        if value is None:
+            self._options.pop(key, None)
+        else:
+            self._options[key] = value
+        _lib.set_option(_lib.lib().rvcmi_front_set_option, self._handle, key, value)
 
     def profile(self, enable: bool) -> None:
         _lib.check(_lib.lib().rvcmi_front_profile_enable(self._handle, 1 if enable else 0))

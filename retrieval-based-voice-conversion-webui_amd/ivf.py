@@ -171,6 +171,10 @@ class IVFFlatHIP:
                                                          float(index_rate), int(k), 1 if skip_if_short else 0, C.c_void_p(st)))
         return feats
 
+    def set_option(self, key: str, value=None) -> None:
+        """Dev / test option of this index (``rvcmi_ivf_set_option``: ``IVF_COARSE_F64``, ``IVF_GENERIC``); ``None`` = default."""
+        _lib.set_option(_lib.lib().rvcmi_ivf_set_option, self._h, key, value)
+
     def profile(self, enable: bool) -> None:
         _lib.check(_lib.lib().rvcmi_ivf_profile_enable(self._h, 1 if enable else 0))
 

@@ -109,6 +109,19 @@ class _HipGenerator(torch.nn.Module):
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(_lib.lib().rvcmi_nsf_create(C.byref(cs), arr, len(names), idx, B, T, C.byref(h)))
         self._handle, self._max_B, self._max_T = h, B, T
+        for k, v in getattr(self, "_options", {}).items():  # options survive a workspace re-creation
+            _lib.set_option(_lib.lib().rvcmi_nsf_set_option, self._handle, k, v)
+
+    def set_option(self, key: str, value=None) -> None:
+        """Dev / test option of this handle (``rvcmi_nsf_set_option``: e.g. ``RB_STREAM`` 0 / 1 pins the ResBlock kernel family,
+        ``RS_SMALL``, ``DBG``); ``None`` restores the default.  The library reads ``RVCMI_<KEY>`` only when a handle is created."""
+        if not hasattr(self, "_options"):
+            self._options = {}
+        if value is None:
+            self._options.pop(key, None)
+        else:
+            self._options[key] = value
+        _lib.set_option(_lib.lib().rvcmi_nsf_set_option, self._handle, key, value)
 
     def _destroy(self) -> None:
         if getattr(self, "_handle", None):

@@ -6,8 +6,9 @@ extractor (rtrvc.py:163-251): retrieval on the new frames only, pitch caches, x2
     rt = RealtimeVC(net_g, index=rvc_amd.read_index(path), index_rate=0.75, device="cuda:0")
     wav = rt.infer(hubert_feats, n_input_samples, block_frame_16k, skip_head, return_length, pitch=p, pitchf=pf)
 
-HuBERT, the f0 estimators and the optional formant resample (``torchaudio.transforms.Resample``, rtrvc.py:249-259) stay
-PyTorch, as in the reference.
+HuBERT and the f0 estimators stay PyTorch, as in the reference; the optional formant resample
+(``torchaudio.transforms.Resample``, rtrvc.py:249-259) is ``SincResample`` below: the same windowed-sinc polyphase filter on a
+HIP kernel (torchaudio is not installable offline: its published formula is restated, parity unpinned).
 """
 from __future__ import annotations
 
@@ -16,7 +17,7 @@ from typing import Optional
 
 import torch
 
-from . import glue
+from . import _lib, glue
 
 
 def f0_extractor_frame(block_frame_16k: int, method: str = "fcpe", window: int = 160) -> int:
@@ -25,6 +26,57 @@ def f0_extractor_frame(block_frame_16k: int, method: str = "fcpe", window: int =
     if method == "rmvpe":
         n = 5120 * ((n - 1) // 5120 + 1) - window
     return n
+
+
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """The filter bank of ``torchaudio.transforms.Resample(orig_freq, new_freq, dtype=torch.float32)`` (its defaults:
+    ``sinc_interp_hann``, ``lowpass_filter_width`` 6, ``rolloff`` 0.99), restated from torchaudio's published
+    ``functional._get_sinc_resample_kernel``: frequencies reduced by their gcd, ``base = min(orig, new) * rolloff``,
+    ``width = ceil(lpw * orig / base)``, taps ``t = (-k/new + i/orig) * base`` for ``i`` in ``[-width, width + orig)`` clamped to
+    ``+-lpw``, hann window ``cos(t * pi / lpw / 2)^2``, ``sinc(t * pi) * window * base / orig``; evaluated in float32 like
+    torchaudio does for ``dtype=float32``.  -> (kernel [new, 2*width + orig] float32 CPU tensor, width, orig, new)."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    of, nf = int(orig_freq) // g, int(new_freq) // g
+    base = min(of, nf) * rolloff
+    width = int(math.ceil(lowpass_filter_width * of / base))
+    idx = torch.arange(-width, width + of, dtype=torch.float32)[None, :] / of
+    t = torch.arange(0, -nf, -1, dtype=torch.float32)[:, None] / nf + idx
+    t = t * base
+    t = t.clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kern = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / of)
+    return kern.contiguous(), width, of, nf
+
+
+class SincResample:
+    """``torchaudio.transforms.Resample(orig_freq, new_freq, dtype=torch.float32).to(device)`` as the realtime path uses it
+    (rtrvc.py:251-259): call with a [1, n] or [n] float32 CUDA tensor, get ``ceil(new * n / orig)`` samples back."""
+
+    def __init__(self, orig_freq: int, new_freq: int, device):
+        k, self.width, self.orig, self.new = sinc_resample_kernel(orig_freq, new_freq)
+        self.device = torch.device(device)
+        self.kernel = k.to(self.device)
+
+    def __call__(self, wav: torch.Tensor) -> torch.Tensor:
+        if wav.device.type != "cuda":
+            raise _lib.RvcmiError("SincResample input must live on the GPU (no CPU fallback)")
+        shape = wav.shape
+        x = wav.reshape(-1, shape[-1]).to(torch.float32).contiguous()
+        if self.orig == self.new:
+            return wav
+        n = int(x.shape[1])
+        n_out = -(-self.new * n // self.orig)
+        out = torch.empty(x.shape[0], n_out, device=x.device, dtype=torch.float32)
+        import ctypes as C
+
+        with torch.cuda.device(x.device):
+            st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+            for r in range(x.shape[0]):
+                _lib.check(_lib.lib().rvcmi_glue_resample_poly(C.c_void_p(x[r].data_ptr()), n, C.c_void_p(self.kernel.data_ptr()), self.orig,
+                                                               self.new, int(self.kernel.shape[1]), self.width, C.c_void_p(out[r].data_ptr()),
+                                                               n_out, st))
+        return out.reshape(shape[:-1] + (n_out,))
 
 
 class PitchCache:
@@ -109,13 +161,9 @@ class RealtimeVC:
         audio = audio.squeeze(1).float()
         upp_res = int(math.floor(factor * self.tgt_sr // 100))                            # :248
         if upp_res != self.tgt_sr // 100:                                                 # :249-259 (formant shift only)
-            try:
-                from torchaudio.transforms import Resample
-            except ImportError as e:  # pragma: no cover - torchaudio is part of every RVC install
-                raise RuntimeError("formant_shift != 0 needs torchaudio's Resample, as in rtrvc.py:251") from e
             if upp_res not in self._resample:
-                self._resample[upp_res] = Resample(orig_freq=upp_res, new_freq=self.tgt_sr // 100, dtype=torch.float32).to(self.device)
-            audio = self._resample[upp_res](audio[:, : return_length * upp_res])
+                self._resample[upp_res] = SincResample(upp_res, self.tgt_sr // 100, self.device)
+            audio = self._resample[upp_res](audio[:, : return_length * upp_res].contiguous())
         return audio.squeeze()
 
 

@@ -336,3 +336,31 @@ def test_front_oracle_matches_the_reference_modules_at_benchmark_size():
     with torch.no_grad():
         z, m1, _ = front_oracle.infer_front(fcfg, wf, phone, pitch, torch.tensor([T]), torch.from_numpy(d["sid"]), noise)
     assert np.abs((z * m1).numpy() - d["z"]).max() < 5e-5
+
+
+def test_sinc_resample_oracle_against_scipy_and_the_product_table():
+    """The formant-shift resampler's oracle (torchaudio's published windowed-sinc formula; UNPINNED: torchaudio is absent) is a
+    sane band-limited resampler -- within 1e-3 of scipy's polyphase filter on a band-limited signal -- and the product's
+    filter table (rvc_amd.sinc_resample_kernel, torch float32) is the table the oracle builds in numpy float32."""
+    from scipy import signal
+
+    import rvc_amd
+
+    n = 4230 * 3
+    t = np.arange(n) / 42300.0
+    x = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.2 * np.sin(2 * np.pi * 3000 * t + 1)).astype(np.float32)
+    y = glue_oracle.sinc_resample(x, 423, 400)
+    y2 = signal.resample_poly(x.astype(np.float64), 400, 423)
+    assert y.shape == y2.shape == (12000,)
+    assert np.sqrt(np.mean((y[200:-200] - y2[200:-200]) ** 2)) / np.sqrt(np.mean(y2 ** 2)) < 1e-3
+    k, width, of, nf = rvc_amd.sinc_resample_kernel(538, 480)
+    assert (width, of, nf) == (7, 269, 240) and tuple(k.shape) == (240, 2 * 7 + 269)
+    imp = np.zeros(269 * 4, np.float32)
+    imp[300] = 1.0  # the response to a unit impulse reads the table back: out[j*nf + p] = kernel[p][300 + width - j*of]
+    r = glue_oracle.sinc_resample(imp, 538, 480)
+    kk = k.numpy()
+    for j in range(2):
+        for p in (0, 7, 239):
+            tap = 300 + width - j * of
+            if 0 <= tap < kk.shape[1]:
+                assert abs(r[j * nf + p] - kk[p, tap]) <= 1e-6

@@ -29,8 +29,16 @@ def hip_gen(cfg, w, operand, gpu):
     return _gens[key]
 
 
-def run_golden(d, cfg, w, operand, gpu):
-    gen = hip_gen(cfg, w, operand, gpu)
+def pin(gen, **opts):
+    """Test options of ONE handle (rvcmi_nsf_set_option): e.g. RB_STREAM=1 forces the streaming ResBlock kernels, RS_SMALL picks
+    their tile height; None restores the launcher's own choice."""
+    for k, v in opts.items():
+        gen.set_option(k, v)
+    return gen
+
+
+def run_golden(d, cfg, w, operand, gpu, **opts):
+    gen = pin(hip_gen(cfg, w, operand, gpu), RB_STREAM=opts.get("RB_STREAM"), RS_SMALL=opts.get("RS_SMALL"))
     z = torch.from_numpy(d["z"]).to(gpu)
     g = torch.from_numpy(d["g"]).to(gpu)
     n_res = None if int(d.get("n_res", -1)) < 0 else int(d["n_res"])
@@ -150,8 +158,8 @@ def test_handle_rejects_bad_shapes_and_grows_its_workspace(gpu):
 
 
 @pytest.mark.parametrize("rb_stream", ["0", "1"])
-def test_full_clip_size_properties(rb_stream, gpu, monkeypatch):
-    """(Both ResBlock kernel families: RVCMI_RB_STREAM=0 the tile kernels, =1 the streaming kernel; a fixed choice, because
+def test_full_clip_size_properties(rb_stream, gpu):
+    """(Both ResBlock kernel families: option RB_STREAM=0 the tile kernels, =1 the streaming kernel; a fixed choice, because
     the launcher otherwise picks per clip length and the two families differ in the last fp32 bit of the residual add.)
     BASELINE size (v2/48k, T = 1198 frames = one 10 s clip): determinism, batch independence and locality.
     Locality is the size-independent property of a conv stack: the waveform of frames [a, b) computed from the
@@ -159,14 +167,13 @@ def test_full_clip_size_properties(rb_stream, gpu, monkeypatch):
     tile boundaries, phase offsets and grid sizes -- so it exercises every halo / tiling decision at full scale."""
     import rvc_amd
 
-    monkeypatch.setenv("RVCMI_RB_STREAM", rb_stream)
     cfg = nsf_oracle.CONFIGS["v2_48k"]
     w = synth.make_dec_weights(cfg, 1234)
     T = 1198
     z, f0, g = synth.make_dec_inputs(cfg, 1, T, 1234)
     f0 = torch.zeros_like(f0)  # unvoiced everywhere: the harmonic phase carries no history, so locality is exact
     noise = nsf_oracle.reference_noise(1, T, cfg.upp, 114514)
-    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=2, max_T=T)
+    gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=2, max_T=T), RB_STREAM=int(rb_stream))
     zd, fd, gd, nd = z.to(gpu), f0.to(gpu), g.to(gpu), noise.to(gpu)
     full = gen(zd, fd, gd, noise=nd)
     assert torch.isfinite(full).all() and full.shape == (1, 1, T * cfg.upp)
@@ -257,15 +264,13 @@ def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
 
 
 @pytest.mark.parametrize("rb_stream", ["0", "1"])
-def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu, monkeypatch):
+def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu):
     """BASELINE configs[2] geometry (grid.z = batch, multi-GB streams, the large-batch launch shapes): 16 different full-size
     voiced clips in one call; every item must be BIT-equal to the same clip run alone -- with the ResBlock kernel family
     pinned (tile kernels / streaming kernel, whose strip partition changes completely between B = 16 and B = 1) -- and item
     0 must meet the parity bar against the reference golden.  Unpinned (the launcher's own choice) the two runs may pick
     different families per stage and agree to fp32 rounding instead."""
     import rvc_amd
-
-    monkeypatch.setenv("RVCMI_RB_STREAM", rb_stream)
 
     cfg = nsf_oracle.CONFIGS["v2_48k"]
     w = synth.make_dec_weights(cfg, 1234)
@@ -276,7 +281,7 @@ def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu, mon
         zs.append(z), fs.append(torch.roll(f0, 37 * b, dims=1)), gs.append(g)
         ns.append(nsf_oracle.reference_noise(1, T, cfg.upp, 114514 + b))
     Z, F, G, N = torch.cat(zs).to(gpu), torch.cat(fs).to(gpu), torch.cat(gs).to(gpu), torch.cat(ns).to(gpu)
-    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T)
+    gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T), RB_STREAM=int(rb_stream))
     out = gen(Z, F, G, noise=N)
     assert out.shape == (B, 1, T * cfg.upp) and torch.isfinite(out).all()
     d = load_golden("full_v2_48k_T1198_voiced")
@@ -284,12 +289,12 @@ def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu, mon
     for b in (0, 1, 7, 15):
         one = gen(Z[b:b + 1].contiguous(), F[b:b + 1].contiguous(), G[b:b + 1].contiguous(), noise=N[b:b + 1].contiguous())
         assert torch.equal(one[0], out[b]), "batch item %d differs from its single-clip result" % b
-    monkeypatch.delenv("RVCMI_RB_STREAM")
+    pin(gen, RB_STREAM=None)
     auto = gen(Z, F, G, noise=N)
     assert rms(auto.cpu(), out.cpu()) <= 5e-4  # different families: last-bit fp32 differences re-round some fp16 operands
 
 
-def test_batch_64_bench_config_3_geometry(gpu, monkeypatch):
+def test_batch_64_bench_config_3_geometry(gpu):
     """BASELINE configs[2] exactly: 64 full-size voiced clips in one call (35 GB workspace, 4.7 GB stage-3 streams: element
     offsets beyond 2^32 bytes, grid of 64 utterances).  First and last items (the ones at the ends of the address range) and
     one in the middle are bit-equal to their single-clip results with the kernel family pinned; item 0 meets the parity bar
@@ -299,7 +304,6 @@ def test_batch_64_bench_config_3_geometry(gpu, monkeypatch):
     free, _ = torch.cuda.mem_get_info(gpu)
     if free < 60 * 2**30:
         pytest.skip("needs ~40 GB of free HBM")
-    monkeypatch.setenv("RVCMI_RB_STREAM", "1")
     cfg = nsf_oracle.CONFIGS["v2_48k"]
     w = synth.make_dec_weights(cfg, 1234)
     B, T = 64, 1198
@@ -309,7 +313,7 @@ def test_batch_64_bench_config_3_geometry(gpu, monkeypatch):
         zs.append(z), fs.append(torch.roll(f0, 17 * b, dims=1)), gs.append(g)
         ns.append(nsf_oracle.reference_noise(1, T, cfg.upp, 114514 + b))
     Z, F, G, N = torch.cat(zs).to(gpu), torch.cat(fs).to(gpu), torch.cat(gs).to(gpu), torch.cat(ns).to(gpu)
-    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T)
+    gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T), RB_STREAM=1)
     out = gen(Z, F, G, noise=N)
     assert out.shape == (B, 1, T * cfg.upp) and torch.isfinite(out).all()
     d = load_golden("full_v2_48k_T1198_voiced")
@@ -317,39 +321,38 @@ def test_batch_64_bench_config_3_geometry(gpu, monkeypatch):
     for b in (0, 41, 63):
         one = gen(Z[b:b + 1].contiguous(), F[b:b + 1].contiguous(), G[b:b + 1].contiguous(), noise=N[b:b + 1].contiguous())
         assert torch.equal(one[0], out[b]), "batch item %d differs from its single-clip result" % b
-    monkeypatch.delenv("RVCMI_RB_STREAM")
+    pin(gen, RB_STREAM=None)
     auto = gen(Z, F, G, noise=N)
     assert rms(auto.cpu(), out.cpu()) <= 5e-4
 
 
 # ---- streaming fused ResBlock kernel (csrc/rb_stream_kernels.hpp) -------------------------------------------------------
-# At full clip size the launcher picks it by itself (the full-size tests above run it); RVCMI_RB_STREAM=1 forces it for
-# the small golden cases too (single short strips, sequence ends inside the first step), RVCMI_RS_SMALL=1 selects the
-# smaller time tiles.
+# At full clip size the launcher picks it by itself (the full-size tests above run it); option RB_STREAM=1 forces it for
+# the small golden cases too (single short strips, sequence ends inside the first step), RS_SMALL selects the time-tile
+# height, RS_V2=1 the two-blocks-per-CU variant k_rb_stream2 (csrc/rb_stream2_kernels.hpp).
 
-@pytest.mark.parametrize("small", ["0", "1"])
+@pytest.mark.parametrize("small", ["0", "1", "v2"])
 @pytest.mark.parametrize("name", ["dec_v2_48k_B1_T70", "dec_v2_48k_B2_T24", "dec_v1_40k_B1_T20", "dec_v1_32k_B1_T16",
                                   "dec_nof0_v2_48k_B1_T16", "dec_v1_40k_nres_T31"])
-def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu, monkeypatch):
-    monkeypatch.setenv("RVCMI_RB_STREAM", "1")
-    monkeypatch.setenv("RVCMI_RS_SMALL", small)
+def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu):
     d = load_golden(name)
     cfg, w = golden_config_and_weights(d)
     for operand in ("fp16", "bf16"):
-        out = run_golden(d, cfg, w, operand, gpu)
+        gen = hip_gen(cfg, w, operand, gpu)
+        gen.set_option("RS_V2", 1 if small == "v2" else None)
+        out = run_golden(d, cfg, w, operand, gpu, RB_STREAM=1, RS_SMALL=None if small == "v2" else int(small))
+        gen.set_option("RS_V2", None)
         assert torch.isfinite(out).all()
         e = rms(out, d["out"])
         assert e <= BAR[operand], "%s/%s (streaming resblocks): RMS error %.3e" % (name, operand, e)
 
 
-@pytest.mark.parametrize("small", ["0", "1"])
-def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu, monkeypatch):
+@pytest.mark.parametrize("small", ["0", "1", "v2"])
+def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu):
     """Forced onto a clip of 300 frames: hundreds of strips of one to three steps each (every strip boundary, warm-up
     and tail case), batch of 2 with different inputs; per-stage taps and the waveform against the oracle."""
     import rvc_amd
 
-    monkeypatch.setenv("RVCMI_RB_STREAM", "1")
-    monkeypatch.setenv("RVCMI_RS_SMALL", small)
     cfg = nsf_oracle.CONFIGS["v2_48k"]
     w = synth.make_dec_weights(cfg, 31)
     B, T = 2, 300
@@ -358,7 +361,8 @@ def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu, monkey
     taps = {}
     with torch.no_grad():
         ref = nsf_oracle.generator_forward(cfg, w, z, f0, g, noise, taps=taps)
-    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T)
+    gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T), RB_STREAM=1,
+              RS_SMALL=None if small == "v2" else int(small), RS_V2=1 if small == "v2" else None)
     zd, fd, gd, nd = z.to(gpu), f0.to(gpu), g.to(gpu), noise.to(gpu)
     out = gen(zd, fd, gd, noise=nd).cpu()
     assert rms(out, ref) <= 1e-3, "streaming resblocks, T=300 B=2: %.3e" % rms(out, ref)
@@ -367,6 +371,6 @@ def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu, monkey
         exp = taps[k] * cfg.num_kernels
         rel = rms(got, exp) / float(exp.pow(2).mean().sqrt())
         assert rel <= 2e-3, "%s: relative RMS %.2e" % (k, rel)
-    monkeypatch.setenv("RVCMI_RB_STREAM", "0")  # and the tile kernels on the same input agree with it to operand rounding
+    pin(gen, RB_STREAM=0)  # and the tile kernels on the same input agree with it to operand rounding
     out0 = gen(zd, fd, gd, noise=nd).cpu()
     assert rms(out0, ref) <= 1e-3 and rms(out0, out) <= 5e-4

@@ -131,7 +131,8 @@ def test_realtime_vc_block_loop(gpu):
         def infer(self, phone, lengths, sid, pitch=None, pitchf=None, skip_head=None, return_length=None, return_length2=None):
             seen.update(phone=phone.cpu(), lengths=lengths.cpu(), pitch=pitch.cpu(), pitchf=pitchf.cpu(), skip_head=skip_head,
                         return_length=return_length, return_length2=return_length2)
-            return torch.zeros(1, 1, return_length * 480, device=phone.device)
+            n = (return_length2 or return_length) * 480
+            return (0.4 * torch.sin(torch.arange(n, device=phone.device, dtype=torch.float32) * 0.013)).reshape(1, 1, n)
 
     rt = rvc_amd.RealtimeVC(Net(), index=hip, index_rate=0.75, device=gpu, tgt_sr=48000)
     n_samples, block16k, skip_head, ret_len = 160 * 118, 4000, 40, 25
@@ -162,11 +163,15 @@ def test_realtime_vc_block_loop(gpu):
         ref = glue_oracle.expand_protect(blended, f2, pitchf[None], 0.33, p_len)
         assert seen["phone"].shape == ref.shape, (seen["phone"].shape, ref.shape)
         assert (seen["phone"] - ref).abs().max() <= 2e-6, "phone: max abs diff %.3e" % (seen["phone"] - ref).abs().max()
-    rt.set_formant(2.0)  # rtrvc.py:190-191, 218-219: the decoder is asked for ceil(return_length * 2^(2/12)) frames
-    try:
-        rt.infer(feats.to(gpu), n_samples, block16k, skip_head, ret_len, pitch=pitch.to(gpu), pitchf=pitchf.to(gpu))
-    except RuntimeError as e:  # torchaudio (the reference's own resampler, rtrvc.py:251) is not installed in this image
-        assert "torchaudio" in str(e)
+    rt.set_formant(2.0)  # rtrvc.py:190-191, 218-219: the decoder is asked for ceil(return_length * 2^(2/12)) frames ...
+    wav = rt.infer(feats.to(gpu), n_samples, block16k, skip_head, ret_len, pitch=pitch.to(gpu), pitchf=pitchf.to(gpu))
+    # ... and its output is resampled from upp_res to tgt_sr / 100 samples per 10 ms (rtrvc.py:248-259) by the HIP polyphase kernel
+    factor = 2 ** (2.0 / 12)
+    upp_res = int(np.floor(factor * 48000 // 100))
+    rl2_ = int(np.ceil(ret_len * factor))
+    sig = (0.4 * torch.sin(torch.arange(rl2_ * 480, dtype=torch.float32) * 0.013)).numpy()[: ret_len * upp_res]
+    want = glue_oracle.sinc_resample(sig, upp_res, 480)
+    assert wav.shape == want.shape and np.abs(wav.cpu().numpy() - want).max() <= 2e-6
     cp[:-shift] = cp[shift:].copy()
     cf[:-shift] = cf[shift:].copy()
     cp[4 - m:] = pitch.numpy()[3:-1]
@@ -174,6 +179,23 @@ def test_realtime_vc_block_loop(gpu):
     rl2 = int(np.ceil(ret_len * 2 ** (2.0 / 12)))
     assert seen["return_length2"] == rl2
     assert np.allclose(seen["pitchf"][0].numpy(), cf[-p_len:] * rl2 / ret_len, rtol=1e-6)
+
+
+def test_sinc_resample_kernel_matches_the_oracle(gpu):
+    """rvcmi_glue_resample_poly + the product's filter table against the independent numpy restatement (oracle unpinned vs
+    torchaudio, see glue_oracle.sinc_resample): up and down ratios of the realtime formant shift, ragged lengths, batch rows."""
+    import rvc_amd
+
+    rng = np.random.default_rng(4)
+    for orig, new, n in ((423, 400, 12345), (538, 480, 13450), (357, 400, 8000), (400, 400, 100), (3, 2, 17)):
+        x = rng.standard_normal((2, n)).astype(np.float32)
+        rs = rvc_amd.SincResample(orig, new, gpu)
+        got = rs(torch.from_numpy(x).to(gpu)).cpu().numpy()
+        for r in range(2):
+            want = glue_oracle.sinc_resample(x[r], orig, new) if orig != new else x[r]
+            assert got[r].shape == want.shape and np.abs(got[r] - want).max() <= 5e-6 * max(1.0, np.abs(want).max()), (orig, new)
+    with pytest.raises(rvc_amd.RvcmiError):
+        rvc_amd.SincResample(423, 400, gpu)(torch.zeros(10))
 
 
 def test_scale_int16_range(gpu):
