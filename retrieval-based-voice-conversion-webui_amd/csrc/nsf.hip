@@ -2,6 +2,7 @@
 // `net_g.dec`), workspace, and the launch sequence of NSFGenerator.forward (rvc/layers/nsf.py:145-191)
 // / Generator.forward (rvc/layers/generators.py:70-98).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <functional>
 #include <memory>
@@ -79,7 +80,7 @@ struct rvcmi_nsf {
     size_t ws_bytes = 0;
     Profiler prof;
     // dev / test options (common.hpp Options): RB_STREAM (absent = auto, 1 = streaming resblock kernels whenever supported, 0 = never),
-    // NO_RBFULL, RB_ORDER (1 = resblock-major pair launches), UPS_NJ, NB (weight-ring depth of k_rb_full), DBG (timing-ablation bit
+    // NO_RBFULL, NO_RB_SPLIT, RB_ORDER (1 = resblock-major pair launches), UPS_NJ, NB (weight-ring depth of k_rb_full), DBG (timing-ablation bit
     // mask: results are WRONG when non-zero) and the rb_stream keys (rb_stream.hpp).  Read from RVCMI_<KEY> once, in rvcmi_nsf_create.
     rvcmi::Options opt;
 };
@@ -93,6 +94,10 @@ constexpr int RB_KG = 4;  // k-steps per weight-prefetch group inside the fused 
 #define RB256_NJ 4  // (96-row tiles, 2 blocks per CU, measured the same 0.33 ms at B=1; 128 rows reuse weights better)
 #endif
 static int rb_rows(int C) { return C == 256 ? 32 * RB256_NJ : RB_ROWS; }
+// Resblock stages of at most this many rows (B x L) at C = 256 run conv by conv, split over output channels (run_conv_jobs): a
+// realtime chunk's first stage is 310 rows = 9 fused pair tiles, each pulling 2.9 MB of weights through ONE CU (3 x 70 us).
+constexpr int RB_SPLIT_MAX_ROWS = 1024;      // C = 256
+constexpr int RB_SPLIT_MAX_ROWS_128 = 4096;  // C = 128 (a chunk's second stage: 3100 rows = 75 pair tiles of 3 x 40 us)
 
 static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights, int n_weights, int device, int max_B,
                        int max_T, rvcmi_nsf** out) {
@@ -107,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "RB_ORDER", "UPS_NJ", "NB", "DBG"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -260,6 +265,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
         h->Yb[j].alloc(fb);
     }
     if (op == RVCMI_OPERAND_F32) h->H.alloc(fb);
+    else h->H.alloc((size_t)3 * std::max(RB_SPLIT_MAX_ROWS * 256, RB_SPLIT_MAX_ROWS_128 * 128) * 2);  // conv1 outputs of the output-channel-split resblock path (tiny launches)
     {
         size_t nz = 0;
         long Ls = max_T;
@@ -614,6 +620,61 @@ static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const 
     HIP_CHECK(hipGetLastError());
 }
 
+// Up to three independent convs of the same shape class (C_in = C_out = 256) in ONE launch of k_conv_mfma_jobs, blocks of
+// 32 output channels x 128 rows (MI = 1, NJ = 1, waves split time): grid = row tiles x 8 channel tiles x (jobs x batch).
+template <typename OpT, int C>
+static void launch_conv_jobs(const ConvJobs& js, int Lq, int B, size_t smem, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    auto kern = &k_conv_mfma_jobs<OpT, C, 1, 1, 1>;
+    if (!(attr_done.load() & (1ull << (dev & 63)))) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done.fetch_or(1ull << (dev & 63));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((Lq + 127) / 128), C / 32, (unsigned)(B * js.njobs)), dim3(256), smem, st, js);
+}
+static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvArgs* as, int nj, int B, const char* name, hipStream_t st) {
+    ConvJobs js;
+    memset(&js, 0, sizeof(js));
+    js.njobs = nj;
+    double flops = 0, bytes = 0;
+    size_t smem = 0;
+    for (int j = 0; j < nj; ++j) {
+        const ConvLayer& L = *Ls[j];
+        ConvArgs a = as[j];
+        if ((L.cin != 256 && L.cin != 128) || L.cout != L.cin || L.cin != Ls[0]->cin || L.nphase != 1 || L.dstep < 0)
+            RVCMI_FAIL(RVCMI_ERR_INVALID, "run_conv_jobs: unsupported layer");
+        a.cin = L.cin;
+        a.cout = L.cout;
+        a.bias = L.bias.as<float>();
+        a.dstep = L.dstep;
+        a.nphase = 1;
+        a.in_off = L.in_off[0];
+        a.w = L.w_pack.p;
+        a.w_ct_stride = L.ct_stride;
+        a.ntaps = L.ntaps_p;
+        a.roff = 0;
+        a.tile_rows = 128 + (L.ntaps_p - 1) * L.dstep;
+        smem = std::max(smem, (size_t)a.tile_rows * (2 * L.cin + 16));
+        flops += L.flops_per_pos * (double)a.Lq * B;
+        bytes += (double)B * a.Lq * L.cin * (a.in_mode == IN_OP_RAW ? 2 : 4) + (double)B * a.Lq * L.cin * (a.out_mode == OUT_ACT ? 2 : 4) +
+                 (a.res ? (double)B * a.Lq * L.cin * 4 : 0) + (double)L.ntaps[0] * L.cin * L.cin * 2;
+        js.job[j] = a;
+    }
+    const bool c256 = Ls[0]->cin == 256;
+    h->prof.launch(name, flops, bytes, st, [&] {
+        if (h->cfg.operand == RVCMI_OPERAND_BF16) {
+            if (c256) launch_conv_jobs<__bf16, 256>(js, as[0].Lq, B, smem, st);
+            else launch_conv_jobs<__bf16, 128>(js, as[0].Lq, B, smem, st);
+        } else {
+            if (c256) launch_conv_jobs<_Float16, 256>(js, as[0].Lq, B, smem, st);
+            else launch_conv_jobs<_Float16, 128>(js, as[0].Lq, B, smem, st);
+        }
+    });
+    HIP_CHECK(hipGetLastError());
+}
+
 // option DBG: timing-ablation bit mask forwarded to the kernels (results are WRONG when non-zero; bench/dev only).
 static int dbg_flags(const rvcmi_nsf* h) { return h->opt.geti("DBG", 0); }
 
@@ -886,6 +947,52 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     run_conv(h, s.rb[j][m].second, a, B, nm, st);
                     src[j] = dst;
                 }
+        } else if (((C == 256 && (long)B * L <= RB_SPLIT_MAX_ROWS) || (C == 128 && (long)B * L <= RB_SPLIT_MAX_ROWS_128 && !h->opt.on("NO_RB_SPLIT128"))) &&
+                   nk <= 3 && !h->opt.on("NO_RB_SPLIT") && rb_stream_mode(h) != 1) {
+            // a handful of rows (realtime chunk): conv1 / conv2 of all resblocks as two output-channel-split launches per pair level
+            snprintf(nm, sizeof(nm), "rb_split_c%d", C);
+            for (size_t m = 0; m < maxnd; ++m) {
+                const ConvLayer* L1[3];
+                const ConvLayer* L2[3];
+                ConvArgs a1[3], a2[3];
+                int nj = 0;
+                for (int j = 0; j < nk; ++j) {
+                    if (m >= s.rb[j].size()) continue;
+                    float* dst = (m & 1) ? h->Yb[j].as<float>() : h->Ya[j].as<float>();
+                    void* hbuf = (char*)h->H.p + (size_t)nj * (h->H.bytes / 3);
+                    ConvArgs a = base_args();
+                    a.in = src[j];
+                    a.in_bstride = L * C;
+                    a.Lin = (int)L;
+                    a.in_mode = IN_F32_ACT;
+                    a.Lq = (int)L;
+                    a.out_mode = OUT_ACT;
+                    a.out = hbuf;
+                    a.out_bstride = L * C;
+                    a.out_C = C;
+                    a1[nj] = a;
+                    L1[nj] = &s.rb[j][m].first;
+                    a = base_args();
+                    a.in = hbuf;
+                    a.in_bstride = L * C;
+                    a.Lin = (int)L;
+                    a.in_mode = IN_OP_RAW;
+                    a.Lq = (int)L;
+                    a.out_mode = OUT_F32;
+                    a.out = dst;
+                    a.out_bstride = L * C;
+                    a.out_C = C;
+                    a.res = src[j];
+                    a.res_bstride = L * C;
+                    a2[nj] = a;
+                    L2[nj] = &s.rb[j][m].second;
+                    src[j] = dst;
+                    ++nj;
+                }
+                if (!nj) continue;
+                run_conv_jobs(h, L1, a1, nj, B, nm, st);
+                run_conv_jobs(h, L2, a2, nj, B, nm, st);
+            }
         } else if (try_rb_stream_full(h, s, op, C, (int)L, B, nk, src, st)) {
             // streaming fused resblocks (rb_stream_kernels.hpp): persistent blocks walk strips of the time axis
         } else if (C <= 64 && maxnd <= 3 && !h->opt.on("NO_RBFULL")) {

@@ -439,6 +439,54 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
         }
         return;
     }
+    if (a.in_mode == IN_OP_RAW || (a.in_mode == IN_F32_ACT && !a.in_b && !a.in_c && a.div_in == 1.f)) {
+        // plain row-major inputs (the conv-by-conv resblock path): SB chunks in flight per thread, clamped addresses so that every
+        // load is unconditional (the one-chunk-at-a-time loop below is a load -> convert -> store round trip per chunk: 22 serial
+        // L2 latencies for a 176-row tile at C = 256, the whole duration of a small launch)
+        constexpr int SB = 8;
+        const int total = rows * C8;
+        const bool raw = a.in_mode == IN_OP_RAW;
+        for (int base = tid; base < total; base += SB * 256) {
+            frag vr[SB];
+            float4 lo[SB], hi[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = min(base + u * 256, total - 1);
+                const int r = idx / C8, c8 = idx - r * C8;
+                const int grc = min(max(g0 + r, 0), a.Lin - 1);
+                if (raw) {
+                    vr[u] = *(const frag*)((const OpT*)a.in + (size_t)b * a.in_bstride + (size_t)grc * CIN + c8 * 8);
+                } else {
+                    const float4* p = (const float4*)((const float*)a.in + (size_t)b * a.in_bstride + (size_t)grc * CIN + c8 * 8);
+                    lo[u] = p[0];
+                    hi[u] = p[1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = base + u * 256;
+                if (idx < total) {
+                    const int r = idx / C8, c8 = idx - r * C8;
+                    const int gr = g0 + r;
+                    const bool ok = gr >= 0 && gr < a.Lin;
+                    frag v;
+                    if (raw) {
+                        v = vr[u];
+                    } else {
+                        const float f[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(lrelu(f[e], a.slope_in));
+                    }
+                    if (!ok) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (OpT)0.f;
+                    }
+                    *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
+                }
+            }
+        }
+        return;
+    }
     for (int idx = tid; idx < rows * C8; idx += 256) {
         const int r = idx / C8;
         const int c8 = idx - r * C8;
@@ -651,21 +699,36 @@ __device__ __forceinline__ void conv_core(f32x16 (&acc)[MI][NJ], const char* lds
 
 // Generic single-conv kernel: stage tile -> conv_core -> epilogue.  Grid: x = time tile,
 // y = (co block) * nphase + phase, z = batch.  Block = 4 waves laid out WCO (co) x WT (time).
-template <typename OpT, int CIN, int MI, int NJ, int WCO>
-static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
+template <typename OpT, int CIN, int MI, int NJ, int WCO, int NB = 2, bool PFW = false>
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int b, char* smem) {
     using TL = Tile<CIN>;
     constexpr int WT = 4 / WCO;
     constexpr int TT = WT * NJ * 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int b = blockIdx.z;
     const int ph = a.nphase > 1 ? (int)(blockIdx.y % a.nphase) : 0;
     const int cob = a.nphase > 1 ? (int)(blockIdx.y / a.nphase) : (int)blockIdx.y;
     const int q0 = blockIdx.x * TT;
     const int in_off = a.nphase > 1 ? a.ph_in_off[ph] : a.in_off;
     const OpT* wbase = (const OpT*)a.w + (a.nphase > 1 ? a.ph_w_off[ph] : 0);
 
+    unsigned pf_acc = 0;
+    if constexpr (PFW) {
+        // Tiny launches (a realtime chunk) use every weight byte for a handful of row tiles only, so the weights are never
+        // L2-resident: the K loop's 12 KB of loads in flight per wave then runs at the latency of the far memory side (measured:
+        // 24 us per launch for a 6 us K loop).  Touch the block's whole weight slice up front -- every thread 16 bytes per 4 KB
+        // round, all rounds in flight next to the tile staging -- so that the K loop finds it in the XCD's L2.
+        const char* wb = (const char*)(wbase + (size_t)cob * WCO * MI * a.w_ct_stride);
+        const size_t bytes = (size_t)WCO * MI * a.w_ct_stride * sizeof(OpT);
+        const size_t rounds = bytes / 4096;
+#pragma unroll 8
+        for (size_t r = 0; r < rounds; ++r) {
+            const uint4 v = *(const uint4*)(wb + r * 4096 + threadIdx.x * 16);
+            pf_acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
     stage_tile<OpT, CIN>(smem, a, b, q0 + in_off - a.roff, a.tile_rows);
+    if constexpr (PFW) {
+        if (pf_acc == 0x9e3779b9u && a.Lq < 0) *(unsigned*)smem = pf_acc;  // never true: keeps the prefetch loads alive
+    }
     __syncthreads();
 
     const int wave = threadIdx.x >> 6;
@@ -685,7 +748,7 @@ static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
 
     const char* lds_lane = smem + (size_t)(tw0 + (lane & 31)) * TL::STRIDE + (lane >> 5) * 16;
     const OpT* wlane = wbase + (size_t)ct0 * a.w_ct_stride + lane * 8;
-    conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.w_ct_stride, a.ntaps, a.roff, a.dstep);
+    conv_core<OpT, CIN, MI, NJ, KGROUP, NB>(acc, lds_lane, wlane, a.w_ct_stride, a.ntaps, a.roff, a.dstep);
 
     // ---- epilogue -------------------------------------------------------------------------
     const int out_add = a.nphase > 1 ? ph : a.out_add;
@@ -738,6 +801,28 @@ static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
             }
         }
     }
+}
+
+template <typename OpT, int CIN, int MI, int NJ, int WCO>
+static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_mfma_body<OpT, CIN, MI, NJ, WCO>(a, (int)blockIdx.z, smem);
+}
+
+// The same conv for up to three independent jobs in ONE launch (grid.z = batch x jobs).  Used where a fused resblock launch would
+// be a handful of blocks (the realtime chunk: 310 rows at C = 256 = 9 pair tiles, each streaming 2.9 MB of weights through one
+// CU): conv1 / conv2 of all the stage's resblocks as separate, output-channel-split launches of ~70 blocks.
+struct ConvJobs {
+    ConvArgs job[3];
+    int njobs;
+};
+template <typename OpT, int CIN, int MI, int NJ, int WCO>
+static __global__ void __launch_bounds__(256) k_conv_mfma_jobs(ConvJobs js) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int j = (int)blockIdx.z % js.njobs, b = (int)blockIdx.z / js.njobs;
+    // a weight ring of 4 groups (12 k-steps in flight): with one MFMA per k-step (NJ = 1) the default 2 groups cover 4 k-steps =
+    // ~260 cycles, less than one L2 round trip, and the K loop ran at the latency of the weight loads (28 us per launch)
+    conv_mfma_body<OpT, CIN, MI, NJ, WCO, 4, true>(js.job[j], b, smem);
 }
 
 // Branch-free helpers.  lrelu as max(x, slope*x) (0 < slope < 1); row masking by AND-ing the value bits so that
