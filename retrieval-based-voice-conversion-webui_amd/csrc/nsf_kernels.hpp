@@ -829,17 +829,42 @@ static __global__ void __launch_bounds__(256) k_conv_mfma_jobs(ConvJobs js) {
 // the compiler cannot turn the select into divergent control flow (it did: ~45 exec-masked blocks per publish).
 // (fmaxf costs a third VALU op per value -- hipcc canonicalises the operand it cannot prove quiet, `v_max_f32 t, v, v` -- but an
 //  inline-asm v_max_f32 in its place pins registers: rb_stream phases 3.0k -> 4.1k cycles, 13-29 spills.  Measured, not kept.)
-// max(v, slope*v) as the MEDIAN of {v, slope*v, +inf}: one v_med3_f32, bit-identical to fmaxf for every non-NaN input, and
-// without the canonicalising `v_max_f32 t, v, v` hipcc puts in front of fmaxf (4.5 -> 3.5 VALU per published value)
+// (round 2 wrote max(v, slope*v) as the median of {v, slope*v, +inf}: LLVM folds a med3 with an infinite operand back into
+//  v_max_f32 WITH the canonicalising v_max in front -- the ISA still had 5.5 VALU per masked value.)
 __device__ __forceinline__ float lrelu_max(float v, float slope) { return __builtin_amdgcn_fmed3f(v, v * slope, __builtin_inff()); }
 __device__ __forceinline__ float mask_bits(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
+
+// lrelu(v, 0.1) of a value that is about to become an MFMA operand, as ONE v_mul + ONE v_med3: the median of {v, 0.1 v, TOP}
+// is max(v, 0.1 v) whenever that is <= TOP, and TOP otherwise -- for fp16 operands TOP = 65504 is the saturation to_op<> applies
+// (identical results for every |v| < 655040; beyond that the fp16 conversion overflows to inf as the reference's .half() does),
+// for bf16 TOP = FLT_MAX (no fold to v_max: a finite constant).  3 VALU per published value with the row mask applied to the
+// PACKED pair (one v_and per two values) instead of 5.5.
+template <typename OpT>
+__device__ __forceinline__ float lrelu_op(float v) {
+    return __builtin_amdgcn_fmed3f(v, v * 0.1f, 3.4028235e38f);
+}
+template <>
+__device__ __forceinline__ float lrelu_op<_Float16>(float v) {
+    return __builtin_amdgcn_fmed3f(v, v * 0.1f, 65504.f);
+}
+// four activated values -> 4 operands (8 bytes), rows outside the utterance zeroed through the packed words
+template <typename OpT, bool MASK>
+__device__ __forceinline__ uint2 pack4_lrelu(float a, float b, float c, float d, unsigned m) {
+    using o4 = __attribute__((ext_vector_type(4))) OpT;
+    o4 o = {(OpT)lrelu_op<OpT>(a), (OpT)lrelu_op<OpT>(b), (OpT)lrelu_op<OpT>(c), (OpT)lrelu_op<OpT>(d)};
+    uint2 u = __builtin_bit_cast(uint2, o);
+    if constexpr (MASK) {
+        u.x &= m;
+        u.y &= m;
+    }
+    return u;
+}
 
 // acc (MFMA D layout) -> lrelu -> OpT -> LDS operand tile.  `base` already points at this lane's (row, 4*(lane>>5))
 // element of the wave's first row; everything else is a compile-time offset.
 template <typename OpT, int C, int MI, int NJ, int STRIDE, bool MASK>
 __device__ __forceinline__ void publish_operand(char* base, const f32x16 (&acc)[MI][NJ], const unsigned (&rowmask)[NJ],
                                                 int cbase = 0) {
-    using o4 = __attribute__((ext_vector_type(4))) OpT;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -847,14 +872,9 @@ __device__ __forceinline__ void publish_operand(char* base, const f32x16 (&acc)[
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if ((C % 32 == 0) || cbase + mi * 32 + 8 * g < C) {  // compile-time true for C % 32 == 0
-                    o4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = lrelu_max(acc[mi][jt][4 * g + e], 0.1f);
-                        if constexpr (MASK) v = mask_bits(v, rowmask[jt]);
-                        o[e] = to_op<OpT>(v);
-                    }
-                    *(o4*)(base + jt * 32 * STRIDE + (mi * 32 + 8 * g) * 2) = o;
+                    const f32x16& t = acc[mi][jt];
+                    *(uint2*)(base + jt * 32 * STRIDE + (mi * 32 + 8 * g) * 2) =
+                        pack4_lrelu<OpT, MASK>(t[4 * g + 0], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3], rowmask[jt]);
                 }
             }
 }
@@ -985,7 +1005,7 @@ static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArg
             const float f[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
             frag v;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(lrelu_max(f[e], 0.1f));
+            for (int e = 0; e < 8; ++e) v[e] = (OpT)lrelu_op<OpT>(f[e]);
             *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
         }
     }

@@ -13,6 +13,7 @@
 #include "rb_stream.hpp"
 #include "rb_stream_kernels.hpp"
 #include "rb_stream2_kernels.hpp"
+#include "rb_stream3_kernels.hpp"
 
 namespace rvcmi {
 int num_cus();
@@ -21,7 +22,7 @@ namespace {
 
 struct Geo {
     int MI, NJ, NCO, bpc;  // bpc = blocks per CU (k_rb_stream: one wave per SIMD, NCO * bpc = 4)
-    int ver;               // 1 = k_rb_stream, 2 = k_rb_stream2 (two blocks per CU, swizzled 256-byte rows)
+    int ver;               // 1 = k_rb_stream, 2 = k_rb_stream2 (two blocks per CU, swizzled 256-byte rows), 3 = k_rb_stream3 (half-step slots)
     double c0;             // planning: a block's time is steps x (k + c0) units
 };
 // k_rb_stream2 (two blocks per CU): every strip pays the same warm-up rows but a step is half as long, so it needs LONG strips
@@ -32,6 +33,9 @@ bool geo_for(int C, int nd, Geo& g, const Options& opt, int ver = 1) {
     if (C == 256 && nd == 1) { g = {2, sm ? 3 : 4, 4, 1, 1, 4.4}; return true; }
     // k_rb_stream2: measured cycles per pair-step 46.2k / 32.9k / 20.0k for k = 11 / 7 / 3 => time ~ steps x (k + 3.1)
     if (C == 128 && nd == 3 && ver == 2) { g = {1, 3, 4, 2, 2, opt.get("RS_C0", 3.1)}; return true; }
+    // k_rb_stream3 (rb_stream3_kernels.hpp): publish / history work in the MFMA shadow; planning constant from the slot model
+    // (per pair-step ~ 4 x (24 k MFMAs x 33 cycles + 72 gaps x 9) + barriers + IO  =>  time ~ steps x (k + 2.0))
+    if (C == 128 && nd == 3 && ver == 3) { g = {1, 6, 4, 1, 3, opt.get("RS_C0", 2.0)}; return true; }
     if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1, 1, 4.4}; return true; }
     // (C = 128 pair by pair with TWO blocks per CU -- NJ = 4, 225 registers, 0 spills -- was measured: both waves of a SIMD sit in
     //  their K loops at the same time (72 cycles per MFMA per wave), the phases overlap no better than in the one-wave design
@@ -57,6 +61,21 @@ void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStre
     }
     if (nblocks < 0) return;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(64 * NCO), smem, st, a);
+}
+
+template <typename OpT>
+void launch_inst3(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    auto kern = &k_rb_stream3<OpT>;
+    if (!(attr_done.load() & bit)) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done.fetch_or(bit);
+    }
+    if (nblocks < 0) return;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(256), smem, st, a);
 }
 
 template <typename OpT, int NJ, int ND>
@@ -85,6 +104,7 @@ void launch_inst2(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStr
 #endif
 template <typename OpT>
 void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st, int ver = 1) {
+    if (ver == 3 && C == 128 && nd == 3) return launch_inst3<OpT>(a, nblocks, B, smem, st);
     if (ver == 2 && C == 128 && nd == 3 && NJ == 3) return launch_inst2<OpT, 3, 3>(a, nblocks, B, smem, st);
     if (C == 256 && nd == 1 && NJ == 4) return launch_inst<OpT, 256, 2, 4, 4, 1>(a, nblocks, B, smem, st);
     if (C == 256 && nd == 1 && NJ == 3) return launch_inst<OpT, 256, 2, 3, 4, 1>(a, nblocks, B, smem, st);
@@ -123,6 +143,8 @@ void rb_stream_prepare() {
     }
     launch_t<__bf16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
     launch_t<_Float16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
+    launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr, 3);
+    launch_t<_Float16>(128, 3, 6, a, -1, 1, 0, nullptr, 3);
 }
 
 bool rb_stream_supported(int operand, int C, int nd) {
@@ -132,11 +154,18 @@ bool rb_stream_supported(int operand, int C, int nd) {
 
 static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B,
                        long bstride, hipStream_t st, const Options& opt, bool dry_run);
+#ifndef RS_V3_DEFAULT
+#define RS_V3_DEFAULT 0  // until the GPU A/B says otherwise
+#endif
 
 bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B, long bstride, bool force,
                       hipStream_t st, const Options& opt, bool dry_run) {
     Geo g;
     if (operand == RVCMI_OPERAND_F32 || njobs < 1 || njobs > 3) return false;
+    // RS_V3: 1 = k_rb_stream3 wherever it is instantiated (C = 128 whole resblocks), 0 = never (A/B runs; default set below)
+    if (opt.geti("RS_V3", RS_V3_DEFAULT) && geo_for(C, nd, g, opt, 3) && g.ver == 3 &&
+        launch_geo(g, force ? 0 : 4, operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
+        return true;
     const int v2 = opt.geti("RS_V2", 0);
     if (v2 && geo_for(C, nd, g, opt, 2) && g.ver == 2 &&
         launch_geo(g, v2 == 1 ? (force ? 0 : 4) : opt.geti("RS_V2_STEPS", 150), operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
@@ -179,8 +208,8 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
             J.b2[m] = d.b2[m];
             J.dil[m] = d.dil[m];
             const int p1 = d.dil[m] * (d.k - 1) / 2;
-            if (p1 + p2 > 32 || 2 * p2 > RS_HROW || p1 + p2 + d.dil[m] - 32 > (g.ver == 2 ? RS2_SLACK : RS_SLACK) ||
-                32 + p1 - p2 > (g.ver == 2 ? RS2_HEAD : RS_HEAD - RS_HROW))
+            if (p1 + p2 > 32 || 2 * p2 > RS_HROW || p1 + p2 + d.dil[m] - 32 > (g.ver >= 2 ? RS2_SLACK : RS_SLACK) ||
+                32 + p1 - p2 > (g.ver >= 2 ? RS2_HEAD : RS_HEAD - RS_HROW) || (g.ver == 3 && d.k < 3))
                 return false;  // halo larger than the 32-row lag / the head room of the tile: not this kernel
             warm[j] += p1;
             J.sx_off[m] = sx;
@@ -267,8 +296,9 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
         a.flags = opt.geti("RS_PRIO", 0) & 1;
     }
     if (min_steps < min_steps_required) return false;
-    const size_t smem = g.ver == 2 ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
-                                   : (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
+    const size_t smem = g.ver == 3   ? (size_t)(RS3_XROWS + RS3_HROWS + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
+                        : g.ver == 2 ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
+                                     : (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
     if (smem > (size_t)160 * 1024 / g.bpc)
         RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large for %d block(s) per CU (C=%d)", smem, g.bpc, C);
     if (dry_run) return true;
@@ -288,7 +318,9 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
         std::vector<unsigned long long> h(nts);
         HIP_CHECK(hipMemcpy(h.data(), ts, nts * 8, hipMemcpyDeviceToHost));
         (void)hipFree(ts);
-        static const char* names[10] = {"phaseA", "barA", "conv1", "bar1", "phaseB", "barB", "conv2", "bar2", "xload", "store"};
+        static const char* names1[10] = {"phaseA", "barA", "conv1", "bar1", "phaseB", "barB", "conv2", "bar2", "xload", "store"};
+        static const char* names3[10] = {"slot1", "bar", "slot2", "bar", "slot3", "bar", "slot4", "bar", "xload", "store"};
+        const char* const* names = g.ver == 3 ? names3 : names1;
         for (int j = 0; j < njobs; ++j) {
             double sum[10] = {0}, steps = 0, tot_max = 0;
             long cnt = 0;
@@ -302,7 +334,7 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
                 ++cnt;
             }
             if (!cnt) continue;
-            fprintf(stderr, "[rs stamps] C=%d nd=%d NJ=%d k=%d strips=%d len=%d steps/blk=%.1f  cycles per PAIR-step:", C, nd, g.NJ, a.job[j].k,
+            fprintf(stderr, "[rs stamps] v%d C=%d nd=%d NJ=%d k=%d strips=%d len=%d steps/blk=%.1f  cycles per PAIR-step:", g.ver, C, nd, g.NJ, a.job[j].k,
                     a.job[j].nstrips, a.job[j].strip_len, steps / cnt);
             for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f", names[i], sum[i] / (steps * nd));
             fprintf(stderr, " | per step: xload %.0f store %.0f | slowest wave total %.0f cycles\n", sum[8] / steps, sum[9] / steps, tot_max);

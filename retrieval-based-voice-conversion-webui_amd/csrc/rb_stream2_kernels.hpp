@@ -30,6 +30,8 @@ constexpr int RS2_SLACK = 3;   // the B prefetch past the last tap reads up to p
 
 using lds_cptr = const __attribute__((address_space(3))) char*;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;  // (uint4 is a class type: no address-space-qualified copies)
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+__device__ __forceinline__ u32x2 to_u32x2(uint2 v) { return u32x2{v.x, v.y}; }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_cptr)p; }
 template <typename T>
 __device__ __forceinline__ T lds_ld(unsigned a) {
@@ -93,37 +95,22 @@ __device__ __forceinline__ void rs2_conv(f32x16 (&acc)[NJ], typename Op<OpT>::fr
 // start), off[g]: byte offset inside the row of this lane's 8-byte piece of chunk g (swizzle folded in).
 template <typename OpT, int NJ, bool MASK>
 __device__ __forceinline__ void rs2_publish(unsigned rowbase, const unsigned (&off)[4], const f32x16 (&acc)[NJ], const unsigned (&rowmask)[NJ]) {
-    using o4 = __attribute__((ext_vector_type(4))) OpT;
 #pragma unroll
     for (int jt = 0; jt < NJ; ++jt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            o4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = lrelu_max(acc[jt][4 * g + e], 0.1f);
-                if constexpr (MASK) v = mask_bits(v, rowmask[jt]);
-                o[e] = to_op<OpT>(v);
-            }
-            lds_st<o4>(rowbase + jt * 32 * RS2_STRIDE + off[g], o);
+            const f32x16& t = acc[jt];
+            lds_st<u32x2>(rowbase + jt * 32 * RS2_STRIDE + off[g],
+                          to_u32x2(pack4_lrelu<OpT, MASK>(t[4 * g + 0], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3], rowmask[jt])));
         }
 }
 
 // the same values of ONE tile once more, into a history buffer (or the dump row)
 template <typename OpT, bool MASK>
 __device__ __forceinline__ void rs2_publish_tail(unsigned rowaddr, const unsigned (&off)[4], const f32x16& acc, unsigned rowmask) {
-    using o4 = __attribute__((ext_vector_type(4))) OpT;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        o4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = lrelu_max(acc[4 * g + e], 0.1f);
-            if constexpr (MASK) v = mask_bits(v, rowmask);
-            o[e] = to_op<OpT>(v);
-        }
-        lds_st<o4>(rowaddr + off[g], o);
-    }
+    for (int g = 0; g < 4; ++g)
+        lds_st<u32x2>(rowaddr + off[g], to_u32x2(pack4_lrelu<OpT, MASK>(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], rowmask)));
 }
 
 template <typename OpT, int NJ, int ND>

@@ -254,11 +254,9 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        o4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            o[e] = to_op<OpT>(mask_bits(lrelu_max(hacc[mi][NJ - 1][4 * g + e], 0.1f), rowmask[NJ - 1]));
-                        *(o4*)(tw + (mi * 32 + 8 * g) * 2) = o;
+                        const f32x16& t = hacc[mi][NJ - 1];
+                        *(uint2*)(tw + (mi * 32 + 8 * g) * 2) =
+                            pack4_lrelu<OpT, true>(t[4 * g + 0], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3], rowmask[NJ - 1]);
                     }
             }
             stamp(4);  // phase B

@@ -258,12 +258,18 @@ def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
     har = gen.debug_tap("har", zd, fd, gd, noise=nd)
     rel = rms(har, taps["har"]) / float(taps["har"].pow(2).mean().sqrt())
     assert rel <= 1e-6, "har (sine source over 1198 voiced frames): relative RMS %.2e" % rel
+    # both streaming ResBlock kernels of the C = 128 stage on the whole clip: k_rb_stream and k_rb_stream3 (half-step slots)
+    for v3 in (0, 1):
+        o = pin(gen, RS_V3=v3)(zd, fd, gd, noise=nd).cpu()
+        assert torch.isfinite(o).all() and rms(o, d["out"]) <= 1e-3, "RS_V3=%d: RMS %.3e vs the reference waveform" % (v3, rms(o, d["out"]))
+        assert rms(o, out) <= 5e-4
+    pin(gen, RS_V3=None)
     # exact-fp32 path on the same clip
     gen32 = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp32", max_B=1, max_T=1198)
     assert rms(gen32(zd, fd, gd, noise=nd).cpu(), d["out"]) <= 2e-5
 
 
-@pytest.mark.parametrize("rb_stream", ["0", "1"])
+@pytest.mark.parametrize("rb_stream", ["0", "1", "v3"])
 def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu):
     """BASELINE configs[2] geometry (grid.z = batch, multi-GB streams, the large-batch launch shapes): 16 different full-size
     voiced clips in one call; every item must be BIT-equal to the same clip run alone -- with the ResBlock kernel family
@@ -281,7 +287,8 @@ def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu):
         zs.append(z), fs.append(torch.roll(f0, 37 * b, dims=1)), gs.append(g)
         ns.append(nsf_oracle.reference_noise(1, T, cfg.upp, 114514 + b))
     Z, F, G, N = torch.cat(zs).to(gpu), torch.cat(fs).to(gpu), torch.cat(gs).to(gpu), torch.cat(ns).to(gpu)
-    gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T), RB_STREAM=int(rb_stream))
+    gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T),
+              RB_STREAM=1 if rb_stream == "v3" else int(rb_stream), RS_V3=1 if rb_stream == "v3" else 0)
     out = gen(Z, F, G, noise=N)
     assert out.shape == (B, 1, T * cfg.upp) and torch.isfinite(out).all()
     d = load_golden("full_v2_48k_T1198_voiced")
@@ -329,9 +336,19 @@ def test_batch_64_bench_config_3_geometry(gpu):
 # ---- streaming fused ResBlock kernel (csrc/rb_stream_kernels.hpp) -------------------------------------------------------
 # At full clip size the launcher picks it by itself (the full-size tests above run it); option RB_STREAM=1 forces it for
 # the small golden cases too (single short strips, sequence ends inside the first step), RS_SMALL selects the time-tile
-# height, RS_V2=1 the two-blocks-per-CU variant k_rb_stream2 (csrc/rb_stream2_kernels.hpp).
+# height, RS_V2=1 the two-blocks-per-CU variant k_rb_stream2 (csrc/rb_stream2_kernels.hpp), RS_V3=1 / 0 the variant with the
+# publish work in the MFMA shadow, k_rb_stream3 (csrc/rb_stream3_kernels.hpp), and its absence.
 
-@pytest.mark.parametrize("small", ["0", "1", "v2"])
+def _rs_opts(small):
+    """test parameter -> (RS_SMALL, RS_V2, RS_V3)"""
+    if small == "v2":
+        return None, 1, 0
+    if small == "v3":
+        return None, None, 1
+    return int(small), None, 0
+
+
+@pytest.mark.parametrize("small", ["0", "1", "v2", "v3"])
 @pytest.mark.parametrize("name", ["dec_v2_48k_B1_T70", "dec_v2_48k_B2_T24", "dec_v1_40k_B1_T20", "dec_v1_32k_B1_T16",
                                   "dec_nof0_v2_48k_B1_T16", "dec_v1_40k_nres_T31"])
 def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu):
@@ -339,15 +356,18 @@ def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu):
     cfg, w = golden_config_and_weights(d)
     for operand in ("fp16", "bf16"):
         gen = hip_gen(cfg, w, operand, gpu)
-        gen.set_option("RS_V2", 1 if small == "v2" else None)
-        out = run_golden(d, cfg, w, operand, gpu, RB_STREAM=1, RS_SMALL=None if small == "v2" else int(small))
+        rs_small, rs_v2, rs_v3 = _rs_opts(small)
+        gen.set_option("RS_V2", rs_v2)
+        gen.set_option("RS_V3", rs_v3)
+        out = run_golden(d, cfg, w, operand, gpu, RB_STREAM=1, RS_SMALL=rs_small)
         gen.set_option("RS_V2", None)
+        gen.set_option("RS_V3", None)
         assert torch.isfinite(out).all()
         e = rms(out, d["out"])
         assert e <= BAR[operand], "%s/%s (streaming resblocks): RMS error %.3e" % (name, operand, e)
 
 
-@pytest.mark.parametrize("small", ["0", "1", "v2"])
+@pytest.mark.parametrize("small", ["0", "1", "v2", "v3"])
 def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu):
     """Forced onto a clip of 300 frames: hundreds of strips of one to three steps each (every strip boundary, warm-up
     and tail case), batch of 2 with different inputs; per-stage taps and the waveform against the oracle."""
@@ -361,8 +381,9 @@ def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu):
     taps = {}
     with torch.no_grad():
         ref = nsf_oracle.generator_forward(cfg, w, z, f0, g, noise, taps=taps)
+    rs_small, rs_v2, rs_v3 = _rs_opts(small)
     gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T), RB_STREAM=1,
-              RS_SMALL=None if small == "v2" else int(small), RS_V2=1 if small == "v2" else None)
+              RS_SMALL=rs_small, RS_V2=rs_v2, RS_V3=rs_v3)
     zd, fd, gd, nd = z.to(gpu), f0.to(gpu), g.to(gpu), noise.to(gpu)
     out = gen(zd, fd, gd, noise=nd).cpu()
     assert rms(out, ref) <= 1e-3, "streaming resblocks, T=300 B=2: %.3e" % rms(out, ref)
