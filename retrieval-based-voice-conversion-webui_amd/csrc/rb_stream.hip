@@ -35,6 +35,9 @@ bool geo_for(int C, int nd, Geo& g, const Options& opt, int ver = 1) {
     if (C == 128 && nd == 3 && ver == 2) { g = {1, 3, 4, 2, 2, opt.get("RS_C0", 3.1)}; return true; }
     // k_rb_stream3 (rb_stream3_kernels.hpp): publish / history work in the MFMA shadow; planning constant from the slot model
     // (per pair-step ~ 4 x (24 k MFMAs x 33 cycles + 72 gaps x 9) + barriers + IO  =>  time ~ steps x (k + 2.0))
+    // k_rb_stream2x: k_rb_stream2's two strips per CU as two groups of one 8-wave block in anti-phase (one K loop and one phase
+    // per inter-barrier interval): planning unit = the pair, time ~ steps x (k + c0) with the phases in the K loops' shadow
+    if (C == 128 && nd == 3 && ver == 4) { g = {1, 3, 4, 2, 4, opt.get("RS_C0", 1.0)}; return true; }
     if (C == 128 && nd == 3 && ver == 3) { g = {1, 6, 4, 1, 3, opt.get("RS_C0", 2.0)}; return true; }
     if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1, 1, 4.4}; return true; }
     // (C = 128 pair by pair with TWO blocks per CU -- NJ = 4, 225 registers, 0 spills -- was measured: both waves of a SIMD sit in
@@ -78,6 +81,22 @@ void launch_inst3(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStr
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(256), smem, st, a);
 }
 
+template <typename OpT, int KL>
+void launch_inst2x(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    auto kern = &k_rb_stream2x<OpT, 3, 3, KL>;
+    if (!(attr_done.load() & bit)) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done.fetch_or(bit);
+    }
+    if (nblocks < 0) return;
+    // (strip counts are even per resblock: launch_geo) one block = two consecutive strips
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B / 2), dim3(512), 2 * smem, st, a);
+}
+
 template <typename OpT, int NJ, int ND>
 void launch_inst2(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
@@ -104,6 +123,7 @@ void launch_inst2(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStr
 #endif
 template <typename OpT>
 void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st, int ver = 1) {
+    if (ver == 4 && C == 128 && nd == 3) return (a.flags & 2) ? launch_inst2x<OpT, 2>(a, nblocks, B, smem, st) : launch_inst2x<OpT, 1>(a, nblocks, B, smem, st);
     if (ver == 3 && C == 128 && nd == 3) return launch_inst3<OpT>(a, nblocks, B, smem, st);
     if (ver == 2 && C == 128 && nd == 3 && NJ == 3) return launch_inst2<OpT, 3, 3>(a, nblocks, B, smem, st);
     if (C == 256 && nd == 1 && NJ == 4) return launch_inst<OpT, 256, 2, 4, 4, 1>(a, nblocks, B, smem, st);
@@ -145,6 +165,12 @@ void rb_stream_prepare() {
     launch_t<_Float16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
     launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr, 3);
     launch_t<_Float16>(128, 3, 6, a, -1, 1, 0, nullptr, 3);
+    for (int fl : {0, 2}) {  // both K-loop variants of k_rb_stream2x
+        a.flags = fl;
+        launch_t<__bf16>(128, 3, 3, a, -1, 1, 0, nullptr, 4);
+        launch_t<_Float16>(128, 3, 3, a, -1, 1, 0, nullptr, 4);
+    }
+    a.flags = 0;
 }
 
 bool rb_stream_supported(int operand, int C, int nd) {
@@ -154,6 +180,9 @@ bool rb_stream_supported(int operand, int C, int nd) {
 
 static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B,
                        long bstride, hipStream_t st, const Options& opt, bool dry_run);
+#ifndef RS_V2X_DEFAULT
+#define RS_V2X_DEFAULT 0
+#endif
 #ifndef RS_V3_DEFAULT
 #define RS_V3_DEFAULT 0  // until the GPU A/B says otherwise
 #endif
@@ -162,6 +191,10 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
                       hipStream_t st, const Options& opt, bool dry_run) {
     Geo g;
     if (operand == RVCMI_OPERAND_F32 || njobs < 1 || njobs > 3) return false;
+    // RS_V2X: 1 = k_rb_stream2x (two anti-phased strips per 8-wave block) wherever it is instantiated, 0 = never
+    if (opt.geti("RS_V2X", RS_V2X_DEFAULT) && geo_for(C, nd, g, opt, 4) && g.ver == 4 &&
+        launch_geo(g, force ? 0 : 4, operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
+        return true;
     // RS_V3: 1 = k_rb_stream3 wherever it is instantiated (C = 128 whole resblocks), 0 = never (A/B runs; default set below)
     if (opt.geti("RS_V3", RS_V3_DEFAULT) && geo_for(C, nd, g, opt, 3) && g.ver == 3 &&
         launch_geo(g, force ? 0 : 4, operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
@@ -286,20 +319,30 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
         const int len = std::max(rows, steps * R - warm[j]);
         J.strip_len = len;
         J.nstrips = (L + len - 1) / len;
+        if (g.ver == 4 && (J.nstrips & 1)) {  // pairs of strips share a block: an odd count gets a shorter split or one empty strip
+            const int n2 = J.nstrips + 1, rows2 = (L + n2 - 1) / n2, steps2 = (rows2 + warm[j] + R - 1) / R;
+            if (steps2 * R - warm[j] >= rows2 && steps2 <= steps) {  // same or fewer steps with one more strip
+                J.strip_len = std::max(rows2, steps2 * R - warm[j]);
+            }
+            J.nstrips = (L + J.strip_len - 1) / J.strip_len;
+            if (J.nstrips & 1) ++J.nstrips;  // the extra strip starts at or beyond L: it loads clamped rows and stores nothing
+        }
         J.blk0 = nblocks;
         nblocks += J.nstrips;
         min_steps = std::min(min_steps, steps);
     }
     a.side_rows = side_rows;
+    if (g.ver == 4) a.flags = opt.geti("RS_V2X", RS_V2X_DEFAULT) == 2 ? 2 : 0;  // RS_V2X = 2: the K loop with B two k-steps ahead
     if (g.ver == 2) {  // RS_SKEW = units of 1024 cycles per (k + 3), RS_PRIO = 1: s_setprio inside the K loops
         a.skew = opt.geti("RS_SKEW", 2);
         a.flags = opt.geti("RS_PRIO", 0) & 1;
     }
     if (min_steps < min_steps_required) return false;
-    const size_t smem = g.ver == 3   ? (size_t)(RS3_XROWS + RS3_HROWS + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
+    const size_t smem = g.ver == 4   ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
+                        : g.ver == 3 ? (size_t)(RS3_XROWS + RS3_HROWS + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
                         : g.ver == 2 ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
                                      : (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
-    if (smem > (size_t)160 * 1024 / g.bpc)
+    if (smem > (size_t)160 * 1024 / (g.ver == 4 ? 2 : g.bpc))
         RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large for %d block(s) per CU (C=%d)", smem, g.bpc, C);
     if (dry_run) return true;
     // dev only: option RS_STAMPS prints the per-phase cycle breakdown of every launch (synchronises; never set it in a timed run)

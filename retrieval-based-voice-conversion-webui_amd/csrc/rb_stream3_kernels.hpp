@@ -35,90 +35,7 @@ constexpr int RS3_HSLACK = 1;   // ... of conv2: one row
 constexpr int RS3_R = 192;
 constexpr int RS3_XROWS = RS3_XHEAD + RS3_R + RS3_XSLACK;
 constexpr int RS3_HROWS = RS3_HHEAD + RS3_R + RS3_HSLACK;
-constexpr int RS3_GAPS = 72;    // MFMA gaps that carry fillers: the first 3 taps of a K loop (every kernel size has >= 3 taps)
 constexpr int RS3_NPUB = 3 + 12 * 7;  // filler ops of publishing one half: 3 row masks + 12 x (4 activations, 2 packs, 1 store)
-
-// Block barrier that orders LDS traffic ONLY: __syncthreads() carries a workgroup release fence over global memory too, i.e. an
-// s_waitcnt vmcnt(0) in front of every s_barrier -- which would drain the weight fragments requested for the next slot (a full
-// L2 round trip, exposed four times per pair-step).  The waves of a block exchange data through LDS only.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-template <int N>
-using ic_t = std::integral_constant<int, N>;
-template <int B, int E, typename F>
-__device__ __forceinline__ void rs3_for(F&& f) {
-    if constexpr (B < E) {
-        f(ic_t<B>{});
-        rs3_for<B + 1, E>(f);
-    }
-}
-// ops [g * N / GAPS, (g + 1) * N / GAPS) of an N-op filler program go into gap g
-template <int N, int G, typename F>
-__device__ __forceinline__ void rs3_gap(F&& op) {
-    rs3_for<(G * N) / RS3_GAPS, ((G + 1) * N) / RS3_GAPS>(op);
-}
-
-template <typename OpT>
-__device__ __forceinline__ void rs3_prefetch(typename Op<OpT>::frag (&A)[8], const OpT* wbase, unsigned loff) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) A[k] = rs2_wload<OpT>(wbase + k * 512, loff);
-}
-
-// Swizzled K loop over one half (3 column tiles), C_in = 128, one 32-channel output tile per wave.  A holds tap 0 on entry
-// (rs3_prefetch) and is refilled IN PLACE: right after the three MFMAs of k-step kk, A[kk] is requested for the next tap (the
-// MFMAs have read it; the data lands a tap later).  Bf is a ring of 4 k-steps, read two k-steps ahead.  fill(gap) is called
-// with a compile-time gap index after every MFMA of the first three taps.
-template <typename OpT, bool ZERO, typename F>
-__device__ __forceinline__ void rs3_conv(f32x16 (&acc)[3], typename Op<OpT>::frag (&A)[8], unsigned row_addr, int s, int h, const OpT* wbase,
-                                         unsigned loff, int ntaps, int dil, F&& fill) {
-    using frag = typename Op<OpT>::frag;
-    constexpr unsigned TS = 32u * RS2_STRIDE;
-    auto tap_base = [&](unsigned ra, int sv) { return ra | (unsigned)(((h ^ sv) & 15) << 4); };
-    unsigned base = tap_base(row_addr, s);
-    frag Bf[4][3];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int jt = 0; jt < 3; ++jt) {
-            Bf[q][jt] = lds_ld<frag>((base ^ (unsigned)(q << 5)) + jt * TS);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    const OpT* an = wbase + 8 * 512;  // tap 1
-    const OpT* const alast = wbase + (size_t)(ntaps - 1) * 8 * 512;
-    auto tap = [&](auto TI) {
-        constexpr int ti = decltype(TI)::value;  // >= 0: one of the first three taps (fillers), -1: the plain loop body
-        row_addr += (unsigned)(dil * RS2_STRIDE);
-        s = (s + dil) & 15;
-        const unsigned nbase = tap_base(row_addr, s);  // next tap (past the last one: rows behind the window, never used)
-        rs3_for<0, 8>([&](auto KK) {
-            constexpr int kk = decltype(KK)::value;
-            const unsigned nb = (kk + 2 < 8) ? (base ^ (unsigned)((kk + 2) << 5)) : (nbase ^ (unsigned)((kk + 2 - 8) << 5));
-            rs3_for<0, 3>([&](auto JT) {
-                constexpr int jt = decltype(JT)::value;
-                if constexpr (ZERO && ti == 0 && kk == 0) {
-                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    acc[jt] = Op<OpT>::mfma(A[kk], Bf[kk & 3][jt], z);
-                } else {
-                    acc[jt] = Op<OpT>::mfma(A[kk], Bf[kk & 3][jt], acc[jt]);
-                }
-                Bf[(kk + 2) & 3][jt] = lds_ld<frag>(nb + jt * TS);
-                if constexpr (jt == 2) A[kk] = rs2_wload<OpT>(an + kk * 512, loff);  // same k-step of the next tap
-                if constexpr (ti >= 0) fill(ic_t<ti * 24 + kk * 3 + jt>{});
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-        base = nbase;
-        an = (an < alast) ? an + 8 * 512 : an;  // clamped: the last tap re-requests itself
-    };
-    tap(ic_t<0>{});
-    tap(ic_t<1>{});
-    tap(ic_t<2>{});
-    for (int t = 3; t < ntaps; ++t) tap(ic_t<-1>{});
-}
 
 template <typename OpT>
 __device__ __forceinline__ unsigned rs3_pack2(float a, float b) {

@@ -258,18 +258,19 @@ def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
     har = gen.debug_tap("har", zd, fd, gd, noise=nd)
     rel = rms(har, taps["har"]) / float(taps["har"].pow(2).mean().sqrt())
     assert rel <= 1e-6, "har (sine source over 1198 voiced frames): relative RMS %.2e" % rel
-    # both streaming ResBlock kernels of the C = 128 stage on the whole clip: k_rb_stream and k_rb_stream3 (half-step slots)
-    for v3 in (0, 1):
-        o = pin(gen, RS_V3=v3)(zd, fd, gd, noise=nd).cpu()
-        assert torch.isfinite(o).all() and rms(o, d["out"]) <= 1e-3, "RS_V3=%d: RMS %.3e vs the reference waveform" % (v3, rms(o, d["out"]))
+    # every streaming ResBlock kernel of the C = 128 stage on the whole clip: k_rb_stream, k_rb_stream3 (half-step slots),
+    # k_rb_stream2x (two anti-phased strips per block, both K loops)
+    for small in ("0", "v3", "v2x", "v2x2"):
+        o = pin(gen, **_rs_opts(small))(zd, fd, gd, noise=nd).cpu()
+        assert torch.isfinite(o).all() and rms(o, d["out"]) <= 1e-3, "%s: RMS %.3e vs the reference waveform" % (small, rms(o, d["out"]))
         assert rms(o, out) <= 5e-4
-    pin(gen, RS_V3=None)
+    pin(gen, **{k: None for k in _rs_opts("0")})
     # exact-fp32 path on the same clip
     gen32 = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp32", max_B=1, max_T=1198)
     assert rms(gen32(zd, fd, gd, noise=nd).cpu(), d["out"]) <= 2e-5
 
 
-@pytest.mark.parametrize("rb_stream", ["0", "1", "v3"])
+@pytest.mark.parametrize("rb_stream", ["0", "1", "v3", "v2x"])
 def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu):
     """BASELINE configs[2] geometry (grid.z = batch, multi-GB streams, the large-batch launch shapes): 16 different full-size
     voiced clips in one call; every item must be BIT-equal to the same clip run alone -- with the ResBlock kernel family
@@ -288,7 +289,7 @@ def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu):
         ns.append(nsf_oracle.reference_noise(1, T, cfg.upp, 114514 + b))
     Z, F, G, N = torch.cat(zs).to(gpu), torch.cat(fs).to(gpu), torch.cat(gs).to(gpu), torch.cat(ns).to(gpu)
     gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T),
-              RB_STREAM=1 if rb_stream == "v3" else int(rb_stream), RS_V3=1 if rb_stream == "v3" else 0)
+              RB_STREAM=int(rb_stream) if rb_stream in "01" else 1, RS_V3=int(rb_stream == "v3"), RS_V2X=int(rb_stream == "v2x"))
     out = gen(Z, F, G, noise=N)
     assert out.shape == (B, 1, T * cfg.upp) and torch.isfinite(out).all()
     d = load_golden("full_v2_48k_T1198_voiced")
@@ -340,15 +341,22 @@ def test_batch_64_bench_config_3_geometry(gpu):
 # publish work in the MFMA shadow, k_rb_stream3 (csrc/rb_stream3_kernels.hpp), and its absence.
 
 def _rs_opts(small):
-    """test parameter -> (RS_SMALL, RS_V2, RS_V3)"""
+    """test parameter -> options of the streaming ResBlock launcher (every variant pinned on or off explicitly)"""
+    o = {"RS_SMALL": None, "RS_V2": 0, "RS_V3": 0, "RS_V2X": 0}
     if small == "v2":
-        return None, 1, 0
-    if small == "v3":
-        return None, None, 1
-    return int(small), None, 0
+        o["RS_V2"] = 1
+    elif small == "v3":
+        o["RS_V3"] = 1
+    elif small == "v2x":     # two anti-phased strips per 8-wave block, K loop with B fragments one k-step ahead
+        o["RS_V2X"] = 1
+    elif small == "v2x2":    # ... two k-steps ahead, one s_waitcnt per k-step
+        o["RS_V2X"] = 2
+    else:
+        o["RS_SMALL"] = int(small)
+    return o
 
 
-@pytest.mark.parametrize("small", ["0", "1", "v2", "v3"])
+@pytest.mark.parametrize("small", ["0", "1", "v2", "v3", "v2x", "v2x2"])
 @pytest.mark.parametrize("name", ["dec_v2_48k_B1_T70", "dec_v2_48k_B2_T24", "dec_v1_40k_B1_T20", "dec_v1_32k_B1_T16",
                                   "dec_nof0_v2_48k_B1_T16", "dec_v1_40k_nres_T31"])
 def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu):
@@ -356,18 +364,16 @@ def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu):
     cfg, w = golden_config_and_weights(d)
     for operand in ("fp16", "bf16"):
         gen = hip_gen(cfg, w, operand, gpu)
-        rs_small, rs_v2, rs_v3 = _rs_opts(small)
-        gen.set_option("RS_V2", rs_v2)
-        gen.set_option("RS_V3", rs_v3)
-        out = run_golden(d, cfg, w, operand, gpu, RB_STREAM=1, RS_SMALL=rs_small)
-        gen.set_option("RS_V2", None)
-        gen.set_option("RS_V3", None)
+        o = _rs_opts(small)
+        pin(gen, **o)
+        out = run_golden(d, cfg, w, operand, gpu, RB_STREAM=1, RS_SMALL=o["RS_SMALL"])
+        pin(gen, **{k: None for k in o})
         assert torch.isfinite(out).all()
         e = rms(out, d["out"])
         assert e <= BAR[operand], "%s/%s (streaming resblocks): RMS error %.3e" % (name, operand, e)
 
 
-@pytest.mark.parametrize("small", ["0", "1", "v2", "v3"])
+@pytest.mark.parametrize("small", ["0", "1", "v2", "v3", "v2x", "v2x2"])
 def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu):
     """Forced onto a clip of 300 frames: hundreds of strips of one to three steps each (every strip boundary, warm-up
     and tail case), batch of 2 with different inputs; per-stage taps and the waveform against the oracle."""
@@ -381,9 +387,7 @@ def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu):
     taps = {}
     with torch.no_grad():
         ref = nsf_oracle.generator_forward(cfg, w, z, f0, g, noise, taps=taps)
-    rs_small, rs_v2, rs_v3 = _rs_opts(small)
-    gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T), RB_STREAM=1,
-              RS_SMALL=rs_small, RS_V2=rs_v2, RS_V3=rs_v3)
+    gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T), RB_STREAM=1, **_rs_opts(small))
     zd, fd, gd, nd = z.to(gpu), f0.to(gpu), g.to(gpu), noise.to(gpu)
     out = gen(zd, fd, gd, noise=nd).cpu()
     assert rms(out, ref) <= 1e-3, "streaming resblocks, T=300 B=2: %.3e" % rms(out, ref)
