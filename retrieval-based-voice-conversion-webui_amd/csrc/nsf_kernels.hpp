@@ -689,6 +689,79 @@ __device__ __forceinline__ void conv_run(f32x16 (&acc)[MI][NJ], typename Op<OpT>
     }
 }
 
+// ---- the lean K loop (round 3) ---------------------------------------------------------------------------------------
+// conv_run's ring of NB groups of KGROUP k-steps pays a scalar/vector bookkeeping tail per group (one MFMA gap of ~9 and a tail
+// of ~14 instructions per 24 MFMAs): 37.0 cycles per MFMA for a lone wave against 34.0 for the same traffic without it
+// (tools/ubench/kloop2.hip).  kconv keeps that structure out of the loop:
+//   * weights are RAW BUFFER loads: SGPR resource + SGPR running offset + one lane offset VGPR + immediate -- no 64-bit per-lane
+//     address arithmetic at all;
+//   * the weight ring is 8 k-steps deep and refilled IN PLACE: A[kk] is re-requested for the k-step 8 later right after its last
+//     MFMA (twice the look-ahead of NB = 2 x KGROUP = 4 in the same registers), so the loop has no group structure;
+//   * B fragments come from the channels-last LDS tile through one base VGPR per 8 k-steps and immediate offsets.
+// For C_in a multiple of 128 (8 k-steps = a whole or half tap).  lds_row: LDS byte address of this lane's row at tap 0 (+ 16 for
+// the upper half-wave), rsrc / loff: this wave's first output-channel tile and lane * 16, ctb: bytes per output-channel tile.
+using lds_cptr_t = const __attribute__((address_space(3))) char*;
+__device__ __forceinline__ unsigned lds_address(const void* p) { return (unsigned)(size_t)(lds_cptr_t)p; }
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
+}
+template <typename OpT>
+__device__ __forceinline__ typename Op<OpT>::frag weight_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(typename Op<OpT>::frag, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+template <typename OpT, int MI>
+__device__ __forceinline__ void kconv_prefetch(typename Op<OpT>::frag (&A)[8][MI], __amdgpu_buffer_rsrc_t r, unsigned loff, unsigned ctb) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) A[kk][mi] = weight_load<OpT>(r, loff + kk * 1024, mi * ctb);
+}
+template <typename OpT, int CIN, int MI, int NJ, int STRIDE>
+__device__ __forceinline__ void kconv(f32x16 (&acc)[MI][NJ], typename Op<OpT>::frag (&A)[8][MI], unsigned lds_row, __amdgpu_buffer_rsrc_t r,
+                                      unsigned loff, unsigned ctb, int ntaps, int dstep) {
+    using frag = typename Op<OpT>::frag;
+    constexpr int CC = CIN / 16, GPT = CC / 8;  // k-steps per tap, groups of 8 k-steps per tap
+    static_assert(CIN % 128 == 0, "kconv: C_in must be a multiple of 128");
+    constexpr unsigned TS = 32u * STRIDE;
+    auto ld = [](unsigned a) { return *(const __attribute__((address_space(3))) frag*)(size_t)a; };
+    frag Bf[2][NJ];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        Bf[0][jt] = ld(lds_row + jt * TS);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned dS = (unsigned)(dstep * STRIDE);
+    const int ngroups = ntaps * GPT;
+    const unsigned slast = (unsigned)(ngroups - 1) * 8192u;
+    unsigned soff = ngroups > 1 ? 8192u : 0u;  // byte offset of the group being requested (clamped: the last one re-requests itself)
+    int gi = 0;                                // group inside the tap
+    for (int g = 0; g < ngroups; ++g) {
+        const unsigned nrow = (gi + 1 == GPT) ? lds_row - (unsigned)((GPT - 1) * 256) + dS : lds_row + 256u;  // next group's first k-step
+        // (opaque copies: loop strength reduction otherwise rebases every read on the POST-increment pointer with negative
+        //  offsets, which do not fit the ds_read offset field -- one v_add per MFMA)
+        unsigned b0 = lds_row, b1 = nrow;
+        asm volatile("" : "+v"(b0), "+v"(b1));
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) {
+                    constexpr int NS = MI * NJ;
+                    const int i = mi * NJ + jt;
+                    acc[mi][jt] = Op<OpT>::mfma(A[kk][mi], Bf[kk & 1][jt], acc[mi][jt]);
+                    if (i < NJ) Bf[(kk + 1) & 1][i] = ld((kk < 7 ? b0 + (unsigned)((kk + 1) * 32) : b1) + i * TS);
+                    if (i >= NS - MI) A[kk][i - (NS - MI)] = weight_load<OpT>(r, loff + kk * 1024, soff + (unsigned)(i - (NS - MI)) * ctb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        lds_row = nrow;
+        gi = (gi + 1 == GPT) ? 0 : gi + 1;
+        soff = soff < slast ? soff + 8192u : soff;
+    }
+}
+
 template <typename OpT, int CIN, int MI, int NJ, int KGROUP = ::rvcmi::KGROUP, int NB = 2>
 __device__ __forceinline__ void conv_core(f32x16 (&acc)[MI][NJ], const char* lds_lane, const OpT* wlane,
                                           long ct_stride, int ntaps_p, int roff, int dstep) {

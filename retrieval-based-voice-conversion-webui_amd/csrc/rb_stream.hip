@@ -51,13 +51,13 @@ bool geo_for(int C, int nd, Geo& g, const Options& opt, int ver = 1) {
 
 // nblocks < 0: only make sure the > 64 KB dynamic-LDS attribute is set on the current device (once per device and instantiation;
 // done at handle creation so that a first forward inside a stream capture does not have to)
-template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG = 4, int NB = 2, int OCC = 1>
+template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG = 4, int NB = 2, int OCC = 1, int KL = 1>
 void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
-    auto kern = &k_rb_stream<OpT, C, MI, NJ, NCO, ND, KG, NB, OCC>;
+    auto kern = &k_rb_stream<OpT, C, MI, NJ, NCO, ND, KG, NB, OCC, KL>;
     if (!(attr_done.load() & bit)) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.fetch_or(bit);
@@ -130,6 +130,7 @@ void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, 
     if (C == 256 && nd == 1 && NJ == 3) return launch_inst<OpT, 256, 2, 3, 4, 1>(a, nblocks, B, smem, st);
     if (C == 128 && nd == 3 && NJ == 8) return launch_inst<OpT, 128, 1, 8, 4, 3>(a, nblocks, B, smem, st);
     // (weight ring 3 / 4 groups deep instead of 2: 65 / 129 spilled registers, 0.70 -> 0.77 / 0.89 ms -- measured, not kept)
+    if (C == 128 && nd == 3 && NJ == 6 && (a.flags & 4)) return launch_inst<OpT, 128, 1, 6, 4, 3, RS_KG128, RS_NB128, 1, 2>(a, nblocks, B, smem, st);  // lean K loop
     if (C == 128 && nd == 3 && NJ == 6) return launch_inst<OpT, 128, 1, 6, 4, 3, RS_KG128, RS_NB128>(a, nblocks, B, smem, st);
     RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: no instantiation for C=%d nd=%d", C, nd);
 }
@@ -161,6 +162,10 @@ void rb_stream_prepare() {
         launch_t<__bf16>(128, 3, nj, a, -1, 1, 0, nullptr);
         launch_t<_Float16>(128, 3, nj, a, -1, 1, 0, nullptr);
     }
+    a.flags = 4;  // the lean-K-loop instantiation of NJ = 6
+    launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr);
+    launch_t<_Float16>(128, 3, 6, a, -1, 1, 0, nullptr);
+    a.flags = 0;
     launch_t<__bf16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
     launch_t<_Float16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
     launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr, 3);
@@ -180,6 +185,9 @@ bool rb_stream_supported(int operand, int C, int nd) {
 
 static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B,
                        long bstride, hipStream_t st, const Options& opt, bool dry_run);
+#ifndef RS_KL_DEFAULT
+#define RS_KL_DEFAULT 1
+#endif
 #ifndef RS_V2X_DEFAULT
 #define RS_V2X_DEFAULT 0
 #endif
@@ -332,6 +340,7 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
         min_steps = std::min(min_steps, steps);
     }
     a.side_rows = side_rows;
+    if (g.ver == 1 && opt.geti("RS_KL", RS_KL_DEFAULT) == 2) a.flags = 4;  // k_rb_stream with the lean K loop (kconv)
     if (g.ver == 4) a.flags = opt.geti("RS_V2X", RS_V2X_DEFAULT) == 2 ? 2 : 0;  // RS_V2X = 2: the K loop with B two k-steps ahead
     if (g.ver == 2) {  // RS_SKEW = units of 1024 cycles per (k + 3), RS_PRIO = 1: s_setprio inside the K loops
         a.skew = opt.geti("RS_SKEW", 2);

@@ -64,7 +64,8 @@ __device__ __forceinline__ void rs_copy_rows(char* dst, const char* src, int row
     for (int i = threadIdx.x; i < total; i += NT) *(uint4*)(dst + (size_t)i * 16) = *(const uint4*)(src + (size_t)i * 16);
 }
 
-template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG, int NB, int OCC = 1>
+// KL = 2: the lean K loop kconv (nsf_kernels.hpp) instead of conv_prefetch / conv_run
+template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG, int NB, int OCC = 1, int KL = 1>
 static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs a) {
     using TL = Tile<C>;
     using frag = typename Op<OpT>::frag;
@@ -113,7 +114,7 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
     const int r0 = S0 - HL;                                       // first row loaded by step 0
     const int nsteps = (S1 - r0 + 32 * ND + R - 1) / R;
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // wave: scalar (SGPR weight bases)
     const int ct0 = wave * MI;               // first 32-channel output tile of this wave
     const int half4 = 4 * (lane >> 5);
     const int lrow = lane & 31;
@@ -141,6 +142,15 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
     };
     if (stamps) tprev = __builtin_readcyclecounter();
 
+    auto bar = [] {  // KL = 2: a barrier that does not drain the prefetched weight fragments (lds_barrier, below)
+        if constexpr (KL == 2) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        } else {
+            __syncthreads();
+        }
+    };
     f32x16 carry[ND][MI];
 #pragma unroll
     for (int m = 0; m < ND; ++m)
@@ -150,7 +160,18 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
             for (int e = 0; e < 16; ++e) carry[m][mi][e] = 0.f;
 
     frag A[NB][KG][MI];  // weight register ring, requested one phase ahead of its use
-    conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w1[0] + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p);
+    frag A8[8][MI];      // ... of the lean loop (KL = 2)
+    const unsigned loff = (unsigned)lane * 16u;
+    const unsigned ctb1 = (unsigned)(J.ct1 * 2), ctb2 = (unsigned)(J.ct2 * 2);
+    auto prefetch = [&](const OpT* wl, long ct, unsigned ctb) {  // wl: this wave's first output-channel tile (wave-uniform)
+        if constexpr (KL == 2) kconv_prefetch<OpT, MI>(A8, weight_rsrc(wl), loff, ctb);
+        else conv_prefetch<OpT, C, MI, KG, NB>(A, wl + lane * 8, ct, J.k_p);
+    };
+    auto run = [&](f32x16 (&acc)[MI][NJ], const char* lds_lane, const OpT* wl, long ct, unsigned ctb, int dstep) {
+        if constexpr (KL == 2) kconv<OpT, C, MI, NJ, STRIDE>(acc, A8, lds_address(lds_lane), weight_rsrc(wl), loff, ctb, J.k, dstep);
+        else conv_run<OpT, C, MI, NJ, KG, NB>(acc, A, lds_lane, wl + lane * 8, ct, J.k_p, 0, dstep);
+    };
+    prefetch((const OpT*)J.w1[0] + (size_t)ct0 * J.ct1, J.ct1, ctb1);
     __syncthreads();
 
     for (int step = 0; step < nsteps; ++step) {
@@ -183,11 +204,28 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
             const bool interior = wm - 32 >= 0 && wm + R <= L;  // block-uniform: every row of the X and H windows is inside the utterance
             char* sideX = side + (size_t)J.sx_off[m] * STRIDE;
             char* sideH = side + (size_t)J.sh_off[m] * STRIDE;
-            const OpT* w1l = (const OpT*)J.w1[m] + (size_t)ct0 * J.ct1 + lane * 8;
-            const OpT* w2l = (const OpT*)J.w2[m] + (size_t)ct0 * J.ct2 + lane * 8;
+            const OpT* w1l = (const OpT*)J.w1[m] + (size_t)ct0 * J.ct1;
+            const OpT* w2l = (const OpT*)J.w2[m] + (size_t)ct0 * J.ct2;
 
             // ---- phase A: M <- [H head | X head | lrelu(x) new rows] ---------------------------------------------------
-            rs_copy_rows<STRIDE, NT>(M + (size_t)(RS_HEAD - Hx) * STRIDE, sideX, Hx);
+            // KL = 2: the X tail is not copied out after conv1 any more; the publish writes its last Hx rows a second time into the
+            // history buffer ("dual write", as k_rb_stream2) and the X head is restored WAVE-PRIVATELY -- each wave moves its own
+            // 32 * MI channels, reads issued before its own dual writes (a wave's LDS operations execute in order) -- so the two
+            // do not race without a barrier.  Saves the Hx-row LDS -> LDS copy of phase B.
+            constexpr int WB = 64 * MI;            // bytes of a row owned by one wave
+            constexpr int WCH = WB / 16;           // ... in 16-byte chunks
+            constexpr int RPI = 64 / WCH;          // history rows one wave moves per instruction
+            constexpr int NIT = (52 + RPI - 1) / RPI;
+            uint4 hb[KL == 2 ? NIT : 1];
+            if constexpr (KL == 2) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int i = min(it * RPI + lane / WCH, Hx - 1);
+                    hb[it] = *(const uint4*)(sideX + (size_t)i * STRIDE + ct0 * 64 + (lane % WCH) * 16);
+                }
+            } else {
+                rs_copy_rows<STRIDE, NT>(M + (size_t)(RS_HEAD - Hx) * STRIDE, sideX, Hx);
+            }
             rs_copy_rows<STRIDE, NT>(M + (size_t)(RS_HROW - 2 * p2) * STRIDE, sideH, 2 * p2);
             {
                 unsigned rowmask[NJ];
@@ -199,6 +237,27 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
                 char* xw = M + (size_t)(RS_HEAD + lrow) * STRIDE + (ct0 * 32 + half4) * 2;
                 if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(xw, xin, rowmask);
                 else publish_operand<OpT, C, MI, NJ, STRIDE, true>(xw, xin, rowmask);
+                if constexpr (KL == 2) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int i = min(it * RPI + lane / WCH, Hx - 1);
+                        *(uint4*)(M + (size_t)(RS_HEAD - Hx + i) * STRIDE + ct0 * 64 + (lane % WCH) * 16) = hb[it];
+                    }
+                    // dual write: new rows [R - Hx, R) -> history rows [0, Hx)   (Hx <= 52 < 64: tiles NJ-2 and NJ-1 only)
+#pragma unroll
+                    for (int jt = NJ - 2; jt < NJ; ++jt) {
+                        const int srow = jt * 32 + lrow - (R - Hx);
+                        char* tw = (srow >= 0 ? sideX + (size_t)srow * STRIDE : dump) + (ct0 * 32 + half4) * 2;
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x16& t = xin[mi][jt];
+                                *(uint2*)(tw + (mi * 32 + 8 * g) * 2) =
+                                    pack4_lrelu<OpT, true>(t[4 * g + 0], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3], rowmask[jt]);
+                            }
+                    }
+                }
             }
             // residual tiles of this pair's output window (= input window - 32 rows): pure register renaming
             f32x16 res[MI][NJ];
@@ -210,7 +269,7 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
                 carry[m][mi] = xin[mi][NJ - 1];
             }
             stamp(0);  // phase A (waits for the x loads when m == 0)
-            __syncthreads();
+            bar();
             stamp(1);
 
             // ---- conv1 (dilated): h rows [a_m, a_m + R), a_m = wm - 32 + p2 ---------------------------------------------
@@ -228,14 +287,14 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
                             for (int e = 0; e < 4; ++e) hacc[mi][jt][4 * g + e] = bv[e];
                     }
             }
-            conv_run<OpT, C, MI, NJ, KG, NB>(hacc, A, M + (size_t)(RS_HEAD - Hx + lrow) * STRIDE + (lane >> 5) * 16, w1l, J.ct1, J.k_p, 0, dil);
-            conv_prefetch<OpT, C, MI, KG, NB>(A, w2l, J.ct2, J.k_p);  // in flight across the publish + barriers
+            run(hacc, M + (size_t)(RS_HEAD - Hx + lrow) * STRIDE + (lane >> 5) * 16, w1l, J.ct1, ctb1, dil);
+            prefetch(w2l, J.ct2, ctb2);  // in flight across the publish + barriers
             stamp(2);  // conv1
-            __syncthreads();  // every wave is done reading X
+            bar();  // every wave is done reading X
             stamp(3);
 
             // ---- phase B: save the X tail, M <- lrelu(h) new rows (+ their tail into the H history) ----------------------
-            rs_copy_rows<STRIDE, NT>(sideX, M + (size_t)(RS_HEAD + R - Hx) * STRIDE, Hx);
+            if constexpr (KL != 2) rs_copy_rows<STRIDE, NT>(sideX, M + (size_t)(RS_HEAD + R - Hx) * STRIDE, Hx);
             {
                 const int am = wm - 32 + p2;
                 unsigned rowmask[NJ];
@@ -260,7 +319,7 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
                     }
             }
             stamp(4);  // phase B
-            __syncthreads();
+            bar();
             stamp(5);
 
             // ---- conv2 accumulates onto the residual: x' rows [wm - 32, wm - 32 + R) ------------------------------------
@@ -277,13 +336,13 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
                             for (int e = 0; e < 4; ++e) res[mi][jt][4 * g + e] += bv[e];
                     }
             }
-            conv_run<OpT, C, MI, NJ, KG, NB>(res, A, M + (size_t)(RS_HROW - 2 * p2 + lrow) * STRIDE + (lane >> 5) * 16, w2l, J.ct2, J.k_p, 0, 1);
+            run(res, M + (size_t)(RS_HROW - 2 * p2 + lrow) * STRIDE + (lane >> 5) * 16, w2l, J.ct2, ctb2, 1);
             {  // next conv1's weights (next pair, or pair 0 of the next step)
                 const int mn = (m + 1 < ND) ? m + 1 : 0;
-                conv_prefetch<OpT, C, MI, KG, NB>(A, (const OpT*)J.w1[mn] + (size_t)ct0 * J.ct1 + lane * 8, J.ct1, J.k_p);
+                prefetch((const OpT*)J.w1[mn] + (size_t)ct0 * J.ct1, J.ct1, ctb1);
             }
             stamp(6);  // conv2
-            __syncthreads();  // every wave is done reading H
+            bar();  // every wave is done reading H
             stamp(7);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)

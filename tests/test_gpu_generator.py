@@ -260,7 +260,7 @@ def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
     assert rel <= 1e-6, "har (sine source over 1198 voiced frames): relative RMS %.2e" % rel
     # every streaming ResBlock kernel of the C = 128 stage on the whole clip: k_rb_stream, k_rb_stream3 (half-step slots),
     # k_rb_stream2x (two anti-phased strips per block, both K loops)
-    for small in ("0", "v3", "v2x", "v2x2"):
+    for small in ("1", "kl2", "v3", "v2x", "v2x2"):
         o = pin(gen, **_rs_opts(small))(zd, fd, gd, noise=nd).cpu()
         assert torch.isfinite(o).all() and rms(o, d["out"]) <= 1e-3, "%s: RMS %.3e vs the reference waveform" % (small, rms(o, d["out"]))
         assert rms(o, out) <= 5e-4
@@ -270,7 +270,7 @@ def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
     assert rms(gen32(zd, fd, gd, noise=nd).cpu(), d["out"]) <= 2e-5
 
 
-@pytest.mark.parametrize("rb_stream", ["0", "1", "v3", "v2x"])
+@pytest.mark.parametrize("rb_stream", ["0", "1", "v3", "v2x", "kl2"])
 def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu):
     """BASELINE configs[2] geometry (grid.z = batch, multi-GB streams, the large-batch launch shapes): 16 different full-size
     voiced clips in one call; every item must be BIT-equal to the same clip run alone -- with the ResBlock kernel family
@@ -289,7 +289,8 @@ def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu):
         ns.append(nsf_oracle.reference_noise(1, T, cfg.upp, 114514 + b))
     Z, F, G, N = torch.cat(zs).to(gpu), torch.cat(fs).to(gpu), torch.cat(gs).to(gpu), torch.cat(ns).to(gpu)
     gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T),
-              RB_STREAM=int(rb_stream) if rb_stream in "01" else 1, RS_V3=int(rb_stream == "v3"), RS_V2X=int(rb_stream == "v2x"))
+              RB_STREAM=int(rb_stream) if rb_stream in "01" else 1, RS_V3=int(rb_stream == "v3"), RS_V2X=int(rb_stream == "v2x"),
+              RS_KL=2 if rb_stream == "kl2" else 1)
     out = gen(Z, F, G, noise=N)
     assert out.shape == (B, 1, T * cfg.upp) and torch.isfinite(out).all()
     d = load_golden("full_v2_48k_T1198_voiced")
@@ -342,7 +343,7 @@ def test_batch_64_bench_config_3_geometry(gpu):
 
 def _rs_opts(small):
     """test parameter -> options of the streaming ResBlock launcher (every variant pinned on or off explicitly)"""
-    o = {"RS_SMALL": None, "RS_V2": 0, "RS_V3": 0, "RS_V2X": 0}
+    o = {"RS_SMALL": None, "RS_V2": 0, "RS_V3": 0, "RS_V2X": 0, "RS_KL": 1}
     if small == "v2":
         o["RS_V2"] = 1
     elif small == "v3":
@@ -351,12 +352,14 @@ def _rs_opts(small):
         o["RS_V2X"] = 1
     elif small == "v2x2":    # ... two k-steps ahead, one s_waitcnt per k-step
         o["RS_V2X"] = 2
+    elif small == "kl2":     # k_rb_stream with the lean K loop (kconv), dual-written X tail, LDS-only barriers
+        o["RS_SMALL"], o["RS_KL"] = 1, 2
     else:
         o["RS_SMALL"] = int(small)
     return o
 
 
-@pytest.mark.parametrize("small", ["0", "1", "v2", "v3", "v2x", "v2x2"])
+@pytest.mark.parametrize("small", ["0", "1", "v2", "v3", "v2x", "v2x2", "kl2"])
 @pytest.mark.parametrize("name", ["dec_v2_48k_B1_T70", "dec_v2_48k_B2_T24", "dec_v1_40k_B1_T20", "dec_v1_32k_B1_T16",
                                   "dec_nof0_v2_48k_B1_T16", "dec_v1_40k_nres_T31"])
 def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu):
@@ -373,7 +376,7 @@ def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu):
         assert e <= BAR[operand], "%s/%s (streaming resblocks): RMS error %.3e" % (name, operand, e)
 
 
-@pytest.mark.parametrize("small", ["0", "1", "v2", "v3", "v2x", "v2x2"])
+@pytest.mark.parametrize("small", ["0", "1", "v2", "v3", "v2x", "v2x2", "kl2"])
 def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu):
     """Forced onto a clip of 300 frames: hundreds of strips of one to three steps each (every strip boundary, warm-up
     and tail case), batch of 2 with different inputs; per-stage taps and the waveform against the oracle."""

@@ -9,7 +9,7 @@ using namespace rvcmi;
 #ifndef VARIANT
 #define VARIANT 0
 #endif
-template <int C, int MI, int NJ, int KG, int NB, bool SHARED = false, int NWV = 4>
+template <int C, int MI, int NJ, int KG, int NB, bool SHARED = false, int NWV = 4, int KL = 1>
 __global__ void __launch_bounds__(64 * NWV, 1) kloop(const _Float16* w, long ct, int k_p, int dil, int reps, int dbg, float* out,
                                                 unsigned long long* ticks) {
     using TL = Tile<C>;
@@ -22,20 +22,33 @@ __global__ void __launch_bounds__(64 * NWV, 1) kloop(const _Float16* w, long ct,
     f32x16 acc[MI][NJ];
     for (int mi = 0; mi < MI; ++mi) for (int jt = 0; jt < NJ; ++jt) for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
     typename Op<_Float16>::frag A[NB][KG][MI];
-    if (SHARED) w += (size_t)(wave & 3) * MI * ct;  // each wave streams its own output-channel slice
-    conv_prefetch<_Float16, C, MI, KG, NB>(A, w + lane * 8, ct, k_p);
-    unsigned long long t0 = __builtin_readcyclecounter();
-    for (int r = 0; r < reps; ++r) {
-        conv_run<_Float16, C, MI, NJ, KG, NB>(acc, A, xl, w + lane * 8, ct, k_p, 32 - dil * (k_p - 1) / 2, dil, dbg);
+    typename Op<_Float16>::frag A8[8][MI];
+    if (SHARED) w += (size_t)__builtin_amdgcn_readfirstlane(wave & 3) * MI * ct;  // each wave streams its own output-channel slice
+    unsigned long long t0, t1;
+    if constexpr (KL == 2) {  // the lean loop (kconv): raw buffer loads, in-place 8-deep ring
+        const __amdgpu_buffer_rsrc_t r = weight_rsrc(w);
+        kconv_prefetch<_Float16, MI>(A8, r, lane * 16, (unsigned)(ct * 2));
+        t0 = __builtin_readcyclecounter();
+        for (int rr = 0; rr < reps; ++rr) {
+            kconv<_Float16, C, MI, NJ, TL::STRIDE>(acc, A8, lds_address(xl + (32 - dil * (k_p - 1) / 2) * TL::STRIDE), r, lane * 16, (unsigned)(ct * 2), k_p, dil);
+            kconv_prefetch<_Float16, MI>(A8, r, lane * 16, (unsigned)(ct * 2));
+        }
+        t1 = __builtin_readcyclecounter();
+    } else {
         conv_prefetch<_Float16, C, MI, KG, NB>(A, w + lane * 8, ct, k_p);
+        t0 = __builtin_readcyclecounter();
+        for (int r = 0; r < reps; ++r) {
+            conv_run<_Float16, C, MI, NJ, KG, NB>(acc, A, xl, w + lane * 8, ct, k_p, 32 - dil * (k_p - 1) / 2, dil, dbg);
+            conv_prefetch<_Float16, C, MI, KG, NB>(A, w + lane * 8, ct, k_p);
+        }
+        t1 = __builtin_readcyclecounter();
     }
-    unsigned long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
     for (int mi = 0; mi < MI; ++mi) for (int jt = 0; jt < NJ; ++jt) for (int e = 0; e < 16; ++e) s += acc[mi][jt][e];
     out[blockIdx.x * 64 * NWV + threadIdx.x] = s;
     if (lane == 0) ticks[blockIdx.x * NWV + wave] = t1 - t0;
 }
-template <int C, int MI, int NJ, int KG, int NB, bool SHARED = false, int NWV = 4>
+template <int C, int MI, int NJ, int KG, int NB, bool SHARED = false, int NWV = 4, int KL = 1>
 void run(int k, int dil, int dbg) {
     using TL = Tile<C>;
     const int CC = C / 16;
@@ -49,16 +62,16 @@ void run(int k, int dil, int dbg) {
     hipMalloc(&w, hw.size() * 2); hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     hipMalloc(&out, blocks * 64 * NWV * 4); hipMalloc(&ticks, blocks * NWV * 8);
     const size_t smem = (size_t)((SHARED ? 1 : 4) * 32 * NJ + 64) * TL::STRIDE;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&kloop<C, MI, NJ, KG, NB, SHARED, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB, SHARED, NWV>), dim3(blocks), dim3(64 * NWV), smem, 0, w, ct, k_p, dil, 2, dbg, out, ticks);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&kloop<C, MI, NJ, KG, NB, SHARED, NWV, KL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB, SHARED, NWV, KL>), dim3(blocks), dim3(64 * NWV), smem, 0, w, ct, k_p, dil, 2, dbg, out, ticks);
     hipDeviceSynchronize();
-    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB, SHARED, NWV>), dim3(blocks), dim3(64 * NWV), smem, 0, w, ct, k_p, dil, reps, dbg, out, ticks);
+    hipLaunchKernelGGL((kloop<C, MI, NJ, KG, NB, SHARED, NWV, KL>), dim3(blocks), dim3(64 * NWV), smem, 0, w, ct, k_p, dil, reps, dbg, out, ticks);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(blocks * NWV);
     hipMemcpy(h.data(), ticks, h.size() * 8, hipMemcpyDeviceToHost);
     double avg = 0; for (auto v : h) avg += v; avg /= h.size();
     const double nm = (double)reps * k_p * CC * MI * NJ;
-    printf("C=%d MI=%d NJ=%d KG=%d NB=%d waves=%d k=%d dil=%d: %.1f cycles/MFMA per wave = %.1f per SIMD-MFMA (%.0f cycles per conv)\n", C, MI, NJ, KG, NB, NWV, k, dil,
+    printf("%sC=%d MI=%d NJ=%d KG=%d NB=%d waves=%d k=%d dil=%d: %.1f cycles/MFMA per wave = %.1f per SIMD-MFMA (%.0f cycles per conv)\n", KL == 2 ? "[kconv] " : "", C, MI, NJ, KG, NB, NWV, k, dil,
            avg / nm, avg / nm / (NWV / 4), avg / reps);
     hipFree(w); hipFree(out); hipFree(ticks);
 }
@@ -71,6 +84,9 @@ int main() {
 #ifdef RVCMI_KLOOP_ABLATE
     printf("ABLATE=%d (1: no weight loads, 2: no B reads)\n", RVCMI_KLOOP_ABLATE);
 #endif
+    run<128, 1, 6, 4, 2, true, 4, 2>(11, 5, 0);
+    run<128, 1, 6, 4, 2, true, 4, 2>(3, 1, 0);
+    run<128, 1, 6, 4, 2, true>(3, 1, 0);
     // latency hypothesis: is the K loop bound by the weight loads' L2 latency vs the ring's prefetch distance ((NB-1) * KG k-steps)?
     run<128, 1, 6, 4, 2, true>(11, 5, 0);
     run<128, 1, 6, 4, 3, true>(11, 5, 0);
