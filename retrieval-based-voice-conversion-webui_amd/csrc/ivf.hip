@@ -452,6 +452,52 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
     }
 }
 
+// ---- list-sorted query order (nprobe == 1) ------------------------------------------------------------------------------
+// The scan is one block per query.  On the benchmark index 599 queries probe 26 lists (16.5 MB of list rows) and walk 568 MB
+// of them; with queries in arrival order every XCD's 4 MB L2 sees all 26 lists, misses, and the launch runs at the ~7.5 TB/s the
+// Infinity Cache delivers (76 us).  Sorting the queries by probed list (counting sort: histogram, one-block exclusive scan,
+// scatter -- the order INSIDE a list is whatever the atomics give, results do not depend on it) and handing every XCD one
+// contiguous range of the sorted order (hardware puts block b on XCD b % 8) leaves each L2 with an eighth of the lists.
+__global__ void __launch_bounds__(256) k_qsort_hist(const int64_t* __restrict__ assign, int64_t nq, int64_t nlist, int* __restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    const int64_t l = assign[i];
+    atomicAdd(&cnt[(l < 0 || l >= nlist) ? nlist : l], 1);  // bucket nlist: queries without a list
+}
+__global__ void __launch_bounds__(1024) k_qsort_scan(int* __restrict__ cnt, int64_t n) {  // in place: counts -> exclusive offsets
+    __shared__ int part[1024];
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t b = (int64_t)threadIdx.x * per, e = b + per < n ? b + per : n;
+    int s = 0;
+    for (int64_t i = b; i < e; ++i) s += cnt[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int64_t i = b; i < e; ++i) {
+        const int c = cnt[i];
+        cnt[i] = run;
+        run += c;
+    }
+}
+__global__ void __launch_bounds__(256) k_qsort_scatter(const int64_t* __restrict__ assign, int64_t nq, int64_t nlist, int* __restrict__ off,
+                                                       int* __restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    const int64_t l = assign[i];
+    perm[atomicAdd(&off[(l < 0 || l >= nlist) ? nlist : l], 1)] = (int)i;
+}
+// logical index of block b when every XCD (b % 8) takes one contiguous range of [0, nb)
+__device__ __forceinline__ int64_t xcd_contiguous(int64_t b, int64_t nb) {
+    const int64_t q = nb >> 3, r = nb & 7, xcd = b & 7, slot = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 // Specialised scan for d = 64*V (V = 12 for the 768-d v2 index, 4 for the 256-d v1 index): the query chunk of each
 // lane lives in registers, every load of TWO rows is in flight before anything is consumed (one memory round trip per
 // pair of rows instead of three per row), row indices are clamped so no load sits behind a branch.
@@ -466,7 +512,8 @@ __global__ void __launch_bounds__(256, 3) k_scan_v(const float* q, const int64_t
                                                    const int64_t* __restrict__ list_off, const int64_t* __restrict__ ids,
                                                    const float* __restrict__ vecs, int64_t nq, int k, float* __restrict__ D,
                                                    int64_t* __restrict__ I, int64_t* __restrict__ P, int* __restrict__ any_short,
-                                                   float* bfeats, float rate, float omr, int64_t pos_last, unsigned long long* ts = nullptr) {
+                                                   float* bfeats, float rate, float omr, int64_t pos_last, unsigned long long* ts = nullptr,
+                                                   const int* __restrict__ perm = nullptr) {
     constexpr int d = LPR * 4 * VL;
     // dev only: wall-clock stamps of block 0's phases (RVCMI_IVF_STAMPS=1)
     auto stamp = [&](int i) {
@@ -478,11 +525,19 @@ __global__ void __launch_bounds__(256, 3) k_scan_v(const float* q, const int64_t
     constexpr int G = 256 / LPR;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     TopK* merge = (TopK*)smem_raw;
-    const int64_t qi = blockIdx.x;
+    const int64_t qi = perm ? (int64_t)perm[xcd_contiguous(blockIdx.x, gridDim.x)] : (int64_t)blockIdx.x;  // list-sorted order, one range per XCD
     const int grp = threadIdx.x / LPR, sub = threadIdx.x % LPR;
-    float4 qv[VL];
+    // the query chunk of this lane, converted to fp64 ONCE (it used to be re-converted for every row: one of the four fp64-rate
+    // instructions per element)
+    double qd[VL][4];
 #pragma unroll
-    for (int i = 0; i < VL; ++i) qv[i] = *(const float4*)(q + qi * d + (sub + LPR * i) * 4);
+    for (int i = 0; i < VL; ++i) {
+        const float4 t4 = *(const float4*)(q + qi * d + (sub + LPR * i) * 4);
+        qd[i][0] = (double)t4.x;
+        qd[i][1] = (double)t4.y;
+        qd[i][2] = (double)t4.z;
+        qd[i][3] = (double)t4.w;
+    }
     // the group's running top-8 lives in LDS and is maintained by the group's first lane: keeping it in registers (48 per
     // lane, all lanes) plus the unrolled compare-swap network cost ~100 VGPRs; a list has only 2-3 rows per group
     TopK& t = merge[grp];
@@ -518,8 +573,8 @@ __global__ void __launch_bounds__(256, 3) k_scan_v(const float* q, const int64_t
                 double acc = 0.0;
 #pragma unroll
                 for (int i = 0; i < VL; ++i) {
-                    const double t0 = (double)qv[i].x - (double)v[u][i].x, t1 = (double)qv[i].y - (double)v[u][i].y;
-                    const double t2 = (double)qv[i].z - (double)v[u][i].z, t3 = (double)qv[i].w - (double)v[u][i].w;
+                    const double t0 = qd[i][0] - (double)v[u][i].x, t1 = qd[i][1] - (double)v[u][i].y;
+                    const double t2 = qd[i][2] - (double)v[u][i].z, t3 = qd[i][3] - (double)v[u][i].w;
                     acc = fma(t0, t0, acc);
                     acc = fma(t1, t1, acc);
                     acc = fma(t2, t2, acc);
@@ -731,13 +786,13 @@ struct rvcmi_ivf {
     // search workspace (grown on demand; see rvcmi_ivf_reserve)
     int64_t cap_nq = 0;
     int cap_nprobe = 0;
-    DevBuf assign, P, Dtmp, Itmp, flag, cdist, cscore;
+    DevBuf assign, P, Dtmp, Itmp, flag, cdist, cscore, qcnt, qperm;
     int64_t cap_chunk = 0;  // queries per coarse-score chunk (bounds the nq x nlist fp32 scratch)
     Profiler prof;
     // dev / test options (common.hpp Options): IVF_COARSE_F64 (brute-force fp64 coarse quantizer), IVF_GENERIC (any-d scan kernel),
-    // IVF_STAMPS (prints; syncs), IVF_DBG.  Read from RVCMI_<KEY> once at handle creation; later only rvcmi_ivf_set_option.
+    // IVF_STAMPS (prints; syncs), IVF_DBG, IVF_SORT (0 = scan the queries in arrival order).  Read from RVCMI_<KEY> once at handle creation; later only rvcmi_ivf_set_option.
     rvcmi::Options opt;
-    rvcmi_ivf() { opt.load_env({"IVF_COARSE_F64", "IVF_GENERIC", "IVF_STAMPS", "IVF_DBG"}); }
+    rvcmi_ivf() { opt.load_env({"IVF_COARSE_F64", "IVF_GENERIC", "IVF_STAMPS", "IVF_DBG", "IVF_SORT"}); }
     const float* centroids() const { return (const float*)(blob + hdr.off_centroids); }
     const float4* centroids_t() const { return (const float4*)(blob + hdr.off_centroids_t); }
     const float* cnorm() const { return (const float*)(blob + hdr.off_cnorm); }
@@ -993,6 +1048,8 @@ static void reserve(rvcmi_ivf* h, int64_t nq) {
     h->Dtmp.alloc((size_t)std::max<int64_t>(nq, 1) * KMAX * 4);
     h->Itmp.alloc((size_t)std::max<int64_t>(nq, 1) * KMAX * 8);
     if (!h->flag.p) h->flag.alloc(256);
+    h->qcnt.alloc((size_t)(h->hdr.nlist + 1) * 4);
+    h->qperm.alloc((size_t)std::max<int64_t>(nq, 1) * 4);
     if (np > 1) h->cdist.alloc((size_t)std::max<int64_t>(nq, 1) * h->hdr.nlist * 8);
     else {
         const int64_t per = std::max<int64_t>(64, (int64_t)(512ll << 20) / (h->hdr.nlist * 4));  // <= 512 MiB of scores
@@ -1056,6 +1113,18 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
                                h->assign.as<int64_t>());
         });
     }
+    // list-sorted, XCD-contiguous query order for the specialised scans (see k_qsort_hist)
+    const int* perm = nullptr;
+    if (np == 1 && nq >= 64 && nq < (1ll << 31) && (d == 768 || d == 256) && !h->opt.on("IVF_GENERIC") && h->opt.geti("IVF_SORT", 1)) {
+        h->prof.launch("ivf_sort", 0.0, (double)nq * 16 + (double)b.nlist * 8, st, [&] {
+            HIP_CHECK(hipMemsetAsync(h->qcnt.p, 0, (size_t)(b.nlist + 1) * 4, st));
+            hipLaunchKernelGGL(k_qsort_hist, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, h->assign.as<int64_t>(), nq, b.nlist, h->qcnt.as<int>());
+            hipLaunchKernelGGL(k_qsort_scan, dim3(1), dim3(1024), 0, st, h->qcnt.as<int>(), b.nlist + 1);
+            hipLaunchKernelGGL(k_qsort_scatter, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, h->assign.as<int64_t>(), nq, b.nlist, h->qcnt.as<int>(),
+                               h->qperm.as<int>());
+        });
+        perm = h->qperm.as<int>();
+    }
     bool fused = false;
     const double rows = b.nlist ? (double)b.ntotal / (double)b.nlist * np : 0;
     const size_t smem = align_up((size_t)d * 4, 16) + SCAN_GROUPS * sizeof(TopK);
@@ -1068,7 +1137,7 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
             if (want_ts) HIP_CHECK(hipMemsetAsync(tsd, 0, 16 * 8, st));
             hipLaunchKernelGGL((k_scan_v<6, 32, 2>), dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
                                h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(), bf ? bf->feats : nullptr,
-                               bf ? bf->rate : 0.f, bf ? bf->omr : 0.f, h->hdr.pos_last, want_ts ? tsd : nullptr);
+                               bf ? bf->rate : 0.f, bf ? bf->omr : 0.f, h->hdr.pos_last, want_ts ? tsd : nullptr, perm);
             if (want_ts) {
                 HIP_CHECK(hipStreamSynchronize(st));
                 unsigned long long t[16];
@@ -1082,7 +1151,7 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
         if (d == 256 && !h->opt.on("IVF_GENERIC")) {
             hipLaunchKernelGGL((k_scan_v<4, 16, 2>), dim3((unsigned)nq), dim3(256), sm2, st, q, h->assign.as<int64_t>(), np, h->list_off(),
                                h->ids(), h->vecs(), nq, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(), bf ? bf->feats : nullptr,
-                               bf ? bf->rate : 0.f, bf ? bf->omr : 0.f, h->hdr.pos_last);
+                               bf ? bf->rate : 0.f, bf ? bf->omr : 0.f, h->hdr.pos_last, nullptr, perm);
             fused = bf != nullptr;
             return;
         }

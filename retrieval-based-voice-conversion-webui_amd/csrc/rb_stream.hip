@@ -20,6 +20,16 @@ int num_cus();
 
 namespace {
 
+#ifndef RS_KL_DEFAULT
+#define RS_KL_DEFAULT 2  // measured (r3k): 0.641 -> 0.623 ms per clip at B = 1 with the planning constant below, 0.614 -> 0.605 at B = 16
+#endif
+#ifndef RS_V2X_DEFAULT
+#define RS_V2X_DEFAULT 0
+#endif
+#ifndef RS_V3_DEFAULT
+#define RS_V3_DEFAULT 0  // until the GPU A/B says otherwise
+#endif
+
 struct Geo {
     int MI, NJ, NCO, bpc;  // bpc = blocks per CU (k_rb_stream: one wave per SIMD, NCO * bpc = 4)
     int ver;               // 1 = k_rb_stream, 2 = k_rb_stream2 (two blocks per CU, swizzled 256-byte rows), 3 = k_rb_stream3 (half-step slots)
@@ -39,7 +49,8 @@ bool geo_for(int C, int nd, Geo& g, const Options& opt, int ver = 1) {
     // per inter-barrier interval): planning unit = the pair, time ~ steps x (k + c0) with the phases in the K loops' shadow
     if (C == 128 && nd == 3 && ver == 4) { g = {1, 3, 4, 2, 4, opt.get("RS_C0", 1.0)}; return true; }
     if (C == 128 && nd == 3 && ver == 3) { g = {1, 6, 4, 1, 3, opt.get("RS_C0", 2.0)}; return true; }
-    if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1, 1, 4.4}; return true; }
+    // (the lean K loop shortens the k = 11 / 7 pair-steps more than the k = 3 ones: per pair-step 45.6k / 33.0k / 20.2k cycles => k + 3.8)
+    if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1, 1, opt.get("RS_C0", (sm && opt.geti("RS_KL", RS_KL_DEFAULT) == 2) ? 3.8 : 4.4)}; return true; }
     // (C = 128 pair by pair with TWO blocks per CU -- NJ = 4, 225 registers, 0 spills -- was measured: both waves of a SIMD sit in
     //  their K loops at the same time (72 cycles per MFMA per wave), the phases overlap no better than in the one-wave design
     //  (MFMA pipe 66 % busy in both) and three launches move 3x the bytes: 0.82 vs 0.71 ms on the same box.  Not kept.)
@@ -185,15 +196,6 @@ bool rb_stream_supported(int operand, int C, int nd) {
 
 static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B,
                        long bstride, hipStream_t st, const Options& opt, bool dry_run);
-#ifndef RS_KL_DEFAULT
-#define RS_KL_DEFAULT 1
-#endif
-#ifndef RS_V2X_DEFAULT
-#define RS_V2X_DEFAULT 0
-#endif
-#ifndef RS_V3_DEFAULT
-#define RS_V3_DEFAULT 0  // until the GPU A/B says otherwise
-#endif
 
 bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int njobs, int L, int B, long bstride, bool force,
                       hipStream_t st, const Options& opt, bool dry_run) {

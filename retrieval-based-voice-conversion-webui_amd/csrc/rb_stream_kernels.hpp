@@ -248,13 +248,15 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
                     for (int jt = NJ - 2; jt < NJ; ++jt) {
                         const int srow = jt * 32 + lrow - (R - Hx);
                         char* tw = (srow >= 0 ? sideX + (size_t)srow * STRIDE : dump) + (ct0 * 32 + half4) * 2;
+                        // (the same expression as the publish above, mask variant included: the packed words are reused, not recomputed)
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 const f32x16& t = xin[mi][jt];
                                 *(uint2*)(tw + (mi * 32 + 8 * g) * 2) =
-                                    pack4_lrelu<OpT, true>(t[4 * g + 0], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3], rowmask[jt]);
+                                    interior ? pack4_lrelu<OpT, false>(t[4 * g + 0], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3], 0u)
+                                             : pack4_lrelu<OpT, true>(t[4 * g + 0], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3], rowmask[jt]);
                             }
                     }
                 }

@@ -34,6 +34,11 @@ def test_search_ids_bit_exact_and_distances(n, d, nq, gpu):
     # torch in -> torch out, device resident
     Dt, It = h.search(torch.from_numpy(q).to(gpu), 8)
     assert Dt.is_cuda and np.array_equal(It.cpu().numpy(), Ir)
+    # queries scanned in arrival order instead of the list-sorted, XCD-contiguous order (k_qsort_*): identical results
+    h.set_option("IVF_SORT", 0)
+    D0, I0 = h.search(q, 8)
+    h.set_option("IVF_SORT", None)
+    assert np.array_equal(I0, Ir) and np.array_equal(D0, Dr)
 
 
 @pytest.mark.parametrize("nprobe", [2, 9])
