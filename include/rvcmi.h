@@ -227,6 +227,13 @@ int rvcmi_ivf_create_from_file(const char* path, int device, rvcmi_ivf** out);
  *   depend on how the centroids were found, and the reference pins nothing here.                      */
 int rvcmi_ivf_build(int d, int64_t n, const float* x_host, int64_t nlist, int niter, uint64_t seed, int device,
                     double* objective_out, rvcmi_ivf** out);
+/* The large-set branch of the index recipe (web.py:522-536: more than 2e5 feature rows are replaced by 10k k-means centres,
+ * sklearn MiniBatchKMeans there) without building an index: the SAME Lloyd iterations as rvcmi_ivf_build -- niter updates
+ * from k seeded training vectors, exact fp64 assignments, a cluster that loses all its points is re-seeded by splitting the
+ * largest one, so all k centres are valid -- and only the centres come back.  x_host [n,d] fp32 HOST, centroids_out_host
+ * [k,d] fp32 HOST, objective_out optional (niter doubles).                                                              */
+int rvcmi_kmeans(int d, int64_t n, const float* x_host, int64_t k, int niter, uint64_t seed, int device, double* objective_out,
+                 float* centroids_out_host);
 /* faiss.write_index(index, path)  (web.py:571) -- so indices round-trip with stock RVC.       */
 int rvcmi_ivf_write_file(const rvcmi_ivf* h, const char* path);
 

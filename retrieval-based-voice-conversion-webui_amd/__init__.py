@@ -5,7 +5,7 @@ reference's own Python call surface.  See DESIGN.md / INTEGRATION.md.
 """
 from . import _lib
 from ._lib import RvcmiError, build
-from .ivf import IVFFlatHIP, read_index, reduce_features, train_index, write_index
+from .ivf import IVFFlatHIP, kmeans, read_index, reduce_features, train_index, write_index
 from .front import FrontHIP, front_config_from_reference, infer_hip
 from .nsf import GeneratorHIP, NSFGeneratorHIP, config_from_reference
 from .pipeline import retrieve_blend

@@ -80,6 +80,7 @@ SYMBOLS = [
     ("rvcmi_front_profile_read", C.c_int, [_P, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int), C.c_int]),
     ("rvcmi_ivf_create_from_file", C.c_int, [C.c_char_p, C.c_int, C.POINTER(_P)]),
     ("rvcmi_ivf_build", C.c_int, [C.c_int, C.c_int64, _P, C.c_int64, C.c_int, C.c_uint64, C.c_int, _P, C.POINTER(_P)]),
+    ("rvcmi_kmeans", C.c_int, [C.c_int, C.c_int64, _P, C.c_int64, C.c_int, C.c_uint64, C.c_int, _P, _P]),
     ("rvcmi_ivf_write_file", C.c_int, [_P, C.c_char_p]),
     ("rvcmi_ivf_create", C.c_int, [C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(_P)]),
     ("rvcmi_ivf_destroy", C.c_int, [_P]),

@@ -53,6 +53,21 @@ int guarded(F&& f) {
     }
 }
 
+// Makes `device` current for the scope and restores the caller's device afterwards (the thread's current device is torch's too).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        HIP_CHECK(hipGetDevice(&prev));
+        if (prev != device) HIP_CHECK(hipSetDevice(device));
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;

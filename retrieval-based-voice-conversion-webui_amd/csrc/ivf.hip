@@ -458,6 +458,9 @@ __global__ void __launch_bounds__(256) k_scan(const float* __restrict__ q, const
 // Infinity Cache delivers (76 us).  Sorting the queries by probed list (counting sort: histogram, one-block exclusive scan,
 // scatter -- the order INSIDE a list is whatever the atomics give, results do not depend on it) and handing every XCD one
 // contiguous range of the sorted order (hardware puts block b on XCD b % 8) leaves each L2 with an eighth of the lists.
+// MEASURED (r3l): scan 77.1 -> 74.4 us on the benchmark index, 52.5 -> 52.2 us per clip at B = 16, for 17 us (3.7 us per clip at
+// B = 16) of sorting launches: the scan is bound by its longest blocks (the size-biased lists: 416 rows = 26 dependent iterations),
+// which the sorted order also packs onto the same XCD, not by where the rows come from.  Opt-in (IVF_SORT=1), off by default.
 __global__ void __launch_bounds__(256) k_qsort_hist(const int64_t* __restrict__ assign, int64_t nq, int64_t nlist, int* __restrict__ cnt) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nq) return;
@@ -790,7 +793,7 @@ struct rvcmi_ivf {
     int64_t cap_chunk = 0;  // queries per coarse-score chunk (bounds the nq x nlist fp32 scratch)
     Profiler prof;
     // dev / test options (common.hpp Options): IVF_COARSE_F64 (brute-force fp64 coarse quantizer), IVF_GENERIC (any-d scan kernel),
-    // IVF_STAMPS (prints; syncs), IVF_DBG, IVF_SORT (0 = scan the queries in arrival order).  Read from RVCMI_<KEY> once at handle creation; later only rvcmi_ivf_set_option.
+    // IVF_STAMPS (prints; syncs), IVF_DBG, IVF_SORT (1 = scan the queries in list-sorted, XCD-contiguous order).  Read from RVCMI_<KEY> once at handle creation; later only rvcmi_ivf_set_option.
     rvcmi::Options opt;
     rvcmi_ivf() { opt.load_env({"IVF_COARSE_F64", "IVF_GENERIC", "IVF_STAMPS", "IVF_DBG", "IVF_SORT"}); }
     const float* centroids() const { return (const float*)(blob + hdr.off_centroids); }
@@ -873,7 +876,7 @@ static std::vector<char> build_blob(int d, int64_t n, int64_t nlist, int nprobe,
 }
 
 static rvcmi_ivf* from_host_blob(const std::vector<char>& blob, int device) {
-    HIP_CHECK(hipSetDevice(device));
+    DeviceGuard dg(device);
     std::unique_ptr<rvcmi_ivf> h(new rvcmi_ivf());
     h->device = device;
     memcpy(&h->hdr, blob.data(), sizeof(BlobHeader));
@@ -1041,7 +1044,7 @@ static void reserve(rvcmi_ivf* h, int64_t nq) {
     const int np = (int)std::min<int64_t>(h->hdr.nprobe, h->hdr.nlist);
     const bool have_scores = np > 1 || (h->cscore.p && h->cap_chunk > 0);
     if (nq <= h->cap_nq && np <= h->cap_nprobe && h->flag.p && have_scores) return;
-    HIP_CHECK(hipSetDevice(h->device));
+    DeviceGuard dg(h->device);
     nq = std::max<int64_t>(nq, h->cap_nq);
     h->assign.alloc((size_t)std::max<int64_t>(nq, 1) * np * 8);
     h->P.alloc((size_t)std::max<int64_t>(nq, 1) * KMAX * 8);
@@ -1115,7 +1118,7 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
     }
     // list-sorted, XCD-contiguous query order for the specialised scans (see k_qsort_hist)
     const int* perm = nullptr;
-    if (np == 1 && nq >= 64 && nq < (1ll << 31) && (d == 768 || d == 256) && !h->opt.on("IVF_GENERIC") && h->opt.geti("IVF_SORT", 1)) {
+    if (np == 1 && nq >= 64 && nq < (1ll << 31) && (d == 768 || d == 256) && !h->opt.on("IVF_GENERIC") && h->opt.geti("IVF_SORT", 0)) {
         h->prof.launch("ivf_sort", 0.0, (double)nq * 16 + (double)b.nlist * 8, st, [&] {
             HIP_CHECK(hipMemsetAsync(h->qcnt.p, 0, (size_t)(b.nlist + 1) * 4, st));
             hipLaunchKernelGGL(k_qsort_hist, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, h->assign.as<int64_t>(), nq, b.nlist, h->qcnt.as<int>());
@@ -1176,18 +1179,20 @@ int rvcmi_ivf_create_from_file(const char* path, int device, rvcmi_ivf** out) {
 int rvcmi_ivf_write_file(const rvcmi_ivf* h, const char* path) {
     return guarded([&] {
         if (!h || !path) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
-        HIP_CHECK(hipSetDevice(h->device));
+        DeviceGuard dg(h->device);
         write_faiss(h, path);
     });
 }
-int rvcmi_ivf_build(int d, int64_t n, const float* x_host, int64_t nlist, int niter, uint64_t seed, int device,
-                    double* objective_out, rvcmi_ivf** out) {
+// shared by rvcmi_ivf_build (centroids_out == nullptr: k-means + add -> *out) and rvcmi_kmeans (centroids only: niter Lloyd updates, no
+// final assignment pass, no list-major copy of the vectors, no index object)
+static int ivf_build_impl(int d, int64_t n, const float* x_host, int64_t nlist, int niter, uint64_t seed, int device,
+                          double* objective_out, float* centroids_out, rvcmi_ivf** out) {
     return guarded([&] {
-        if (!x_host || !out) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        if (!x_host || (!out && !centroids_out)) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+        DeviceGuard dg(device);
         validate(d, n, nlist, 1);
         if (n < nlist) RVCMI_FAIL(RVCMI_ERR_INVALID, "need at least nlist=%lld training vectors, got %lld", (long long)nlist, (long long)n);
         if (niter < 0 || niter > 1000) RVCMI_FAIL(RVCMI_ERR_INVALID, "niter out of range");
-        HIP_CHECK(hipSetDevice(device));
         hipStream_t st = nullptr;
         DevBuf X, Cd, Cn, Sc, As, Ord, Off, Dist;
         X.alloc((size_t)n * d * 4);
@@ -1217,6 +1222,7 @@ int rvcmi_ivf_build(int d, int64_t n, const float* x_host, int64_t nlist, int ni
         std::vector<float> cn(nlist);
         std::vector<double> dist(n);
         for (int it = 0; it <= niter; ++it) {
+            if (centroids_out && it == niter) break;  // centres only: the assignment after the last update is not needed
             double cmax2 = 0.0;
             for (int64_t c = 0; c < nlist; ++c) {
                 double n2 = 0.0;
@@ -1285,6 +1291,10 @@ int rvcmi_ivf_build(int d, int64_t n, const float* x_host, int64_t nlist, int ni
                 sz[big] -= sz[l];
             }
         }
+        if (centroids_out) {  // every centre is valid: a cluster that lost all its points was re-seeded by splitting the largest one
+            memcpy(centroids_out, cent.data(), cent.size() * 4);
+            return;
+        }
         // index.add: list-major copy of the vectors, then the packed blob (same layout the reader produces)
         DevBuf V;
         V.alloc((size_t)std::max<int64_t>(n, 1) * d * 4);
@@ -1295,6 +1305,16 @@ int rvcmi_ivf_build(int d, int64_t n, const float* x_host, int64_t nlist, int ni
         auto blob = build_blob(d, n, nlist, 1, cent.data(), off.data(), order.data(), vecs.data());
         *out = from_host_blob(blob, device);
     });
+}
+int rvcmi_ivf_build(int d, int64_t n, const float* x_host, int64_t nlist, int niter, uint64_t seed, int device,
+                    double* objective_out, rvcmi_ivf** out) {
+    if (!out) return rvcmi::guarded([&] { RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument"); });
+    return ivf_build_impl(d, n, x_host, nlist, niter, seed, device, objective_out, nullptr, out);
+}
+int rvcmi_kmeans(int d, int64_t n, const float* x_host, int64_t k, int niter, uint64_t seed, int device, double* objective_out,
+                 float* centroids_out_host) {
+    if (!centroids_out_host) return rvcmi::guarded([&] { RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument"); });
+    return ivf_build_impl(d, n, x_host, k, niter, seed, device, objective_out, centroids_out_host, nullptr);
 }
 int rvcmi_ivf_create(int d, int64_t n, int64_t nlist, int nprobe, const float* centroids, const int64_t* list_offsets,
                      const int64_t* ids, const float* vecs, int device, rvcmi_ivf** out) {
@@ -1315,7 +1335,7 @@ int rvcmi_ivf_set_nprobe(rvcmi_ivf* h, int nprobe) {
     return guarded([&] {
         if (!h || nprobe < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "bad nprobe");
         h->hdr.nprobe = nprobe;
-        HIP_CHECK(hipSetDevice(h->device));
+        DeviceGuard dg(h->device);
         HIP_CHECK(hipMemcpy(h->blob, &h->hdr, sizeof(BlobHeader), hipMemcpyHostToDevice));
     });
 }
@@ -1373,7 +1393,7 @@ int rvcmi_ivf_reconstruct_n(const rvcmi_ivf* h, int64_t i0, int64_t n, float* ou
         if (i0 < 0 || n < 0 || i0 + n > b.ntotal) RVCMI_FAIL(RVCMI_ERR_INVALID, "range [%lld,%lld) outside ntotal %lld",
                                                                  (long long)i0, (long long)(i0 + n), (long long)b.ntotal);
         if (!n) return;
-        HIP_CHECK(hipSetDevice(h->device));
+        DeviceGuard dg(h->device);
         std::vector<int64_t> ids(b.ntotal);
         std::vector<float> vecs((size_t)b.ntotal * b.d);
         HIP_CHECK(hipMemcpy(ids.data(), h->blob + b.off_ids, ids.size() * 8, hipMemcpyDeviceToHost));
@@ -1402,7 +1422,7 @@ int rvcmi_ivf_blob(const rvcmi_ivf* h, void** dev_ptr, size_t* bytes) {
 int rvcmi_ivf_centroids(const rvcmi_ivf* h, float* out_host) {
     return guarded([&] {
         if (!h || !out_host) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
-        HIP_CHECK(hipSetDevice(h->device));
+        DeviceGuard dg(h->device);
         HIP_CHECK(hipMemcpy(out_host, h->centroids(), (size_t)h->hdr.nlist * h->hdr.d * sizeof(float), hipMemcpyDeviceToHost));
     });
 }
@@ -1410,14 +1430,14 @@ int rvcmi_ivf_blob_copy(const rvcmi_ivf* h, void* dst_dev, size_t capacity, void
     return guarded([&] {
         if (!h || !dst_dev) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
         if (capacity < h->hdr.total_bytes) RVCMI_FAIL(RVCMI_ERR_INVALID, "blob_copy: destination holds %zu bytes, the index needs %zu", capacity, (size_t)h->hdr.total_bytes);
-        HIP_CHECK(hipSetDevice(h->device));
+        DeviceGuard dg(h->device);
         HIP_CHECK(hipMemcpyAsync(dst_dev, h->blob, h->hdr.total_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     });
 }
 int rvcmi_ivf_create_from_blob(void* dev_ptr, size_t bytes, int device, int take_ownership, rvcmi_ivf** out) {
     return guarded([&] {
         if (!dev_ptr || !out || bytes < sizeof(BlobHeader)) RVCMI_FAIL(RVCMI_ERR_INVALID, "bad blob");
-        HIP_CHECK(hipSetDevice(device));
+        DeviceGuard dg(device);
         std::unique_ptr<rvcmi_ivf> h(new rvcmi_ivf());
         h->device = device;
         HIP_CHECK(hipMemcpy(&h->hdr, dev_ptr, sizeof(BlobHeader), hipMemcpyDeviceToHost));

@@ -216,7 +216,22 @@ def reduce_features(big_npy: np.ndarray, n_clusters: int = 10000, threshold: flo
     x = np.ascontiguousarray(big_npy, dtype=np.float32)
     if x.shape[0] <= threshold:
         return x
-    return IVFFlatHIP.train(x, nlist=int(n_clusters), niter=niter, seed=seed, device=device).centroids()
+    return kmeans(x, int(n_clusters), niter=niter, seed=seed, device=device)
+
+
+def kmeans(x: np.ndarray, k: int, niter: int = 10, seed: int = 1234, device="cuda:0") -> np.ndarray:
+    """``k`` k-means centres of the rows of ``x`` (``rvcmi_kmeans``): the Lloyd iterations of :meth:`IVFFlatHIP.train` without the
+    index -- no ``add`` pass over the N rows, no list-major copy in HBM.  A cluster that loses all its points is re-seeded by
+    splitting the largest one, so all ``k`` rows returned are valid centres."""
+    dev = _cuda(device)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if x.ndim != 2:
+        raise ValueError("x must be [N, d]")
+    n, d = x.shape
+    out = np.empty((int(k), d), dtype=np.float32)
+    _lib.check(_lib.lib().rvcmi_kmeans(d, n, x.ctypes.data_as(C.c_void_p), int(k), int(niter), int(seed), _idx(dev), C.c_void_p(None),
+                                       out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def train_index(big_npy: np.ndarray, path: str = None, nlist: int = None, niter: int = 10, seed: int = 1234, device="cuda:0") -> IVFFlatHIP:

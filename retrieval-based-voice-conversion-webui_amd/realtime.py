@@ -143,6 +143,12 @@ class RealtimeVC:
         p_len = int(n_input_samples) // self.window                                       # :189
         factor = pow(2, self.formant_shift / 12)                                          # :190
         return_length2 = int(math.ceil(return_length * factor))                           # :191
+        pf = pitchf if (protect < 0.5 and pitch is not None and pitchf is not None) else None   # :224
+        if pf is not None and pf.numel() != p_len:
+            # rtrvc.py:221-231 multiplies feats [1, p_len, d] by the RAW estimator output pitchff [m, 1]: torch broadcasting makes
+            # that an error unless m == p_len.  Truncating instead would mix frames that are not aligned with the feature rows.
+            raise RuntimeError("protect < 0.5 needs pitchf of exactly p_len = %d frames (got %d), as the reference's broadcast at "
+                               "infer/lib/rtrvc.py:229 does" % (p_len, pf.numel()))
         cache_pitch = cache_pitchf = None
         if self.if_f0 == 1:
             if pitch is None or pitchf is None:
@@ -150,7 +156,6 @@ class RealtimeVC:
             self.cache.update(pitch, pitchf, block_frame_16k, self.window)                # :213-217
             cache_pitch, cache_pitchf = self.cache.window(p_len, return_length, return_length2)
         use_index = self.index is not None and self.index_rate > 0                        # :167
-        pf = pitchf if (protect < 0.5 and pitch is not None and pitchf is not None) else None   # :224
         phone = glue.retrieve_blend_expand(feats, self.index if use_index else None, self.index_rate if use_index else 0.0,
                                            pf, protect if pf is not None else 1.0, p_len, realtime_guard=True,
                                            skip_rows=int(skip_head) // 2)                  # :167-185, 221-233

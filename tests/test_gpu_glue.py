@@ -163,6 +163,8 @@ def test_realtime_vc_block_loop(gpu):
         ref = glue_oracle.expand_protect(blended, f2, pitchf[None], 0.33, p_len)
         assert seen["phone"].shape == ref.shape, (seen["phone"].shape, ref.shape)
         assert (seen["phone"] - ref).abs().max() <= 2e-6, "phone: max abs diff %.3e" % (seen["phone"] - ref).abs().max()
+    with pytest.raises(RuntimeError, match="exactly p_len"):  # the reference's broadcast (rtrvc.py:229) fails for m != p_len as well
+        rt.infer(feats.to(gpu), n_samples, block16k, skip_head, ret_len, pitch=pitch[:-3].to(gpu), pitchf=pitchf[:-3].to(gpu), protect=0.33)
     rt.set_formant(2.0)  # rtrvc.py:190-191, 218-219: the decoder is asked for ceil(return_length * 2^(2/12)) frames ...
     wav = rt.infer(feats.to(gpu), n_samples, block16k, skip_head, ret_len, pitch=pitch.to(gpu), pitchf=pitchf.to(gpu))
     # ... and its output is resampled from upp_res to tgt_sr / 100 samples per 10 ms (rtrvc.py:248-259) by the HIP polyphase kernel

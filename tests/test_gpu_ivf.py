@@ -34,8 +34,8 @@ def test_search_ids_bit_exact_and_distances(n, d, nq, gpu):
     # torch in -> torch out, device resident
     Dt, It = h.search(torch.from_numpy(q).to(gpu), 8)
     assert Dt.is_cuda and np.array_equal(It.cpu().numpy(), Ir)
-    # queries scanned in arrival order instead of the list-sorted, XCD-contiguous order (k_qsort_*): identical results
-    h.set_option("IVF_SORT", 0)
+    # queries scanned in the list-sorted, XCD-contiguous order (k_qsort_*, opt-in) instead of arrival order: identical results
+    h.set_option("IVF_SORT", 1)
     D0, I0 = h.search(q, 8)
     h.set_option("IVF_SORT", None)
     assert np.array_equal(I0, Ir) and np.array_equal(D0, Dr)
@@ -339,3 +339,5 @@ def test_reduce_features_is_the_large_set_branch_of_the_index_recipe(gpu):
     obj = ((x - c[a]) ** 2).sum()
     c0 = x[rng.choice(6000, 64, replace=False)]
     assert obj < 0.8 * ((x - c0[synth.assign_nearest(x, c0)]) ** 2).sum()
+    # the centres-only entry (rvcmi_kmeans) runs the SAME Lloyd iterations as the index build, without the add pass
+    assert np.array_equal(c, rvc_amd.IVFFlatHIP.train(x, nlist=64, niter=15, device=gpu).centroids())
