@@ -353,6 +353,12 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
                         : g.ver == 3 ? (size_t)(RS3_XROWS + RS3_HROWS + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
                         : g.ver == 2 ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
                                      : (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
+    // k_rb_stream with KL = 2 (lean K loop + coalesced step IO): [side | dump | biases | M ...] with the fp32 transposition tile
+    // T (R rows x (4 C + 16) bytes) starting at M and running over its end (rb_stream_kernels.hpp)
+    const bool kl2 = g.ver == 1 && C == 128 && nd == 3 && g.NJ == 6 && (a.flags & 4);
+    const size_t smem_kl2 = (size_t)(side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float) +
+                            std::max((size_t)(RS_HEAD + R + RS_SLACK) * (2 * C + 16), (size_t)R * (4 * C + 16));
+    if (kl2 && smem_kl2 > (size_t)160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large (C=%d)", smem_kl2, C);
     if (smem > (size_t)160 * 1024 / (g.ver == 4 ? 2 : g.bpc))
         RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large for %d block(s) per CU (C=%d)", smem, g.bpc, C);
     if (dry_run) return true;
@@ -365,8 +371,8 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
         HIP_CHECK(hipMemsetAsync(ts, 0, nts * 8, st));
         a.ts = ts;
     }
-    if (operand == RVCMI_OPERAND_BF16) launch_t<__bf16>(C, nd, g.NJ, a, nblocks, B, smem, st, g.ver);
-    else launch_t<_Float16>(C, nd, g.NJ, a, nblocks, B, smem, st, g.ver);
+    if (operand == RVCMI_OPERAND_BF16) launch_t<__bf16>(C, nd, g.NJ, a, nblocks, B, kl2 ? smem_kl2 : smem, st, g.ver);
+    else launch_t<_Float16>(C, nd, g.NJ, a, nblocks, B, kl2 ? smem_kl2 : smem, st, g.ver);
     if (want_stamps) {
         HIP_CHECK(hipStreamSynchronize(st));
         std::vector<unsigned long long> h(nts);

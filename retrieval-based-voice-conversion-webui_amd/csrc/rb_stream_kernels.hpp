@@ -77,11 +77,13 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
     static_assert(CP == C, "waves must tile the channels exactly");
     constexpr int MROWS = RS_HEAD + R + RS_SLACK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* M = smem;
-    char* side = smem + (size_t)MROWS * STRIDE;
+    // KL = 1: [M | side | dump row | biases].  KL = 2: [side | dump row | biases | M ...]: the fp32 transposition tile T of the
+    // coalesced step IO (R rows x (4 C + 16) bytes = 101 KB at C = 128) starts at M and runs over M's end into the unused LDS.
+    char* side = KL == 2 ? smem : smem + (size_t)MROWS * STRIDE;
     // after the side area: one dump row (discarded history writes), then the biases [ND][2][CP]
     char* dump = side + (size_t)a.side_rows * STRIDE;
     float* bias_l = (float*)(dump + STRIDE);
+    char* M = KL == 2 ? (char*)(bias_l + ND * 2 * CP) : smem;
 
     // ---- which job / utterance / strip ---------------------------------------------------------------------------------
     // The launch is one 1-D grid of (strips of all jobs) x B blocks.  Hardware places block i on XCD i % 8; the logical
@@ -121,9 +123,10 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
 
     // ---- zero the whole LDS image once (histories start empty, slack rows stay zero), stage the biases ----------------
     {
-        const int total16 = (int)(((size_t)(MROWS + a.side_rows + 1) * STRIDE) / 16);
+        const int total16 = (int)(((size_t)(MROWS + a.side_rows + 1) * STRIDE + (KL == 2 ? ND * 2 * CP * 4 : 0)) / 16);
         const uint4 z = make_uint4(0, 0, 0, 0);
         for (int i = threadIdx.x; i < total16; i += NT) *(uint4*)(smem + (size_t)i * 16) = z;
+        if constexpr (KL == 2) __syncthreads();
         for (int i = threadIdx.x; i < ND * 2 * CP; i += NT) {
             const int m = i / (2 * CP), w = (i / CP) & 1, c = i % CP;
             bias_l[i] = (w ? J.b2[m] : J.b1[m])[c];
@@ -174,9 +177,56 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
     prefetch((const OpT*)J.w1[0] + (size_t)ct0 * J.ct1, J.ct1, ctb1);
     __syncthreads();
 
+    // ---- coalesced step IO (KL = 2) ---------------------------------------------------------------------------------------
+    // The D-layout global accesses of KL = 1 (every instruction touches 32 rows x 32 bytes) are TA-issue-bound: 96 loads +
+    // 96 stores = 10.6k cycles per step, the largest non-MFMA item left.  Here a step's R rows move as whole rows -- 1 KB
+    // contiguous per wave instruction, 24 per wave each way -- and change layout through an fp32 tile T in LDS (row stride
+    // 4 C + 16 bytes: conflict-free for both the row-wise and the D-layout 16-byte accesses).  The next step's rows are
+    // requested BEFORE the finished rows are stored, so their HBM latency runs under the store phase.
+    constexpr int CHR = C / 4;            // 16-byte chunks per fp32 row
+    constexpr int NCH = R * CHR / NT;     // chunks per thread per step
+    constexpr int TSTR = C * 4 + 16;
+    static_assert(KL != 2 || ((R * CHR) % NT == 0 && NT % CHR == 0), "row chunks must tile the block");
+    char* T = M;
+    f32x4 xr[KL == 2 ? NCH : 1];
+    auto issue_loads = [&](int w0) {
+#pragma unroll
+        for (int it = 0; it < NCH; ++it) {
+            const int row = it * (NT / CHR) + (int)threadIdx.x / CHR, c = (int)threadIdx.x % CHR;
+            const int tgc = min(max(w0 + row, 0), L - 1);
+            xr[it] = *(const f32x4*)(src + (size_t)tgc * C + c * 4);
+        }
+    };
+    if constexpr (KL == 2) issue_loads(r0);
+
     for (int step = 0; step < nsteps; ++step) {
-        // ---- load the next R rows of x straight into the accumulator layout (clamped addresses, masked values) -------
         f32x16 xin[MI][NJ];
+        if constexpr (KL == 2) {
+            const int w0 = r0 + step * R;
+            bar();  // every thread is done with T (the previous step's row-wise reads for its stores)
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int row = it * (NT / CHR) + (int)threadIdx.x / CHR, c = (int)threadIdx.x % CHR;
+                *(f32x4*)(T + (size_t)row * TSTR + c * 16) = xr[it];
+            }
+            bar();
+            const bool inside = w0 >= 0 && w0 + R <= L;  // block-uniform: no row of this step needs masking
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                const int tg = w0 + jt * 32 + lrow;
+                const unsigned msk = (inside || (tg >= 0 && tg < L)) ? 0xffffffffu : 0u;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = *(const f32x4*)(T + (size_t)(jt * 32 + lrow) * TSTR + ((ct0 + mi) * 32 + 8 * g + half4) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xin[mi][jt][4 * g + e] = mask_bits(v[e], msk);
+                    }
+            }
+            bar();  // before phase A publishes into M (the same LDS)
+        } else
+        // ---- load the next R rows of x straight into the accumulator layout (clamped addresses, masked values) -------
         {
             const int w0 = r0 + step * R;
 #pragma unroll
@@ -352,6 +402,27 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
                 for (int jt = 0; jt < NJ; ++jt) xin[mi][jt] = res[mi][jt];
         }
         // ---- store the rows of this strip ------------------------------------------------------------------------------
+        if constexpr (KL == 2) {
+            const int wout = r0 - 32 * ND + step * R;
+            issue_loads(r0 + (step + 1) * R);  // the next step's rows: in flight under the store phase (clamped past the end)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {xin[mi][jt][4 * g + 0], xin[mi][jt][4 * g + 1], xin[mi][jt][4 * g + 2], xin[mi][jt][4 * g + 3]};
+                        *(f32x4*)(T + (size_t)(jt * 32 + lrow) * TSTR + ((ct0 + mi) * 32 + 8 * g + half4) * 4) = v;
+                    }
+            bar();
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int row = it * (NT / CHR) + (int)threadIdx.x / CHR, c = (int)threadIdx.x % CHR;
+                const int tg = wout + row;
+                const f32x4 v = *(const f32x4*)(T + (size_t)row * TSTR + c * 16);
+                if (tg >= S0 && tg < S1) *(f32x4*)(dst + (size_t)tg * C + c * 4) = v;
+            }
+        } else
         {
             const int wout = r0 - 32 * ND + step * R;
 #pragma unroll
