@@ -183,46 +183,68 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
     // contiguous per wave instruction, 24 per wave each way -- and change layout through an fp32 tile T in LDS (row stride
     // 4 C + 16 bytes: conflict-free for both the row-wise and the D-layout 16-byte accesses).  The next step's rows are
     // requested BEFORE the finished rows are stored, so their HBM latency runs under the store phase.
+    // One instruction per 16-byte chunk in every IO loop (a lone wave issues ~4.5 cycles per instruction: the first version, with
+    // per-chunk address arithmetic, row clamps and store predicates, cost as much as the D-layout accesses it replaced):
+    //   * global rows go through RAW BUFFER descriptors whose range check does the masking: the load descriptor covers the
+    //     utterance (rows outside [0, L) read as zeros), the store descriptor covers THIS STRIP (rows outside [S0, S1) are dropped);
+    //     the row offset lives in the VGPR offset (the range check covers VGPR + immediate offset);
+    //   * thread (g8, c) = (tid / 32, tid % 32) owns chunk c of the 24 rows 24 g8 .. 24 g8 + 23: chunk `it` is an immediate offset
+    //     (it % 8) * 512 on one of three offset registers in global memory and it * TSTR on one base register in LDS.
     constexpr int CHR = C / 4;            // 16-byte chunks per fp32 row
-    constexpr int NCH = R * CHR / NT;     // chunks per thread per step
+    constexpr int NG8 = NT / CHR;         // thread groups (8)
+    constexpr int NCH = R / NG8;          // rows (= chunks) per thread per step (24)
     constexpr int TSTR = C * 4 + 16;
-    static_assert(KL != 2 || ((R * CHR) % NT == 0 && NT % CHR == 0), "row chunks must tile the block");
+    static_assert(KL != 2 || (NT % CHR == 0 && R % NG8 == 0 && NCH % 8 == 0 && C * 4 * 8 == 4096), "IO chunk geometry");
     char* T = M;
     f32x4 xr[KL == 2 ? NCH : 1];
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)((size_t)L * C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dst =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (size_t)S0 * C), 0, (int)((size_t)max(S1 - S0, 0) * C * 4), 0x00020000);
+    const int g8 = (int)threadIdx.x / CHR, cch = (int)threadIdx.x % CHR;
+    const unsigned io_voff = (unsigned)(g8 * NCH * C * 4 + cch * 16);           // this thread's chunk of its first row, in bytes
+    const unsigned io_lds = lds_address(T) + (unsigned)(g8 * NCH * TSTR + cch * 16);
     auto issue_loads = [&](int w0) {
+        // (wraps for w0 < 0: far outside the descriptor => zeros.  Three opaque offset registers, 4096 bytes apart: the rest of a
+        //  chunk's offset fits the instruction's 12-bit immediate; left transparent, the compiler hoists 24 per-chunk registers)
+        unsigned v0[NCH / 8];
 #pragma unroll
-        for (int it = 0; it < NCH; ++it) {
-            const int row = it * (NT / CHR) + (int)threadIdx.x / CHR, c = (int)threadIdx.x % CHR;
-            const int tgc = min(max(w0 + row, 0), L - 1);
-            xr[it] = *(const f32x4*)(src + (size_t)tgc * C + c * 4);
+        for (int j = 0; j < NCH / 8; ++j) {
+            v0[j] = io_voff + (unsigned)(w0 * (C * 4)) + (unsigned)(j * 4096);
+            asm volatile("" : "+v"(v0[j]));
         }
+#pragma unroll
+        for (int it = 0; it < NCH; ++it)
+            xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, v0[it / 8] + (unsigned)((it % 8) * (C * 4)), 0, 0));
     };
+    // D-layout addresses of this lane inside T: tiles 0..2 from one base register, 3..5 from a second (16-bit offset fields)
+    const unsigned dl_lds = lds_address(T) + (unsigned)(lrow * TSTR + (ct0 * 32 + half4) * 4);
+    using lds_f32x4 = __attribute__((address_space(3))) f32x4;
     if constexpr (KL == 2) issue_loads(r0);
 
     for (int step = 0; step < nsteps; ++step) {
         f32x16 xin[MI][NJ];
         if constexpr (KL == 2) {
-            const int w0 = r0 + step * R;
             bar();  // every thread is done with T (the previous step's row-wise reads for its stores)
+            {
+                unsigned b = io_lds;
+                asm volatile("" : "+v"(b));
 #pragma unroll
-            for (int it = 0; it < NCH; ++it) {
-                const int row = it * (NT / CHR) + (int)threadIdx.x / CHR, c = (int)threadIdx.x % CHR;
-                *(f32x4*)(T + (size_t)row * TSTR + c * 16) = xr[it];
+                for (int it = 0; it < NCH; ++it) *(lds_f32x4*)(size_t)(b + (unsigned)(it * TSTR)) = xr[it];
             }
             bar();
-            const bool inside = w0 >= 0 && w0 + R <= L;  // block-uniform: no row of this step needs masking
+            {
+                unsigned b0 = dl_lds, b1 = dl_lds + (unsigned)(3 * 32 * TSTR);
+                asm volatile("" : "+v"(b0), "+v"(b1));
 #pragma unroll
-            for (int jt = 0; jt < NJ; ++jt) {
-                const int tg = w0 + jt * 32 + lrow;
-                const unsigned msk = (inside || (tg >= 0 && tg < L)) ? 0xffffffffu : 0u;
+                for (int jt = 0; jt < NJ; ++jt)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = *(const f32x4*)(T + (size_t)(jt * 32 + lrow) * TSTR + ((ct0 + mi) * 32 + 8 * g + half4) * 4);
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = *(const lds_f32x4*)(size_t)((jt < 3 ? b0 : b1) + (unsigned)((jt % 3) * 32 * TSTR + (mi * 32 + 8 * g) * 4));
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) xin[mi][jt][4 * g + e] = mask_bits(v[e], msk);
-                    }
+                            for (int e = 0; e < 4; ++e) xin[mi][jt][4 * g + e] = v[e];
+                        }
             }
             bar();  // before phase A publishes into M (the same LDS)
         } else
@@ -404,23 +426,35 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
         // ---- store the rows of this strip ------------------------------------------------------------------------------
         if constexpr (KL == 2) {
             const int wout = r0 - 32 * ND + step * R;
-            issue_loads(r0 + (step + 1) * R);  // the next step's rows: in flight under the store phase (clamped past the end)
+            issue_loads(r0 + (step + 1) * R);  // the next step's rows: in flight under the store phase (zeros past the end)
+            {
+                unsigned b0 = dl_lds, b1 = dl_lds + (unsigned)(3 * 32 * TSTR);
+                asm volatile("" : "+v"(b0), "+v"(b1));
 #pragma unroll
-            for (int jt = 0; jt < NJ; ++jt)
+                for (int jt = 0; jt < NJ; ++jt)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = {xin[mi][jt][4 * g + 0], xin[mi][jt][4 * g + 1], xin[mi][jt][4 * g + 2], xin[mi][jt][4 * g + 3]};
-                        *(f32x4*)(T + (size_t)(jt * 32 + lrow) * TSTR + ((ct0 + mi) * 32 + 8 * g + half4) * 4) = v;
-                    }
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = {xin[mi][jt][4 * g + 0], xin[mi][jt][4 * g + 1], xin[mi][jt][4 * g + 2], xin[mi][jt][4 * g + 3]};
+                            *(lds_f32x4*)(size_t)((jt < 3 ? b0 : b1) + (unsigned)((jt % 3) * 32 * TSTR + (mi * 32 + 8 * g) * 4)) = v;
+                        }
+            }
             bar();
+            {
+                unsigned b = io_lds;
+                asm volatile("" : "+v"(b));
+                unsigned v0[NCH / 8];  // (wraps for rows in front of the strip: dropped)
 #pragma unroll
-            for (int it = 0; it < NCH; ++it) {
-                const int row = it * (NT / CHR) + (int)threadIdx.x / CHR, c = (int)threadIdx.x % CHR;
-                const int tg = wout + row;
-                const f32x4 v = *(const f32x4*)(T + (size_t)row * TSTR + c * 16);
-                if (tg >= S0 && tg < S1) *(f32x4*)(dst + (size_t)tg * C + c * 4) = v;
+                for (int j = 0; j < NCH / 8; ++j) {
+                    v0[j] = io_voff + (unsigned)((wout - S0) * (C * 4)) + (unsigned)(j * 4096);
+                    asm volatile("" : "+v"(v0[j]));
+                }
+#pragma unroll
+                for (int it = 0; it < NCH; ++it) {
+                    const f32x4 v = *(const lds_f32x4*)(size_t)(b + (unsigned)(it * TSTR));
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_dst, v0[it / 8] + (unsigned)((it % 8) * (C * 4)), 0, 0);
+                }
             }
         } else
         {
