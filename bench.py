@@ -581,7 +581,7 @@ def main():
         # HBM-side bytes per launch of the dominant kernel: NOT measured in this run (PMC counters need their own rocprofv3
         # passes); taken from the newest committed pass of the same command, and labelled as such.
         traffic, traffic_source, traffic_all = None, None, None
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             fn = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
             if not os.path.exists(fn):
                 continue
@@ -603,6 +603,13 @@ def main():
                 "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
                 "generator_all_kernels": {"ms_per_step": tot_ms, "achieved": gen_ach / 1e12, "frac": gen_ach / peak},
                 "kernels_ms_per_step": {s["name"]: round(s["ms"] / 3.0, 4) for s in gs + ivs}}
+        # Context, not a different yardstick: what the SAME K loop (MFMA + LDS B fragments + L2 weight fragments, nothing else)
+        # reaches when it has the chip to itself.  The power management holds such a loop at ~1.5 of the 2.4 GHz the 2.5 PF
+        # figure assumes (tools/ubench/kloop2.hip, profiles/r03_ubench_kloop2_issue_model.txt: 34.0 cycles per MFMA at an
+        # effective 1.52 GHz = 1505 TFLOP/s; an MFMA-only loop: 1804 TFLOP/s at 1.74 GHz).
+        if a.operand in ("fp16", "bf16"):
+            roof["ubench_ceiling"] = {"kloop_tflops": 1505.0, "mfma_only_tflops": 1804.0, "frac_of_kloop_ceiling": ach / 1505e12,
+                                      "source": "profiles/r03_ubench_kloop2_issue_model.txt (measured on an MI355X of this pool, round 3)"}
         scan = [s for s in ivs if s["name"] == "ivf_scan"]
         if scan and scan[0]["ms"] > 0:
             roof["ivf_scan_hbm"] = {"achieved": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
