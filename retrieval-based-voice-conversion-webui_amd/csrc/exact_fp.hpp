@@ -28,4 +28,17 @@ __device__ __forceinline__ float div_rn(float a, float b) {
     return a / b;
 }
 
+// x / 3 -- the stage mean of the three ResBlocks (rvc/layers/nsf.py:186, `xs / self.num_kernels`) -- in THREE instructions instead of
+// the ~10 of an IEEE division (v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup), bit-identical to it: Markstein's
+// correction q' = q + (x - 3 q) * y with the correctly rounded reciprocal y = RN(1/3).  tools/check_div3.py compares it with the
+// IEEE quotient for ALL 2^23 mantissas x 2 signs at seven exponents (scaling by a power of two is exact, so that covers every
+// x whose quotient is normal): 0 mismatches.  (x = +-inf gives NaN instead of +-inf, -0 gives +0: neither occurs / matters for
+// activations.)
+__device__ __forceinline__ float div3_exact(float x) {
+    const float y = 0x1.555556p-2f;  // RN32(1/3) = 0x3EAAAAAB
+    const float q = mul_rn(x, y);
+    const float r = __builtin_fmaf(-3.0f, q, x);  // the exact residual
+    return __builtin_fmaf(r, y, q);
+}
+
 }  // namespace rvcmi

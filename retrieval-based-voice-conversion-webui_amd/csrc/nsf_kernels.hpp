@@ -299,7 +299,8 @@ static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ x
                     float4 v = va[u];
                     if (xb) { v.x += vb[u].x; v.y += vb[u].y; v.z += vb[u].z; v.w += vb[u].w; }
                     if (xc) { v.x += vc[u].x; v.y += vc[u].y; v.z += vc[u].z; v.w += vc[u].w; }
-                    if (div != 1.f) { v.x = v.x / div; v.y = v.y / div; v.z = v.z / div; v.w = v.w / div; }
+                    if (div == 3.f) { v.x = div3_exact(v.x); v.y = div3_exact(v.y); v.z = div3_exact(v.z); v.w = div3_exact(v.w); }
+                    else if (div != 1.f) { v.x = v.x / div; v.y = v.y / div; v.z = v.z / div; v.w = v.w / div; }
                     v.x = lrelu(v.x, 0.01f); v.y = lrelu(v.y, 0.01f); v.z = lrelu(v.z, 0.01f); v.w = lrelu(v.w, 0.01f);
                     if (t < 0 || t >= L) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     *(float4*)(tile + r * S + c4 * 4) = v;
@@ -530,7 +531,8 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float x = f[e];
-                    if (a.div_in != 1.f) x = x / a.div_in;
+                    if (a.div_in == 3.f) x = div3_exact(x);
+                    else if (a.div_in != 1.f) x = x / a.div_in;
                     v[e] = to_op<OpT>(lrelu(x, a.slope_in));
                 }
             } else {  // IN_F32_CF
@@ -1264,11 +1266,16 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
             const int r = idx / C8;
             const int c8 = idx - r * C8;
             frag v;
+            if (a.div == 3.f) {  // the three ResBlocks of every shipped config: the short exact quotient, one v_mul + one v_med3 lrelu
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float x = f[u][e];
-                if (a.div != 1.f) x = x / a.div;
-                v[e] = to_op<OpT>(lrelu(x, 0.1f));
+                for (int e = 0; e < 8; ++e) v[e] = (OpT)lrelu_op<OpT>(div3_exact(f[u][e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = f[u][e];
+                    if (a.div != 1.f) x = x / a.div;
+                    v[e] = to_op<OpT>(lrelu(x, 0.1f));
+                }
             }
             *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
         }

@@ -364,3 +364,14 @@ def test_sinc_resample_oracle_against_scipy_and_the_product_table():
             tap = 300 + width - j * of
             if 0 <= tap < kk.shape[1]:
                 assert abs(r[j * nf + p] - kk[p, tap]) <= 1e-6
+
+
+def test_three_instruction_division_by_three_is_the_ieee_quotient():
+    """csrc/exact_fp.hpp:div3_exact (the stage mean `/ num_kernels` of nsf.py:186 in k_ups / k_post): every mantissa, both signs."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("check_div3", os.path.join(os.path.dirname(__file__), "..", "tools", "check_div3.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.mismatches(0, 1.0) == 0 and m.mismatches(3, -1.0) == 0
