@@ -20,6 +20,7 @@ namespace {
 
 struct AttnLayer {
     ConvLayer qkv, o, f1, f2;
+    ConvLayer f2s[4];  // conv_2 re-packed per quarter of the hidden channels (split FFN, k_fr_ffn_part)
     DevBuf relk, relv, g1, b1, g2, b2;
 };
 struct FlowLayer {
@@ -40,6 +41,7 @@ struct rvcmi_front {
     DevBuf cond_w, cond_b;  // all flows' cond_layer concatenated: [n_flows * 2H * n_layers][gin]
     // workspace
     DevBuf X, X2, QK, KF, VT, A, F, ZP, Ha, Hb, SK, GC;  // QK: q [B][T][H]; KF / VT: k / v tiles in fragment order
+    DevBuf FP;           // split FFN: fp32 partial sums [4][rows <= FFN_SPLIT_ROWS][H]
     size_t ws_bytes = 0;
     Profiler prof;
     // dev / test options (common.hpp Options): FR_NJ (1 / 2: time-tile height), FR_NO_FFN_FUSION, FR_STAMPS (prints; syncs).
@@ -48,6 +50,9 @@ struct rvcmi_front {
 };
 
 namespace {
+
+constexpr int FFN_SPLIT = 4;            // slices of the hidden channels in the split FFN
+constexpr size_t FFN_SPLIT_ROWS = 8192;  // B * T rows up to which the split form may be chosen (sizes its scratch)
 
 struct TapReq {
     std::string what;
@@ -170,6 +175,35 @@ void launch_ffn_nj(rvcmi_front* h, FrFfnArgs a, const ConvLayer& L1, const ConvL
     });
     HIP_CHECK(hipGetLastError());
 }
+// split form for small grids (see k_fr_ffn_part): S x the blocks, each with a quarter of the weight stream, + a LayerNorm pass
+template <typename OpT, int NJ1>
+void launch_ffn_split_nj(rvcmi_front* h, FrFfnArgs a, const ConvLayer& L1, const ConvLayer (&L2s)[4], const ConvLayer& L2, int B, hipStream_t st) {
+    constexpr int H = 192, F = 768, FS = F / FFN_SPLIT;
+    a.w1 = L1.w_pack.p;
+    a.ct1 = L1.ct_stride;
+    a.b1 = L1.bias.as<float>();
+    for (int s = 0; s < FFN_SPLIT; ++s) a.w2s[s] = L2s[s].w_pack.p;
+    a.ct2s = L2s[0].ct_stride;
+    a.b2 = L2.bias.as<float>();
+    a.ntaps = L1.ntaps[0];
+    a.part = h->FP.as<float>();
+    a.nsplit = FFN_SPLIT;
+    constexpr int HR = 32 * NJ1;
+    const int TV = HR - (a.ntaps - 1);
+    const size_t smem = (size_t)(HR + a.ntaps - 1 + 2) * Tile<H>::STRIDE + (size_t)(HR + a.ntaps - 1 + 2) * Tile<FS>::STRIDE;
+    auto kern = k_fr_ffn_part<OpT, H, FS, NJ1>;
+    static std::atomic<unsigned long long> attr_done{0};
+    ensure_dyn_lds(reinterpret_cast<const void*>(kern), attr_done);
+    const double flops = (L1.flops_per_pos + L2.flops_per_pos) * (double)a.T * B;
+    h->prof.launch("enc_ffn_part", flops, 0.0, st, [&] {
+        hipLaunchKernelGGL(kern, dim3((a.T + TV - 1) / TV, B, FFN_SPLIT), dim3(64 * (H / 32)), smem, st, a);
+    });
+    h->prof.launch("enc_ffn_ln", 0.0, 0.0, st, [&] {
+        hipLaunchKernelGGL(k_fr_ffn_ln<H>, dim3((unsigned)(((size_t)B * a.T + 3) / 4)), dim3(256), 0, st, (const float*)a.part, FFN_SPLIT, a.x, a.xo, a.b2,
+                           a.gamma, a.beta, a.len, a.T, B);
+    });
+    HIP_CHECK(hipGetLastError());
+}
 template <typename OpT>
 void launch_ffn(rvcmi_front* h, const FrFfnArgs& a, const ConvLayer& L1, const ConvLayer& L2, int B, hipStream_t st) {
     if (pick_nj(h, B, a.T) == 1) launch_ffn_nj<OpT, 1>(h, a, L1, L2, B, st);
@@ -253,7 +287,14 @@ void front_forward_t(rvcmi_front* h, int B, int T, const float* phone, const lon
             FrFfnArgs a = {};
             a.x = X; a.xo = X2; a.bstride = (long)T * H; a.T = T; a.len = lengths;
             a.gamma = L.g2.as<float>(); a.beta = L.b2.as<float>();
-            launch_ffn<OpT>(h, a, L.f1, L.f2, B, st);
+            // few time tiles (a single clip): split the hidden channels over 4x the blocks; option FR_FFN_SPLIT = 0 / 1 pins the choice
+            const int nj = pick_nj(h, B, T);
+            const long tiles = (long)((T + 32 * nj - 3) / (32 * nj - 2)) * B;
+            const bool split = c.kernel_size == 3 && c.filter_channels == 768 && (size_t)B * T <= FFN_SPLIT_ROWS &&
+                               h->opt.geti("FR_FFN_SPLIT", tiles <= 96 ? 1 : 0) != 0;
+            if (split && nj == 1) launch_ffn_split_nj<OpT, 1>(h, a, L.f1, L.f2s, L.f2, B, st);
+            else if (split) launch_ffn_split_nj<OpT, 2>(h, a, L.f1, L.f2s, L.f2, B, st);
+            else launch_ffn<OpT>(h, a, L.f1, L.f2, B, st);
             std::swap(X, X2);
         } else {
             {
@@ -382,7 +423,7 @@ rvcmi_front* front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* wei
     WeightMap wm;
     for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
     std::unique_ptr<rvcmi_front> h(new rvcmi_front);
-    h->opt.load_env({"FR_NJ", "FR_NO_FFN_FUSION", "FR_STAMPS"});
+    h->opt.load_env({"FR_NJ", "FR_NO_FFN_FUSION", "FR_FFN_SPLIT", "FR_STAMPS"});
     h->cfg = c;
     h->device = device;
     h->max_B = max_B;
@@ -445,6 +486,12 @@ rvcmi_front* front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* wei
                    wdata(wm, f + "conv_1.bias", {FC}), op);
         build_conv(L.f2, FC, H, 1, &ks, &zero, 1, [&](int co, int ci, int, int tap) { return W2[((size_t)co * FC + ci) * ks + tap]; },
                    wdata(wm, f + "conv_2.bias", {H}), op);
+        if (FC % FFN_SPLIT == 0) {
+            const int FSl = FC / FFN_SPLIT;
+            for (int sp = 0; sp < FFN_SPLIT; ++sp)  // conv_2 restricted to the input channels [sp * FSl, (sp + 1) * FSl): a conv of its own
+                build_conv(L.f2s[sp], FSl, H, 1, &ks, &zero, 1,
+                           [&](int co, int ci, int, int tap) { return W2[((size_t)co * FC + sp * FSl + ci) * ks + tap]; }, nullptr, op);
+        }
     }
     auto paired = [&](int cop, int Hh) {  // packed row -> original row for [a-tile, b-tile] pairs (b rows start at Hh)
         const int tile = cop / 32, pair = tile / 2, which = tile % 2;
@@ -520,6 +567,7 @@ rvcmi_front* front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* wei
     A(h->Hb, BT * H * 4);
     A(h->SK, BT * H * 4);
     A(h->GC, (size_t)max_B * gcn * c.flow_n_flows * 4 + 16);
+    A(h->FP, (size_t)FFN_SPLIT * std::min(BT, FFN_SPLIT_ROWS) * H * 4);
     HIP_CHECK(hipMemset(h->VT.p, 0, h->VT.bytes));  // key padding columns must stay finite
     HIP_CHECK(hipMemset(h->KF.p, 0, h->KF.bytes));
     h->ws_bytes = ws;

@@ -756,6 +756,11 @@ struct FrFfnArgs {
     int ntaps;          // kernel size (odd)
     const float* gamma;
     const float* beta;
+    // split form (k_fr_ffn_part + k_fr_ffn_ln): conv_2 re-packed per slice of the hidden channels, fp32 partial sums [S][B][T][H]
+    const void* w2s[4];
+    long ct2s;
+    float* part;
+    int nsplit;
 };
 
 template <typename OpT, int H, int F, int NJ1>
@@ -906,6 +911,137 @@ static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_ffn(FrFfnArgs a) {
                 *(f32x4*)(a.xo + boff + (size_t)tt[jt] * H + cb + 8 * g) = o;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The FFN for SMALL grids (one clip: 38 time tiles on 256 CUs).  In k_fr_ffn every block streams ALL of a layer's FFN weights
+// (1.77 MB at H = 192, F = 768, k = 3) through one CU's L1 at 64 B/clk: 27.6k cycles before anything else, 43 us per layer for
+// 2.1 GFLOP.  Here grid.z = S slices of the hidden channels: block (tile, b, s) computes ITS F / S hidden channels (conv_1 + relu
+// + mask -> LDS), multiplies them with its slice of conv_2 (re-packed per slice on the host) and writes the fp32 partial sums
+// [rows][H]; k_fr_ffn_ln adds the S partials in slice order, bias, mask, residual and applies the LayerNorm.  4x the blocks, a
+// quarter of the weight stream each.  (The partial sums add in a different order than one long K loop: last-bit differences.)
+// ------------------------------------------------------------------------------------------------
+template <typename OpT, int H, int FS, int NJ1>
+static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_ffn_part(FrFfnArgs a) {
+    using TLH = Tile<H>;
+    using TLF = Tile<FS>;
+    using o4 = __attribute__((ext_vector_type(4))) OpT;
+    constexpr int NW = H / 32;
+    constexpr int NT = 64 * NW;
+    constexpr int HR = 32 * NJ1;
+    static_assert(FS == 32 * NW, "one hidden-channel tile per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.y, sl = blockIdx.z;
+    const int pad = (a.ntaps - 1) / 2;
+    const int TV = HR - 2 * pad;
+    const int q0 = blockIdx.x * TV;
+    const int h0 = q0 - pad;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hl = lane >> 5;
+    const int xrows = HR + a.ntaps - 1 + 2;
+    char* XS = smem;
+    char* HS = smem + (size_t)xrows * TLH::STRIDE;  // hidden tile [HR + ntaps - 1 + 2][FS]
+    const long boff = (long)b * a.bstride;
+    const long long lenb = a.len ? a.len[b] : (long long)a.T;
+    const int lenrow = (int)(lenb < (long long)a.T ? lenb : (long long)a.T);
+
+    const OpT* w1lane = (const OpT*)a.w1 + (size_t)(sl * NW + wave) * a.ct1 + lane * 8;
+    constexpr int NBF = NJ1 == 1 ? FR_NB : 2;
+    typename Op<OpT>::frag Aw[NBF][KGROUP][1];
+    conv_prefetch<OpT, H, 1, KGROUP, NBF>(Aw, w1lane, a.ct1, a.ntaps);
+    fr_stage<OpT, H, NT>(XS, a.x, 0, boff, a.T, h0 - pad, xrows, lenrow);
+    for (int i = threadIdx.x; i < (a.ntaps - 1 + 2) * (TLF::STRIDE / 4); i += NT) ((unsigned*)(HS + (size_t)HR * TLF::STRIDE))[i] = 0u;
+    __syncthreads();
+
+    // ---- conv_1 (this slice's hidden channels) + relu + mask -> hidden tile ----
+    const char* x_lane = XS + (size_t)(lane & 31) * TLH::STRIDE + hl * 16;
+    {
+        f32x16 acc[1][NJ1];
+#pragma unroll
+        for (int jt = 0; jt < NJ1; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][jt][e] = 0.f;
+        conv_run<OpT, H, 1, NJ1, KGROUP, NBF>(acc, Aw, x_lane, w1lane, a.ct1, a.ntaps, 0, 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = wave * 32 + 8 * g + 4 * hl;  // channel inside the slice
+            const f32x4 bb = *(const f32x4*)(a.b1 + sl * FS + cl);
+#pragma unroll
+            for (int jt = 0; jt < NJ1; ++jt) {
+                const int hr = jt * 32 + (lane & 31);
+                const int t = h0 + hr;
+                const float mk = (t >= 0 && t < lenrow) ? 1.f : 0.f;
+                o4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(fmaxf(acc[0][jt][4 * g + e] + bb[e], 0.f) * mk);
+                *(o4*)(HS + (size_t)hr * TLF::STRIDE + cl * 2) = o;
+            }
+        }
+    }
+    // ---- this slice's part of conv_2 ----
+    const OpT* w2lane = (const OpT*)a.w2s[sl] + (size_t)wave * a.ct2s + lane * 8;
+    typename Op<OpT>::frag Aw2[NBF][KGROUP][1];
+    conv_prefetch<OpT, FS, 1, KGROUP, NBF>(Aw2, w2lane, a.ct2s, a.ntaps);
+    __syncthreads();
+    f32x16 acc2[1][NJ1];
+#pragma unroll
+    for (int jt = 0; jt < NJ1; ++jt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[0][jt][e] = 0.f;
+    const char* h_lane = HS + (size_t)(lane & 31) * TLF::STRIDE + hl * 16;
+    conv_run<OpT, FS, 1, NJ1, KGROUP, NBF>(acc2, Aw2, h_lane, w2lane, a.ct2s, a.ntaps, 0, 1);
+    const int cb = wave * 32 + 4 * hl;
+    float* pp = a.part + ((size_t)sl * gridDim.y + b) * (size_t)a.T * H;
+#pragma unroll
+    for (int jt = 0; jt < NJ1; ++jt) {
+        const int j = jt * 32 + (lane & 31);
+        const int t = q0 + j;
+        if (j < TV && t < a.T) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 o = {acc2[0][jt][4 * g + 0], acc2[0][jt][4 * g + 1], acc2[0][jt][4 * g + 2], acc2[0][jt][4 * g + 3]};
+                *(f32x4*)(pp + (size_t)t * H + cb + 8 * g) = o;
+            }
+        }
+    }
+}
+
+// y = LayerNorm(x + (sum_s part[s] + b2) * mask)   (encoders.py:78-80); one wave per row, H = 64 * CPL channels
+template <int H>
+static __global__ void __launch_bounds__(256) k_fr_ffn_ln(const float* __restrict__ part, int nsplit, const float* __restrict__ x, float* __restrict__ xo,
+                                                          const float* __restrict__ b2, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const long long* __restrict__ len, int T, int B) {
+    constexpr int CPL = H / 64;
+    static_assert(H % 64 == 0, "channels per lane");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= (long)B * T) return;
+    const int b = (int)(row / T), t = (int)(row - (long)b * T);
+    const float pm = (len ? (long long)t < len[b] : true) ? 1.f : 0.f;
+    float v[CPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        float p = part[(size_t)row * H + c];
+        for (int s = 1; s < nsplit; ++s) p += part[((size_t)s * B * T + row) * H + c];
+        v[i] = x[(size_t)row * H + c] + (p + b2[c]) * pm;
+        sum += v[i];
+    }
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / (float)H;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        v[i] -= mean;
+        s2 += v[i] * v[i];
+    }
+    for (int off = 32; off >= 1; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+    const float rstd = 1.f / sqrtf(s2 / (float)H + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        xo[(size_t)row * H + c] = v[i] * rstd * gamma[c] + beta[c];
     }
 }
 

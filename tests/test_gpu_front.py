@@ -166,16 +166,18 @@ def test_front_rejects_bad_input(gpu):
         rvc_amd.FrontHIP(vars(FrontConfig(n_heads=4)), wf, device=gpu)
 
 
-@pytest.mark.parametrize("fused_ffn", [True, False])
+@pytest.mark.parametrize("fused_ffn", [True, False, "split", "split_nj1"])
 def test_front_large_batch_tile_height_and_unfused_ffn(fused_ffn, gpu):
-    """Large batches run 64-row time tiles (pick_nj) and the FFN can run as two launches: force both code paths on a
-    small golden input (they are otherwise only reached at B*T/64 >= 192) through the handle's test options."""
+    """Large batches run 64-row time tiles (pick_nj) and the FFN exists in three forms -- one fused launch (k_fr_ffn, large
+    grids), two plain conv launches, and the split form for small grids (k_fr_ffn_part: hidden channels over 4x the blocks +
+    k_fr_ffn_ln) -- : force every code path on a small golden input through the handle's test options."""
     for name in ("front_v2_B2_T50", "front_v2_B1_T100_head6"):
         d = load_golden(name)
         fcfg, wf = front_weights(d, int(d["in_channels"]))
         fr = hip_front(fcfg, wf, "fp16", gpu)
-        fr.set_option("FR_NJ", 2)
-        if not fused_ffn:
+        fr.set_option("FR_NJ", 1 if fused_ffn == "split_nj1" else 2)
+        fr.set_option("FR_FFN_SPLIT", 1 if str(fused_ffn).startswith("split") else 0)
+        if fused_ffn is False:
             fr.set_option("FR_NO_FFN_FUSION", 1)
         fh = max(int(d["flow_head"]), 0)
         z = fr(dev(d, "phone", gpu), dev(d, "pitch", gpu), dev(d, "lengths", gpu), dev(d, "g", gpu), fh, noise=dev(d, "noise", gpu)).cpu()
