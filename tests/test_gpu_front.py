@@ -259,6 +259,8 @@ def test_front_batch_16_equals_single_clips(gpu):
     nz = torch.randn(B, 192, T, generator=torch.Generator().manual_seed(8))
     g = wf["emb_g.weight"][sid].unsqueeze(-1)
     fr = hip_front(fcfg, wf, "fp16", gpu, max_B=B, max_T=T)
+    # (the FFN form pinned: a single clip would otherwise take the split form, whose partial sums add in another order)
+    fr.set_option("FR_FFN_SPLIT", 0)
     z = fr(phone.to(gpu), pitch.to(gpu), lengths.to(gpu), g.to(gpu), 0, noise=nz.to(gpu))
     assert z.shape == (B, 192, T) and torch.isfinite(z).all()
     for b in (0, 5, 15):
@@ -267,6 +269,9 @@ def test_front_batch_16_equals_single_clips(gpu):
         assert e <= 1e-6, "front batch item %d differs from its single-clip result: %.3e" % (b, e)
         if int(lengths[b]) < T:
             assert float(z[b, :, int(lengths[b]):].abs().max()) == 0.0  # masked tail
+    fr.set_option("FR_FFN_SPLIT", None)   # the launcher's own choice for one clip (split): same z to operand rounding
+    one = fr(phone[5:6].to(gpu), pitch[5:6].to(gpu), lengths[5:6].to(gpu), g[5:6].to(gpu), 0, noise=nz[5:6].to(gpu))
+    assert rms(one[0].cpu(), z[5].cpu()) <= 2e-3
     with torch.no_grad():
         zr, m1, _ = front_oracle.infer_front(fcfg, wf, phone[15:16], pitch[15:16], lengths[15:16], sid[15:16], nz[15:16])
     assert rms(z[15:16].cpu(), zr * m1) <= Z_BAR["fp16"]
