@@ -132,6 +132,11 @@ def build(verbose: bool = True, force: bool = False) -> str:
         o = os.path.join(CSRC, os.path.basename(s) + ".o")
         objs.append(o)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        if not os.environ.get("RVCMI_NO_MFMA_VGPR_FORM"):
+            # MFMA results in VGPRs wherever the 256 architectural VGPRs allow it: by default LLVM puts every accumulator in an
+            # AGPR and copies it out with v_accvgpr_read for each VALU use (publish, bias, residual) -- 21 000 such copies in
+            # nsf.hip alone, none with this option; the 512-register kernels keep their overflow in AGPRs
+            cmd[1:1] = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
         for d_ in os.environ.get("RVCMI_DEFINES", "").split():
             cmd.insert(1, "-D" + d_)  # dev: geometry experiments, e.g. RVCMI_DEFINES="RBF32_NWV=8"
         if os.environ.get("RVCMI_DEV_STAMPS"):
