@@ -8,7 +8,7 @@ KEEP = ("k_rb_pair", "k_rb_full", "k_rb_stream", "k_frame_rms", "k_change_rms", 
         "k_rmvpe", "k_phase_scan", "k_sine")
 with tempfile.TemporaryDirectory() as tmp:
     for src in ("nsf.hip", "rb_stream.hip", "ivf.hip", "front.hip", "glue.hip"):
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(CSRC, src), "-o",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-O3", "-std=c++17", "-c", os.path.join(CSRC, src), "-o",
                         os.path.join(tmp, src + ".o"), "-save-temps=obj"], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         asm = [f for f in os.listdir(tmp) if f.startswith(src.split(".")[0] + "-hip-amdgcn") and f.endswith(".s")]
         if not asm:
