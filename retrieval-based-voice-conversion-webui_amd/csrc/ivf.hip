@@ -1075,6 +1075,7 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
         RVCMI_FAIL(RVCMI_ERR_INVALID, "k=%d outside [1,%d]: the kernels keep at most %d neighbours per query (RVC asks for 8, "
                    "pipeline.py:126; legacy top-1 tools/cmd/infer-pm-index256.py:161)", k, KMAX, KMAX);
     if (nq == 0) return false;
+    DeviceGuard dg(h->device);  // a C caller's current device need not be the handle's (restored on return)
     reserve(h, nq);
     const BlobHeader& b = h->hdr;
     const int d = b.d;
