@@ -954,6 +954,17 @@ __device__ __forceinline__ void publish_operand(char* base, const f32x16 (&acc)[
             }
 }
 
+// Block barrier that orders LDS traffic ONLY: __syncthreads() carries a workgroup release fence over global memory too, i.e. an
+// s_waitcnt vmcnt(0) in front of every s_barrier -- which would drain the weight fragments requested for the next slot (a full
+// L2 round trip, exposed four times per pair-step).  The waves of a block exchange data through LDS only.
+// (Measured for k_rb_pair / k_rb_full, whose two-plus waves per SIMD already hide that round trip: +1 % time -- they keep __syncthreads.)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Fused ResBlock1 pair (residuals.py:73-82):   x <- conv2(lrelu(conv1_dil(lrelu(x)) + b1)) + b2 + x
 // ------------------------------------------------------------------------------------------------

@@ -30,15 +30,6 @@ constexpr int RS2_STRIDE = 256;
 constexpr int RS2_HEAD = 52;   // first M row of the new X / H rows; X history (<= 52 rows) / H history (<= 10) in front
 constexpr int RS2_SLACK = 3;   // the B prefetch past the last tap reads up to p1 + p2 + dil - 32 <= 3 rows behind the tile (unused)
 
-// Block barrier that orders LDS traffic ONLY: __syncthreads() carries a workgroup release fence over global memory too, i.e. an
-// s_waitcnt vmcnt(0) in front of every s_barrier -- which would drain the weight fragments requested for the next slot (a full
-// L2 round trip, exposed four times per pair-step).  The waves of a block exchange data through LDS only.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
 using lds_cptr = const __attribute__((address_space(3))) char*;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;  // (uint4 is a class type: no address-space-qualified copies)
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
