@@ -375,3 +375,36 @@ def test_three_instruction_division_by_three_is_the_ieee_quotient():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.mismatches(0, 1.0) == 0 and m.mismatches(3, -1.0) == 0
+
+
+@pytest.mark.parametrize("k,dils,L,strips", [(11, [1, 3, 5], 1000, 3), (3, [1, 3, 5], 300, 1), (7, [3, 5], 777, 2)])
+def test_streaming_resblock_schedule_models(k, dils, L, strips):
+    """tools/model_rb_stream.py restates the buffer layouts, row arithmetic, masks, history copies / dual writes and (k_rb_stream3)
+    the slot-by-slot filler schedule of the streaming ResBlock kernels in numpy; every variant must equal a direct evaluation of
+    ResBlock1 (rvc/layers/residuals.py:68-85), and run_strip3 additionally asserts that no filler writes a row its K loop reads."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("model_rb_stream", os.path.join(os.path.dirname(__file__), "..", "tools", "model_rb_stream.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.default_rng(k)
+    C, nd = 16, len(dils)
+    W1 = [rng.standard_normal((C, C, k), dtype=np.float32) / np.float32(np.sqrt(C * k)) for _ in range(nd)]
+    W2 = [rng.standard_normal((C, C, k), dtype=np.float32) / np.float32(np.sqrt(C * k)) for _ in range(nd)]
+    B1 = [(rng.standard_normal(C, dtype=np.float32) * np.float32(0.1)).astype(np.float32) for _ in range(nd)]
+    B2 = [(rng.standard_normal(C, dtype=np.float32) * np.float32(0.1)).astype(np.float32) for _ in range(nd)]
+    x = rng.standard_normal((L, C), dtype=np.float32)
+    ref = m.reference(x, W1, B1, W2, B2, k, dils)
+    sl = -(-L // strips)
+    for variant in ("v1", "v2", "v3"):
+        out = np.full((L, C), np.nan, np.float32)
+        for s_ in range(strips):
+            S0, S1 = s_ * sl, min(L, (s_ + 1) * sl)
+            if variant == "v1":
+                m.run_strip(x, W1, B1, W2, B2, k, dils, S0, S1, 192, out)
+            elif variant == "v2":
+                m.run_strip2(x, W1, B1, W2, B2, k, dils, S0, S1, 96, out)
+            else:
+                m.run_strip3(x, W1, B1, W2, B2, k, dils, S0, S1, out)
+        assert np.isfinite(out).all() and np.abs(out - ref).max() < 2e-4, variant
