@@ -44,7 +44,8 @@ struct rvcmi_front {
     DevBuf FP;           // split FFN: fp32 partial sums [4][rows <= FFN_SPLIT_ROWS][H]
     size_t ws_bytes = 0;
     Profiler prof;
-    // dev / test options (common.hpp Options): FR_NJ (1 / 2: time-tile height), FR_NO_FFN_FUSION, FR_STAMPS (prints; syncs).
+    // dev / test options (common.hpp Options): FR_NJ (1 / 2: time-tile height), FR_NO_FFN_FUSION, FR_FFN_SPLIT (0 / 1: the FFN with its
+    // hidden channels split over 4x the blocks; default by grid size), FR_STAMPS (prints; syncs).
     // Read from RVCMI_<KEY> once, in rvcmi_front_create; changed afterwards only through rvcmi_front_set_option.
     rvcmi::Options opt;
 };

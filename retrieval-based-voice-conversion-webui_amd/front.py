@@ -161,7 +161,7 @@ class FrontHIP(torch.nn.Module):
         return self._run(phone, pitch, lengths, g, noise, flow_head, tap=what)
 
     def set_option(self, key: str, value=None) -> None:
-        """Dev / test option of this handle (``rvcmi_front_set_option``: ``FR_NJ``, ``FR_NO_FFN_FUSION``); ``None`` = default."""
+        """Dev / test option of this handle (``rvcmi_front_set_option``: ``FR_NJ``, ``FR_NO_FFN_FUSION``, ``FR_FFN_SPLIT``); ``None`` = default."""
         if not hasattr(self, "_options"):
             self._options = {}
         if value is None:

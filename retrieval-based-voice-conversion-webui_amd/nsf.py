@@ -114,7 +114,7 @@ class _HipGenerator(torch.nn.Module):
 
     def set_option(self, key: str, value=None) -> None:
         """Dev / test option of this handle (``rvcmi_nsf_set_option``: e.g. ``RB_STREAM`` 0 / 1 pins the ResBlock kernel family,
-        ``RS_SMALL``, ``DBG``); ``None`` restores the default.  The library reads ``RVCMI_<KEY>`` only when a handle is created."""
+        ``RS_SMALL``, ``RS_KL``, ``RS_V2`` / ``RS_V2X`` / ``RS_V3`` (the opt-in streaming variants), ``DBG``); ``None`` restores the default.  The library reads ``RVCMI_<KEY>`` only when a handle is created."""
         if not hasattr(self, "_options"):
             self._options = {}
         if value is None:
