@@ -21,6 +21,11 @@
 // the weight ring is one whole tap (8 k-steps = 768 cycles) deep and refilled in place, and B fragments are read TWO k-steps
 // ahead.  Global IO (x rows in, x' rows out, D-layout) stays outside the K loops: VMEM in a filler would put the weight ring's
 // vmcnt behind HBM latencies.
+//
+// MEASURED (round 3): parity-green, 0.704 vs 0.641 ms per clip for k_rb_stream -- the plain taps run at 40.5 cycles per
+// MFMA like k_rb_stream's loop, but the 72 gaps with fillers take ~70: the compiler needs 7-9 instructions per gap where a lone wave
+// hides five, and the half tiles stream the weights out of L2 twice as fast.  Opt-in (RS_V3=1); kept as the reference for the
+// slot / filler machinery (rs3_conv, rs3_gap) that k_rb_stream2x's K loop reuses.
 #pragma once
 #include <type_traits>
 
