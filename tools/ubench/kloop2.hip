@@ -4,6 +4,8 @@
 // and reports cycles per MFMA per SIMD.  It answers: what does one extra instruction in an MFMA gap cost a lone wave (the
 // model T = max(32, a + b n) fitted in DESIGN.md), does one s_waitcnt per k-step instead of one per MFMA matter, what do
 // MI = 2 tiles (half the B reads) buy, and how much of it a second wave per SIMD hides.
+// Build / run:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o kloop2 kloop2.hip && ./kloop2   (output of round 3:
+// profiles/r03_ubench_kloop2_issue_model.txt)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
