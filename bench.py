@@ -609,6 +609,7 @@ def main():
         # effective 1.52 GHz = 1505 TFLOP/s; an MFMA-only loop: 1804 TFLOP/s at 1.74 GHz).
         if a.operand in ("fp16", "bf16"):
             roof["ubench_ceiling"] = {"kloop_tflops": 1505.0, "mfma_only_tflops": 1804.0, "frac_of_kloop_ceiling": ach / 1505e12,
+                                      "kind": "constants from a committed micro-benchmark run, NOT measured in this run",
                                       "source": "profiles/r03_ubench_kloop2_issue_model.txt (measured on an MI355X of this pool, round 3)"}
         scan = [s for s in ivs if s["name"] == "ivf_scan"]
         if scan and scan[0]["ms"] > 0:

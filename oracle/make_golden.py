@@ -270,19 +270,57 @@ def front_full_case(name: str = "bigfront_v2_B1_T1198_z", T: int = 1198, seed: i
         name, z.pow(2).mean().sqrt().item(), err, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
 
 
+class NumpyFaissIndex:
+    """The faiss index OBJECT as the reference's pipeline uses it (pipeline.py:214-215,126: ``ntotal``, ``reconstruct_n``,
+    ``search``), answered by the CPU oracle (oracle/ivf_oracle.py) on a file in the IwFl layout.  faiss itself is not
+    installable offline: what this pins is every line of the reference AROUND the faiss calls, not faiss' arithmetic."""
+
+    def __init__(self, path):
+        from oracle import ivf_oracle
+
+        self._ix = ivf_oracle.read_index(path)
+        self.ntotal = int(self._ix["ids"].shape[0])
+        self.searches = 0
+
+    def reconstruct_n(self, i0, n):
+        from oracle import ivf_oracle
+
+        return ivf_oracle.reconstruct_n(self._ix, i0, n)
+
+    def search(self, x, k):
+        from oracle import ivf_oracle
+
+        assert x.dtype == np.float32 and x.flags.c_contiguous
+        self.searches += 1
+        return ivf_oracle.search(self._ix, x, k)
+
+
 def import_reference_pipeline():
     """The REAL ``infer.modules.vc.pipeline`` of the reference.  Its module-level imports of faiss / librosa and numba's ``jit``
-    (rvc/f0/gen.py) are not installable offline and are NOT used by the code paths exercised here (no index file, rms_mix_rate 1,
-    no resample, precomputed f0): they are replaced by empty stand-ins for the import only."""
+    (rvc/f0/gen.py) are not installable offline; stand-ins carry exactly the four names the exercised lines call:
+    ``faiss.read_index`` -> ``NumpyFaissIndex`` (CPU oracle), ``librosa.feature.rms`` -> ``glue_oracle.frame_rms`` (restatement
+    of librosa's documented behaviour, unpinned), ``librosa.filters.mel`` / ``librosa.util.pad_center`` (import-time names of
+    rvc/f0/mel.py and stft.py, never called: the mel front end of the fake RMVPE is a stand-in), ``numba.jit`` -> identity."""
     import types
 
-    for name in ("faiss", "librosa", "numba"):
-        if name not in sys.modules:
-            m = types.ModuleType(name)
-            if name == "numba":
-                m.jit = lambda *a, **k: (lambda f: f)
-            sys.modules[name] = m
-    sys.path.insert(0, REF)
+    from oracle import glue_oracle
+
+    nb = types.ModuleType("numba")
+    nb.jit = lambda *a, **k: (lambda f: f)
+    fa = types.ModuleType("faiss")
+    fa.read_index = NumpyFaissIndex
+    lb = types.ModuleType("librosa")
+    lb.__path__ = []
+    for sub, names in (("filters", ["mel"]), ("util", ["pad_center"]), ("feature", [])):
+        m = types.ModuleType("librosa." + sub)
+        for n in names:
+            setattr(m, n, None)
+        setattr(lb, sub, m)
+        sys.modules["librosa." + sub] = m
+    lb.feature.rms = lambda y, frame_length, hop_length: glue_oracle.frame_rms(y, frame_length, hop_length)[None]
+    sys.modules.update(numba=nb, faiss=fa, librosa=lb)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
     os.environ.setdefault("rmvpe_root", "/nonexistent")
     import importlib.util
 
@@ -350,6 +388,105 @@ def pipeline_case(name: str = "pipeline_v2_48k_3seg", n_audio: int = 38400, seed
                         **{"cfg_" + k: v for k, v in PIPE_CFG.items()})
     print("%-28s out rms %.1f (int16 range), segments %s, scale %.1f  (%d KB)" % (
         name, float(np.sqrt(np.mean(out.astype(np.float64) ** 2))), lens, scale, os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
+def reference_rmvpe(seed: int):
+    """A REAL ``rvc.f0.rmvpe.RMVPE`` object without its constructor (which loads the checkpoint and builds librosa's mel filter
+    bank): ``compute_f0``, ``_mel2hidden``, ``_decode``, ``_to_local_average_cents`` and the ``F0Predictor`` resize /
+    interpolate methods are the reference's own; only the mel front end and the network are the seeded stand-ins of
+    oracle/synth.py."""
+    from rvc.f0.rmvpe import RMVPE
+
+    r = RMVPE.__new__(RMVPE)
+    r.hop_length, r.f0_min, r.f0_max, r.sampling_rate = 160, 30, 8000, 16000
+    r.device, r.is_half = torch.device("cpu"), False
+    r.cents_mapping = np.pad(20 * np.arange(360) + 1997.3794084376191, (4, 4))  # rmvpe.py:62-63
+    r.mel_extractor, r.model = synth.FakeMel(), synth.FakeRMVPEModel(seed)
+    return r
+
+
+WEBUI = dict(f0_method="rmvpe", index_rate=0.75, filter_radius=3, resample_sr=0, rms_mix_rate=0.25, protect=0.33, f0_up_key=0)
+WEBUI_INDEX = dict(n=3000, d=768, seed=11)
+
+
+def pipeline_webui_case(name: str = "pipeline_v2_48k_webui", n_audio: int = 38400, seed: int = 1234, f0_up_key: int = 0):
+    """The reference's own ``Pipeline.pipeline`` with the WebUI's single-inference defaults (web.py:756-802: rmvpe,
+    index_rate 0.75 WITH an index file, filter_radius 3, rms_mix_rate 0.25, protect 0.33, if_f0 1): ``faiss.read_index`` +
+    ``reconstruct_n`` (pipeline.py:214-215), ``Generator.calculate`` -> ``RMVPE.compute_f0`` -> ``post_process`` (gen.py:103-137),
+    three ``Pipeline.vc`` calls WITH the retrieval branch (pipeline.py:113-138), ``change_rms`` (pipeline.py:26-46), int16 scaling.
+    Stand-ins: HuBERT, the RMVPE mel + network, the faiss object (CPU oracle), ``librosa.feature.rms`` (restatement)."""
+    import hashlib
+    import tempfile
+    import types
+
+    from oracle import ivf_oracle
+
+    pl = import_reference_pipeline()
+    cfg, fcfg = CONFIGS["v2_48k"], FrontConfig()
+    wd, wf = synth.make_dec_weights(cfg, seed), synth.make_front_weights(fcfg, seed)
+    net = build_reference_net(cfg, fcfg, wd, wf)
+    config = types.SimpleNamespace(device=torch.device("cpu"), **PIPE_CFG)
+    pipe = pl.Pipeline(cfg.sr, config)
+    pipe.f0_gen.rmvpe = reference_rmvpe(seed)
+    audio = synth.make_audio16k(n_audio, seed)
+    idx = synth.make_ivf(WEBUI_INDEX["n"], WEBUI_INDEX["d"], seed=WEBUI_INDEX["seed"])
+    lens, raw, pitches, found = [], [], [], []
+    orig_infer, orig_vc, orig_read = net.infer, pl.Pipeline.vc, pl.faiss.read_index
+
+    def infer_spy(phone, lengths, *a, **k):
+        lens.append(int(phone.shape[1]))
+        return orig_infer(phone, lengths, *a, **k)
+
+    def vc_spy(self, model, net_g, sid, audio0, pitch, pitchf, times, index, big_npy, *a, **k):
+        assert isinstance(index, NumpyFaissIndex) and big_npy.shape == (WEBUI_INDEX["n"], WEBUI_INDEX["d"])
+        found.append(index)
+        pitches.append((pitch[0].numpy().copy(), pitchf[0].numpy().copy()))
+        o = orig_vc(self, model, net_g, sid, audio0, pitch, pitchf, times, index, big_npy, *a, **k)
+        raw.append(o.copy())
+        return o
+
+    net.infer = infer_spy
+    pl.Pipeline.vc = vc_spy
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "added.index")
+        ivf_oracle.write_index(idx, path)
+        try:
+            torch.manual_seed(114514)
+            times = [0, 0, 0]
+            out = pipe.pipeline(synth.FakeHubert(768, seed), net, 3, audio.copy(), times, f0_up_key, WEBUI["f0_method"], path,
+                                WEBUI["index_rate"], 1, WEBUI["filter_radius"], cfg.sr, WEBUI["resample_sr"], WEBUI["rms_mix_rate"],
+                                "v2", WEBUI["protect"])
+        finally:
+            pl.Pipeline.vc = orig_vc
+    assert len(lens) == 3 and found[0].searches == 3 and pipe.f0_gen.rmvpe.model.calls == 1, (lens, found[0].searches)
+    h = hashlib.sha256()
+    for nz, nd in synth.infer_noise(lens, cfg.upp):
+        h.update(nz.numpy().tobytes())
+        h.update(nd.numpy().tobytes())
+    # the f0 track the reference computed for the whole padded input (its three vc calls see overlapping slices of it)
+    p_len_all = (n_audio + 2 * pipe.t_pad) // pipe.window
+    sal = pipe.f0_gen.rmvpe._mel2hidden(synth.FakeMel()(torch.zeros(1, n_audio + 2 * pipe.t_pad))).squeeze(0).numpy()
+    from oracle import glue_oracle
+
+    o_pitch, o_pitchf = glue_oracle.rmvpe_f0(sal, p_len_all, f0_up_key, 0.03)
+    assert np.array_equal(pitches[0][0], o_pitch[: len(pitches[0][0])]) and np.array_equal(pitches[0][1], o_pitchf[: len(pitches[0][1])])
+    # what the oracle restatements make of the same three raw segments: change_rms + scaling (pins the glue oracle end to end)
+    cat = np.concatenate([r[pipe.t_pad_tgt:-pipe.t_pad_tgt] for r in raw])
+    from scipy import signal as sg
+
+    a_hp = sg.filtfilt(pl.bh, pl.ah, audio)
+    ora = glue_oracle.scale_int16_range(glue_oracle.change_rms(a_hp, 16000, cat, cfg.sr, WEBUI["rms_mix_rate"]))
+    assert np.allclose(ora, out, rtol=1e-6, atol=1e-3)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), seed=seed, n_audio=n_audio, sid=3, out=out.astype(np.float32),
+                        seg_frames=np.array(lens), pitch=o_pitch, pitchf=o_pitchf, noise_sha256=h.hexdigest(),
+                        index_n=WEBUI_INDEX["n"], index_d=WEBUI_INDEX["d"], index_seed=WEBUI_INDEX["seed"],
+                        index_rate=WEBUI["index_rate"], filter_radius=WEBUI["filter_radius"], rms_mix_rate=WEBUI["rms_mix_rate"],
+                        protect=WEBUI["protect"], f0_up_key=f0_up_key, voiced_frames=int((o_pitchf > 0).sum()),
+                        front_sha256=synth.weights_sha256(wf), dec_sha256=synth.weights_sha256(wd),
+                        **{"cfg_" + k: v for k, v in PIPE_CFG.items()})
+    print("%-28s out rms %.1f (int16 range), segments %s, %d of %d frames voiced  (%d KB)" % (
+        name, float(np.sqrt(np.mean(out.astype(np.float64) ** 2))), lens, int((o_pitchf > 0).sum()), p_len_all,
+        os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
 
 
 def glue_case(name: str = "glue_f0"):
@@ -454,8 +591,11 @@ def main():
         return dec_full_case()
     if os.environ.get("GOLDEN_ONLY_MUTE"):
         return mute_case()
+    if os.environ.get("GOLDEN_ONLY_WEBUI"):
+        return pipeline_webui_case()
     if os.environ.get("GOLDEN_ONLY_PIPELINE"):
         pipeline_case()
+        pipeline_webui_case()
         return front_full_case()
     mute_case()
     main_front()
@@ -473,6 +613,7 @@ def main():
     infer_case()
     dec_full_case()
     pipeline_case()
+    pipeline_webui_case()
     front_full_case()
 
 

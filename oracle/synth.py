@@ -337,3 +337,57 @@ def infer_noise(lengths, upp: int, seed: int = 114514):
         nd = torch.randn(1, int(T) * upp, 1, generator=gen).squeeze(-1)
         out.append((nz, nd))
     return out
+
+
+class FakeMel:
+    """Stands in for ``rvc.f0.mel.MelSpectrogram`` (needs librosa's filter bank) as ``RMVPE.compute_f0`` calls it
+    (rvc/f0/rmvpe.py:113): ``mel_extractor(wav [1, n], center=True)`` -> ``[1, 128, n // 160 + 1]`` (the frame count of a
+    centred STFT with hop 160).  The values carry nothing; the fake network below only looks at the frame count."""
+
+    def __call__(self, audio, center=True):
+        assert audio.dim() == 2 and audio.shape[0] == 1 and center
+        return torch.zeros(1, 128, int(audio.shape[1]) // 160 + 1, device=audio.device, dtype=torch.float32)
+
+
+class FakeRMVPEModel:
+    """Stands in for the RMVPE network (rvc/f0/models.py; its checkpoint is not available offline) as ``RMVPE._mel2hidden``
+    calls it (rvc/f0/rmvpe.py:144-163): mel ``[1, 128, n_pad]`` -> salience ``[1, n_pad, 360]``.  The salience is a seeded
+    function of the frame count only: a Gaussian bump (peak 0.5 .. 0.95) around a wandering cents bin on voiced frames, noise
+    below the 0.03 voicing threshold everywhere else, unvoiced runs of 12 frames every 67 -- made on the CPU in float32 and
+    moved to the caller's device, so both sides of a parity test see the same bits."""
+
+    def __init__(self, seed: int = 1234):
+        self.seed, self.calls = seed, 0
+
+    def __call__(self, mel):
+        n = int(mel.shape[-1])
+        self.calls += 1
+        rng = np.random.default_rng(self.seed + n)
+        sal = (rng.random((n, 360), dtype=np.float32) * np.float32(0.02)).astype(np.float32)
+        t = np.arange(n)
+        centre = np.rint(150 + 70 * np.sin(t / 23.0) + 25 * np.sin(t / 5.0)).astype(np.int64)
+        voiced = (t % 67) >= 12
+        peak = (0.5 + 0.45 * rng.random(n)).astype(np.float32)
+        w = np.arange(-6, 7)
+        bump = np.exp(-0.5 * (w / 2.0) ** 2).astype(np.float32)
+        for i in np.nonzero(voiced)[0]:
+            k = centre[i] + w
+            ok = (k >= 0) & (k < 360)
+            sal[i, k[ok]] += peak[i] * bump[ok]
+        return torch.from_numpy(sal).unsqueeze(0).to(mel.device, mel.dtype)
+
+
+class FakeRMVPE:
+    """What ``rvc_amd.pipeline`` needs of an ``rvc.f0.rmvpe.RMVPE`` instance (the GPU box has no reference checkout): the mel
+    extractor, the network call with its pad-to-32 / crop (rvc/f0/rmvpe.py:144-163), ``device`` and ``is_half``.  No decode."""
+
+    def __init__(self, device, seed: int = 1234):
+        self.device, self.is_half = device, False
+        self.mel_extractor, self.model = FakeMel(), FakeRMVPEModel(seed)
+
+    def _mel2hidden(self, mel):
+        n_frames = mel.shape[-1]
+        n_pad = 32 * ((n_frames - 1) // 32 + 1) - n_frames
+        if n_pad > 0:
+            mel = torch.nn.functional.pad(mel, (0, n_pad), mode="constant")
+        return self.model(mel.float())[:, :n_frames]

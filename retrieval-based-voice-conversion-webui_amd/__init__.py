@@ -16,6 +16,6 @@ from .install import install, uninstall
 from .realtime import PitchCache, RealtimeVC, SincResample, f0_extractor_frame, sinc_resample_kernel
 
 __all__ = [
-    "RvcmiError", "build", "IVFFlatHIP", "read_index", "write_index", "train_index", "reduce_features", "GeneratorHIP", "NSFGeneratorHIP",
+    "RvcmiError", "build", "IVFFlatHIP", "read_index", "write_index", "train_index", "reduce_features", "kmeans", "GeneratorHIP", "NSFGeneratorHIP",
     "config_from_reference", "FrontHIP", "front_config_from_reference", "infer_hip", "retrieve_blend", "accelerate_synthesizer", "get_synthesizer", "load_synthesizer", "dist", "glue", "install", "uninstall", "RealtimeVC", "PitchCache", "f0_extractor_frame", "SincResample", "sinc_resample_kernel",
 ]

@@ -112,7 +112,15 @@ SYMBOLS = [
 
 
 class RvcmiError(RuntimeError):
-    pass
+    """``code``: the C ABI's return value (include/rvcmi.h: -1 invalid, -2 HIP, -3 IO / not an IVF-Flat L2 file, -4 no memory,
+    -5 missing weight); None for errors raised on the Python side."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+ERR_IO = -3
 
 
 _lib = None
@@ -177,7 +185,15 @@ def lib() -> C.CDLL:
 def check(rc: int) -> None:
     if rc != 0:
         msg = lib().rvcmi_last_error()
-        raise RvcmiError("rvcmi error %d: %s" % (rc, msg.decode(errors="replace") if msg else "?"))
+        raise RvcmiError("rvcmi error %d: %s" % (rc, msg.decode(errors="replace") if msg else "?"), code=int(rc))
+
+
+def device_index(dev) -> int:
+    """The ordinal of a CUDA (ROCm) device; ``cuda`` without an index means the current device."""
+    import torch
+
+    dev = torch.device(dev)
+    return dev.index if dev.index is not None else torch.cuda.current_device()
 
 
 def set_option(fn, handle, key: str, value) -> None:

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -111,8 +112,10 @@ struct DevBuf {
 // table; nothing on them calls getenv.  Keys are listed next to the handles that honour them.
 struct Options {
     std::map<std::string, double> v;
+    std::set<std::string> known;  // the keys this handle honours (everything ever passed to load_env)
     void load_env(std::initializer_list<const char*> keys) {
         for (const char* k : keys) {
+            known.insert(k);
             const std::string e = std::string("RVCMI_") + k;
             if (const char* sv = getenv(e.c_str())) v[k] = atof(sv);
         }
@@ -124,9 +127,12 @@ struct Options {
     }
     int geti(const char* k, int dflt) const { return (int)get(k, (double)dflt); }
     bool on(const char* k) const { return get(k, 0.0) != 0.0; }
-    void set(const char* k, double val) {
+    // false: not a key of this handle (a typo would otherwise pin nothing and a test would silently run the default path)
+    bool set(const char* k, double val) {
+        if (!known.count(k)) return false;
         if (val != val) v.erase(k);  // NaN: back to the default
         else v[k] = val;
+        return true;
     }
 };
 

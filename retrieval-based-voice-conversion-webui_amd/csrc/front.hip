@@ -614,7 +614,7 @@ int rvcmi_front_debug_forward(rvcmi_front* h, int B, int T, const float* phone, 
 int rvcmi_front_set_option(rvcmi_front* h, const char* key, double value) {
     return guarded([&] {
         if (!h || !key) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
-        h->opt.set(key, value);
+        if (!h->opt.set(key, value)) RVCMI_FAIL(RVCMI_ERR_INVALID, "unknown option '%s' for this handle", key);
     });
 }
 int rvcmi_front_profile_enable(rvcmi_front* h, int enable) {

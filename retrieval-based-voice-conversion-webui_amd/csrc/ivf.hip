@@ -1453,7 +1453,7 @@ int rvcmi_ivf_create_from_blob(void* dev_ptr, size_t bytes, int device, int take
 int rvcmi_ivf_set_option(rvcmi_ivf* h, const char* key, double value) {
     return guarded([&] {
         if (!h || !key) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
-        h->opt.set(key, value);
+        if (!h->opt.set(key, value)) RVCMI_FAIL(RVCMI_ERR_INVALID, "unknown option '%s' for this handle", key);
     });
 }
 int rvcmi_ivf_profile_enable(rvcmi_ivf* h, int enable) {

@@ -1233,7 +1233,7 @@ int rvcmi_nsf_debug_forward(rvcmi_nsf* h, int B, int T, const float* x, const fl
 int rvcmi_nsf_set_option(rvcmi_nsf* h, const char* key, double value) {
     return guarded([&] {
         if (!h || !key) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
-        h->opt.set(key, value);
+        if (!h->opt.set(key, value)) RVCMI_FAIL(RVCMI_ERR_INVALID, "unknown option '%s' for this handle", key);
     });
 }
 int rvcmi_nsf_profile_enable(rvcmi_nsf* h, int enable) {

@@ -12,8 +12,17 @@
 #include "common.hpp"
 #include "rb_stream.hpp"
 #include "rb_stream_kernels.hpp"
+// k_rb_stream2 / 2x / 3 (two blocks per CU, anti-phased groups, half-step slots): parity-green and measured SLOWER than
+// k_rb_stream in round 3.  Kept as dev variants: compiled only with RVCMI_DEFINES="RVCMI_DEV_VARIANTS", not part
+// of the product library or the default GPU suite; their schedule models stay tested (tools/model_rb_stream.py).
+#ifdef RVCMI_DEV_VARIANTS
 #include "rb_stream2_kernels.hpp"
 #include "rb_stream3_kernels.hpp"
+#else
+namespace rvcmi {  // geometry constants of the dev variants that the (shared) strip planner names
+constexpr int RS2_STRIDE = 256, RS2_HEAD = 52, RS2_SLACK = 3, RS3_XROWS = 52 + 192 + 3, RS3_HROWS = 10 + 192 + 1;
+}
+#endif
 
 namespace rvcmi {
 int num_cus();
@@ -77,6 +86,7 @@ void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStre
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(64 * NCO), smem, st, a);
 }
 
+#ifdef RVCMI_DEV_VARIANTS
 template <typename OpT>
 void launch_inst3(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
@@ -123,6 +133,8 @@ void launch_inst2(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStr
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(256), smem, st, a);
 }
 
+#endif  // RVCMI_DEV_VARIANTS
+
 // weight ring of the C = 128 kernel: NB groups of KG k-steps; a group is requested (NB-1)*KG k-steps ahead of its use.
 // (4 groups of 2 k-steps -- the same 32 registers, 6 instead of 4 k-steps of L2 latency covered -- was measured: 47 instead
 // of 37 cycles per MFMA, the group bookkeeping comes twice as often; 0.69 vs 0.62 ms.  RVCMI_DEFINES="RS_KG128=2 RS_NB128=4".)
@@ -134,9 +146,12 @@ void launch_inst2(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStr
 #endif
 template <typename OpT>
 void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st, int ver = 1) {
+#ifdef RVCMI_DEV_VARIANTS
     if (ver == 4 && C == 128 && nd == 3) return (a.flags & 2) ? launch_inst2x<OpT, 2>(a, nblocks, B, smem, st) : launch_inst2x<OpT, 1>(a, nblocks, B, smem, st);
     if (ver == 3 && C == 128 && nd == 3) return launch_inst3<OpT>(a, nblocks, B, smem, st);
     if (ver == 2 && C == 128 && nd == 3 && NJ == 3) return launch_inst2<OpT, 3, 3>(a, nblocks, B, smem, st);
+#endif
+    if (ver != 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: variant %d is a dev variant (build with RVCMI_DEFINES=RVCMI_DEV_VARIANTS)", ver);
     if (C == 256 && nd == 1 && NJ == 4) return launch_inst<OpT, 256, 2, 4, 4, 1>(a, nblocks, B, smem, st);
     if (C == 256 && nd == 1 && NJ == 3) return launch_inst<OpT, 256, 2, 3, 4, 1>(a, nblocks, B, smem, st);
     if (C == 128 && nd == 3 && NJ == 8) return launch_inst<OpT, 128, 1, 8, 4, 3>(a, nblocks, B, smem, st);
@@ -177,6 +192,7 @@ void rb_stream_prepare() {
     launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr);
     launch_t<_Float16>(128, 3, 6, a, -1, 1, 0, nullptr);
     a.flags = 0;
+#ifdef RVCMI_DEV_VARIANTS
     launch_t<__bf16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
     launch_t<_Float16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
     launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr, 3);
@@ -187,6 +203,7 @@ void rb_stream_prepare() {
         launch_t<_Float16>(128, 3, 3, a, -1, 1, 0, nullptr, 4);
     }
     a.flags = 0;
+#endif
 }
 
 bool rb_stream_supported(int operand, int C, int nd) {
@@ -201,6 +218,7 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
                       hipStream_t st, const Options& opt, bool dry_run) {
     Geo g;
     if (operand == RVCMI_OPERAND_F32 || njobs < 1 || njobs > 3) return false;
+#ifdef RVCMI_DEV_VARIANTS
     // RS_V2X: 1 = k_rb_stream2x (two anti-phased strips per 8-wave block) wherever it is instantiated, 0 = never
     if (opt.geti("RS_V2X", RS_V2X_DEFAULT) && geo_for(C, nd, g, opt, 4) && g.ver == 4 &&
         launch_geo(g, force ? 0 : 4, operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
@@ -213,6 +231,7 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
     if (v2 && geo_for(C, nd, g, opt, 2) && g.ver == 2 &&
         launch_geo(g, v2 == 1 ? (force ? 0 : 4) : opt.geti("RS_V2_STEPS", 150), operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
         return true;
+#endif
     if (!geo_for(C, nd, g, opt)) return false;
     // auto mode: only where the persistent walk measured faster than the tile kernels -- C = 128 (whole resblocks) from 4 steps
     // per block; C = 256 (pair level) only with long strips (large batches).

@@ -162,13 +162,13 @@ class FrontHIP(torch.nn.Module):
 
     def set_option(self, key: str, value=None) -> None:
         """Dev / test option of this handle (``rvcmi_front_set_option``: ``FR_NJ``, ``FR_NO_FFN_FUSION``, ``FR_FFN_SPLIT``); ``None`` = default."""
+        _lib.set_option(_lib.lib().rvcmi_front_set_option, self._handle, key, value)  # raises on a key this handle does not honour
         if not hasattr(self, "_options"):
             self._options = {}
         if value is None:
             self._options.pop(key, None)
         else:
             self._options[key] = value
-        _lib.set_option(_lib.lib().rvcmi_front_set_option, self._handle, key, value)
 
     def profile(self, enable: bool) -> None:
         _lib.check(_lib.lib().rvcmi_front_profile_enable(self._handle, 1 if enable else 0))

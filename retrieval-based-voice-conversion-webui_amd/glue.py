@@ -44,6 +44,9 @@ def _blend_expand_into(out: torch.Tensor, f: torch.Tensor, index, index_rate: fl
         if index is not None and index_rate != 0:
             if d != index.d:
                 raise ValueError("index mistatch")  # the reference's message (pipeline.py:128)
+            if _lib.device_index(index.device) != _lib.device_index(dev):
+                raise _lib.RvcmiError("the index lives on %s, the features on %s: read the index on the pipeline's device "
+                                      "(read_index(path, device=...))" % (index.device, dev))
             index.reserve(nq)
             _lib.check(L.rvcmi_ivf_search_blend_expand(index._h, nq, _ptr(f), float(index_rate), 8, 1 if realtime_guard else 0,
                                                        _ptr(pf), float(protect), p_len, _ptr(out), _stream(dev)))

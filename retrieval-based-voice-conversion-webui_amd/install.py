@@ -29,6 +29,7 @@ from typing import Optional
 
 import torch
 
+from . import _lib
 from . import ivf as _ivf
 from . import synthesizer as _syn
 
@@ -53,11 +54,13 @@ class _FaissShim(types.ModuleType):
             dev = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
         try:
             return _ivf.read_index(path, device=dev)
-        except Exception:  # an index kind the HIP reader does not serve (not IVF-Flat / L2, hashed direct map ...)
+        except _lib.RvcmiError as e:
+            # ONLY "this file is not something the HIP reader serves" (not IVF-Flat / L2, hashed direct map ...: RVCMI_ERR_IO)
+            # goes to real faiss; out-of-memory, HIP errors and everything else propagate -- they are not faiss' to paper over
             real = self.__dict__.get("_rvcmi_real")
-            if real is None:
+            if e.code != _lib.ERR_IO or real is None:
                 raise
-            return real.read_index(path, *a, **k)  # real faiss can: the rebound vc / infer hand such an index to the reference code
+            return real.read_index(path, *a, **k)  # the rebound vc / pipeline / infer hand such an index to the reference code
 
     def write_index(self, index, path):
         if isinstance(index, _ivf.IVFFlatHIP):
@@ -93,8 +96,7 @@ def _rebind_methods(rebound) -> None:
         for name, new in (("vc", _pl.vc_hip), ("pipeline", _pl.pipeline_hip)):
             old = cls.__dict__.get(name)
             if old is not None and old is not new:
-                if name == "vc":
-                    _pl.vc_hip._rvcmi_original = old
+                new._rvcmi_original = old
                 setattr(cls, name, new)
                 rebound.append((cls, name, old))
     mod = grab(_RTRVC_MODULE)

@@ -118,9 +118,16 @@ def _cut_points(self, audio, audio_pad_w):
     return opt_ts
 
 
-def _rmvpe_on_device(self, audio_pad, p_len, f0_up_key, filter_radius):
+RMVPE_THRED = 0.03  # rvc/f0/gen.py:113: Generator.calculate hard-codes compute_f0(..., filter_radius=0.03) for rmvpe
+
+
+def _rmvpe_on_device(self, audio_pad, p_len, f0_up_key):
     """RMVPE salience on PyTorch-ROCm (the reference's own mel extractor + network), decoded by ``rvcmi_glue_rmvpe_f0``
-    (rvc/f0/rmvpe.py:119-164, f0.py:31-78, gen.py:10-41) without visiting the host.  None when this f0_gen has no torch RMVPE."""
+    (rvc/f0/rmvpe.py:119-164, f0.py:31-78, gen.py:10-41) without visiting the host.  None when this f0_gen has no torch RMVPE.
+
+    The caller's ``filter_radius`` is NOT the voicing threshold: it is harvest's median radius (the UI slider 0..7, web.py:794)
+    that ``vc_single`` forwards to every estimator; ``Generator.calculate`` ignores it for rmvpe and passes the constant 0.03
+    (rvc/f0/gen.py:113), and so does this function."""
     from . import glue
 
     gen = self.f0_gen
@@ -138,7 +145,7 @@ def _rmvpe_on_device(self, audio_pad, p_len, f0_up_key, filter_radius):
     with torch.no_grad():
         mel = r.mel_extractor(wav.float().to(r.device).unsqueeze(0), center=True)
         hidden = r._mel2hidden(mel)
-    return glue.rmvpe_f0(hidden.squeeze(0).float(), p_len, int(f0_up_key), 0.03 if filter_radius is None else float(filter_radius))
+    return glue.rmvpe_f0(hidden.squeeze(0).float(), p_len, int(f0_up_key), RMVPE_THRED)
 
 
 def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr,
@@ -150,18 +157,24 @@ def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, fi
 
     import numpy as np
 
-    from . import glue, ivf
+    from . import _lib, glue, ivf
 
     ref = _ref_module(self)
     dev = torch.device(self.device)
     index = None
     if file_index != "" and os.path.exists(file_index) and index_rate != 0:
         try:
-            index = ref.faiss.read_index(file_index)  # install() made this the HIP reader; big_npy is never materialised
-            if not _is_hip_index(index):
-                index = ivf.read_index(file_index, device=dev)
-        except Exception:  # noqa: the reference prints and converts without an index (pipeline.py:216-218)
-            traceback.print_exc()
+            # on THIS pipeline's device (config.device), not the process's current GPU; big_npy is never materialised
+            index = ivf.read_index(file_index, device=dev)
+        except _lib.RvcmiError as e:
+            orig = getattr(pipeline_hip, "_rvcmi_original", None)
+            real = getattr(getattr(ref, "faiss", None), "_rvcmi_real", None)
+            if e.code == _lib.ERR_IO and orig is not None and real is not None:
+                # an index kind only real faiss reads (not IVF-Flat / L2 ...): the reference's own pipeline serves it, retrieval
+                # included (its vc calls come back here through vc_hip, which hands a non-HIP index to the reference's vc)
+                return orig(self, model, net_g, sid, audio, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius,
+                            tgt_sr, resample_sr, rms_mix_rate, version, protect, f0_file)
+            traceback.print_exc()  # the reference prints and converts without an index (pipeline.py:216-218)
             index = None
     audio = ref.signal.filtfilt(ref.bh, ref.ah, audio)
     opt_ts = _cut_points(self, audio, np.pad(audio, (self.window // 2, self.window // 2), mode="reflect"))
@@ -182,7 +195,7 @@ def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, fi
     if if_f0:
         got = None
         if if_f0 == 1 and f0_method == "rmvpe" and inp_f0 is None:
-            got = _rmvpe_on_device(self, audio_pad, p_len, f0_up_key, filter_radius)
+            got = _rmvpe_on_device(self, audio_pad, p_len, f0_up_key)
         if got is not None:
             pitch, pitchf = got[0][:, :p_len].long(), got[1][:, :p_len].float()
         else:

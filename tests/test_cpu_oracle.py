@@ -408,3 +408,23 @@ def test_streaming_resblock_schedule_models(k, dils, L, strips):
             else:
                 m.run_strip3(x, W1, B1, W2, B2, k, dils, S0, S1, out)
         assert np.isfinite(out).all() and np.abs(out - ref).max() < 2e-4, variant
+
+
+def test_webui_golden_f0_track_is_what_the_fake_rmvpe_and_the_glue_oracle_make():
+    """Fixture pipeline_v2_48k_webui was produced by the REAL ``Pipeline.pipeline`` -> ``Generator.calculate`` ->
+    ``RMVPE.compute_f0`` (real ``_mel2hidden`` / ``_decode`` / resize / interpolate) -> ``post_process``.  The stand-in the
+    GPU test uses on a box without the reference (``synth.FakeRMVPE``: restated pad-to-32 / crop) and the glue oracle must give
+    exactly that track from the same seed -- with the threshold 0.03 of rvc/f0/gen.py:113, not the UI's filter_radius 3."""
+    from oracle import glue_oracle, synth
+
+    d = load_golden("pipeline_v2_48k_webui")
+    fake = synth.FakeRMVPE(torch.device("cpu"), int(d["seed"]))
+    n_pad = int(d["n_audio"]) + 2 * 16000 * int(d["cfg_x_pad"])
+    sal = fake._mel2hidden(fake.mel_extractor(torch.zeros(1, n_pad), center=True)).squeeze(0).numpy()
+    assert sal.shape == (n_pad // 160 + 1, 360) and sal.dtype == np.float32
+    pitch, pitchf = glue_oracle.rmvpe_f0(sal, n_pad // 160, int(d["f0_up_key"]), 0.03)
+    assert np.array_equal(pitch, d["pitch"]) and np.array_equal(pitchf, d["pitchf"])
+    assert int(d["filter_radius"]) == 3 and float(d["rms_mix_rate"]) == 0.25 and float(d["index_rate"]) == 0.75
+    # with the UI's filter_radius as the threshold (the round-3 bug) every frame would be unvoiced
+    p3, f3 = glue_oracle.rmvpe_f0(sal, n_pad // 160, 0, 3.0)
+    assert (f3 == 0).all() and (p3 == 1).all() and (pitchf > 0).any()

@@ -219,6 +219,21 @@ class _CpuSpy:
         monkeypatch.setattr(torch.Tensor, "cpu", spy)
 
 
+def _bind_reference_noise(net_g, noise, gpu):
+    """Test-only shim: the reference draws its noise from the CPU generator inside net_g.infer; hand the same draws, call by
+    call, to the HIP infer.  ``net_g.infer.rewind()`` starts over at the first call's draws."""
+    real_infer = net_g.infer
+    pos = [0]
+
+    def infer_with_reference_noise(*a, **k):
+        nz, nd = noise[pos[0]]
+        pos[0] += 1
+        return real_infer(*a, noise_zp=nz.to(gpu), noise_dec=nd.to(gpu), **k)
+
+    infer_with_reference_noise.rewind = lambda: pos.__setitem__(0, 0)
+    net_g.infer = infer_with_reference_noise
+
+
 def _pipeline_fixture(gpu, rvc_tree, tmp_path):
     import types
 
@@ -241,15 +256,7 @@ def _pipeline_fixture(gpu, rvc_tree, tmp_path):
         h.update(nz.numpy().tobytes())
         h.update(nd.numpy().tobytes())
     assert h.hexdigest() == str(d["noise_sha256"]), "torch's CPU generator changed: the stored noise hash no longer matches"
-    # test-only shim: the reference draws its noise from the CPU generator inside net_g.infer; hand the same draws to the HIP infer
-    it = iter(noise)
-    real_infer = net_g.infer
-
-    def infer_with_reference_noise(*a, **k):
-        nz, nd = next(it)
-        return real_infer(*a, noise_zp=nz.to(gpu), noise_dec=nd.to(gpu), **k)
-
-    net_g.infer = infer_with_reference_noise
+    _bind_reference_noise(net_g, noise, gpu)
     config = types.SimpleNamespace(device=gpu, **{k[4:]: (bool(d[k]) if k == "cfg_is_half" else int(d[k])) for k in d if k.startswith("cfg_")})
     pipe = pl.Pipeline(cfg.sr, config)
     audio = synth.make_audio16k(int(d["n_audio"]), seed)
@@ -281,11 +288,13 @@ def test_unmodified_pipeline_entry_runs_device_resident_and_matches_the_referenc
         pipe.pipeline(hub, net_g, 3, audio.copy(), times, 0, (pitch, pitchf), "", 0.75, 2, 3, cfg.sr, 0, 1, "v2", 0.33)
 
 
-def test_unmodified_vc_caller_with_an_index_is_device_resident_and_matches_the_oracle(rvc_tree, gpu, tmp_path, monkeypatch):
-    """``Pipeline.vc`` (numpy in, numpy out, the reference's signature) on the first segment of the same fixture: without an
-    index it reproduces the reference's segment; with an ``IVFFlatHIP`` index it equals the numpy expressions of
-    pipeline.py:126-159 (oracle search + blend, x2, protect mix) fed through the same ``net_g.infer`` -- one host hop each."""
+def test_unmodified_vc_caller_without_and_with_an_index(rvc_tree, gpu, tmp_path, monkeypatch):
+    """``Pipeline.vc`` (numpy in, numpy out, the reference's signature) on the first segment of the same fixture.  Without an
+    index it reproduces the reference's segment.  WITH an ``IVFFlatHIP`` index it equals the numpy expressions of
+    pipeline.py:118-159 (oracle search + inverse-square blend, x2, protect mix) fed through the same ``net_g.infer`` with the
+    same noise -- one host hop each."""
     import rvc_amd
+    from oracle import glue_oracle
 
     d, cfg, pl, pipe, net_g, audio, pitch, pitchf = _pipeline_fixture(gpu, rvc_tree, tmp_path)
     from scipy import signal as sg
@@ -304,6 +313,101 @@ def test_unmodified_vc_caller_with_an_index_is_device_resident_and_matches_the_o
     assert len(spy.calls) == 1 and o.dtype == np.float32
     ref0 = d["out"][: o.shape[0] - 2 * pipe.t_pad_tgt] / float(d["scale"])
     assert rms(o[pipe.t_pad_tgt: o.shape[0] - pipe.t_pad_tgt], ref0) <= 1e-3
+    # ---- with an index: the retrieval branch of pipeline.py:113-138 ----
+    idx = synth.make_ivf(3000, 768, seed=11)
+    index = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=gpu)
+    big_npy = idx["xb"]  # what index.reconstruct_n(0, ntotal) returns (pipeline.py:215); the HIP vc only checks it is not None
+    net_g.infer.rewind()
+    del spy.calls[:]
+    oi = pipe.vc(hub, net_g, sid, seg, pt, pf, [0, 0, 0], index, big_npy, 0.75, "v2", float(d["protect"]))
+    assert len(spy.calls) == 1 and oi.shape == o.shape
+    assert rms(oi, o) > 1e-2, "the index changed nothing: the retrieval branch did not run"
+    # expected: the reference's numpy lines on the CPU oracle, then the SAME HIP net_g.infer with the same noise
+    feats = hub.extract_features(torch.zeros(1, seg.shape[0]), torch.zeros(1, seg.shape[0], dtype=torch.bool), 12)[0]
+    hub.calls -= 1
+    npy = feats[0].numpy()
+    blended = torch.from_numpy(ivf_oracle.search_blend(idx, npy, 0.75, 8)).unsqueeze(0)
+    exp_feats = glue_oracle.expand_protect(blended, feats, pf.cpu(), float(d["protect"]), seg.shape[0] // pipe.window)
+    assert exp_feats.shape[1] == T0
+    net_g.infer.rewind()
+    with torch.no_grad():
+        exp = net_g.infer(exp_feats.to(gpu), torch.tensor([T0], device=gpu), sid, pitch=pt[:, :T0], pitchf=pf[:, :T0])[0, 0]
+    e = rms(oi, exp.cpu())
+    assert e <= 2e-5, "Pipeline.vc with an index vs oracle retrieval + the same infer: RMS %.3e" % e
+    # index_rate 0 and a missing big_npy are the reference's "no retrieval" guards (pipeline.py:113-117)
+    for args in ((index, big_npy, 0), (index, None, 0.75)):
+        net_g.infer.rewind()
+        assert np.array_equal(pipe.vc(hub, net_g, sid, seg, pt, pf, [0, 0, 0], args[0], args[1], args[2], "v2", float(d["protect"])), o)
+
+
+def test_webui_defaults_through_the_rebound_pipeline(rvc_tree, gpu, tmp_path, monkeypatch):
+    """The WebUI's single-inference defaults (web.py:756-802) through the rebound ``Pipeline.pipeline``: f0_method "rmvpe" with
+    the UI's filter_radius 3 (NOT a voicing threshold: rvc/f0/gen.py:113 passes the constant 0.03), an index FILE with
+    index_rate 0.75, rms_mix_rate 0.25, protect 0.33, if_f0 1.  Expected waveform: fixture pipeline_v2_48k_webui, returned by the
+    REAL reference ``Pipeline.pipeline`` (its own read_index / reconstruct_n / search+blend / Generator.calculate /
+    RMVPE.compute_f0 / change_rms lines; stand-ins only for HuBERT, the RMVPE network, the faiss object = CPU oracle, and
+    ``librosa.feature.rms``).  Executes ``pipeline_hip``'s index branch, ``_rmvpe_on_device`` and ``glue.change_rms``."""
+    import hashlib
+    import types
+
+    import rvc_amd
+    from oracle import ivf_oracle as io
+
+    d = load_golden("pipeline_v2_48k_webui")
+    seed = int(d["seed"])
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    assert synth.weights_sha256(synth.make_dec_weights(cfg, seed)) == str(d["dec_sha256"])
+    rvc_amd.install(device=gpu, operand="fp16")
+    import infer.modules.vc.pipeline as pl
+    import rvc.synthesizer as rs
+
+    net_g, _ = rs.get_synthesizer(make_cpt(seed), gpu)
+    noise = synth.infer_noise([int(x) for x in d["seg_frames"]], cfg.upp)
+    h = hashlib.sha256()
+    for nz, nd in noise:
+        h.update(nz.numpy().tobytes())
+        h.update(nd.numpy().tobytes())
+    assert h.hexdigest() == str(d["noise_sha256"])
+    _bind_reference_noise(net_g, noise, gpu)
+    config = types.SimpleNamespace(device=gpu, **{k[4:]: (bool(d[k]) if k == "cfg_is_half" else int(d[k])) for k in d if k.startswith("cfg_")})
+    pipe = pl.Pipeline(cfg.sr, config)
+    fake = synth.FakeRMVPE(gpu, seed)
+    pipe.f0_gen = types.SimpleNamespace(rmvpe=fake, is_half=False, device=gpu)  # no ``calculate``: a host fallback would raise
+    audio = synth.make_audio16k(int(d["n_audio"]), seed)
+    path = str(tmp_path / "added.index")
+    io.write_index(synth.make_ivf(int(d["index_n"]), int(d["index_d"]), seed=int(d["index_seed"])), path)
+    f0_calls = []
+    real_rmvpe_f0 = rvc_amd.glue.rmvpe_f0
+
+    def rmvpe_f0_spy(sal, p_len, key, thred):
+        r = real_rmvpe_f0(sal, p_len, key, thred)
+        f0_calls.append((tuple(sal.shape), p_len, key, thred, r[0].clone(), r[1].clone()))
+        return r
+
+    monkeypatch.setattr(rvc_amd.glue, "rmvpe_f0", rmvpe_f0_spy)
+    rms_calls = []
+    real_change_rms = rvc_amd.glue.change_rms
+    monkeypatch.setattr(rvc_amd.glue, "change_rms", lambda *a: (rms_calls.append(a[4]), real_change_rms(*a))[1])
+    spy = _CpuSpy(monkeypatch)
+    hub = synth.FakeHubert(768, seed)
+    times = [0, 0, 0]
+    out = pipe.pipeline(hub, net_g, int(d["sid"]), audio.copy(), times, int(d["f0_up_key"]), "rmvpe", path, float(d["index_rate"]), 1,
+                        int(d["filter_radius"]), cfg.sr, 0, float(d["rms_mix_rate"]), "v2", float(d["protect"]))
+    assert hub.calls == 3 and fake.model.calls == 1 and rms_calls == [0.25]
+    assert isinstance(out, np.ndarray) and out.shape == d["out"].shape
+    assert spy.calls == [tuple(d["out"].shape)], "host hops between HuBERT and the returned audio: %s" % spy.calls
+    # the f0 track: threshold 0.03 whatever filter_radius says; bins identical and Hz to the last ulps vs the reference's track
+    (_, p_len, key, thred, pitch, pitchf), = f0_calls
+    assert thred == 0.03 and key == int(d["f0_up_key"]) and p_len == d["pitch"].shape[0]
+    assert int((pitchf > 0).sum()) == int(d["voiced_frames"]) > 0
+    assert np.array_equal(pitch[0].cpu().numpy(), d["pitch"])
+    assert np.allclose(pitchf[0].cpu().numpy(), d["pitchf"], rtol=2e-6, atol=0)
+    e = rms(out / 32768.0, d["out"] / 32768.0)
+    assert e <= 1e-3, "WebUI defaults through the drop-in: RMS %.3e (int16 range / 32768) vs the reference" % e
+    assert times[0] > 0 and times[1] > 0 and times[2] > 0
+    # an index on another kind of device object is refused loudly, not searched on the wrong GPU (ADVICE round 3)
+    with pytest.raises(rvc_amd.RvcmiError, match="no CPU fallback"):
+        rvc_amd.read_index(path, device="cpu")
 
 
 def test_front_at_benchmark_size_matches_the_reference_modules(gpu):

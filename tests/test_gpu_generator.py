@@ -29,10 +29,26 @@ def hip_gen(cfg, w, operand, gpu):
     return _gens[key]
 
 
+DEV_KEYS = ("RS_V2", "RS_V3", "RS_V2X")  # the opt-in streaming variants: only in a library built with RVCMI_DEV_VARIANTS
+
+
 def pin(gen, **opts):
     """Test options of ONE handle (rvcmi_nsf_set_option): e.g. RB_STREAM=1 forces the streaming ResBlock kernels, RS_SMALL picks
-    their tile height; None restores the launcher's own choice."""
+    their tile height; None restores the launcher's own choice.  A dev-variant key (k_rb_stream2 / 2x / 3) that is switched ON
+    skips the test when the loaded library was built without those kernels (the default build: an unknown option key is an
+    error, never silently ignored); switched off / restored it is simply not sent."""
+    import rvc_amd
+
     for k, v in opts.items():
+        if k in DEV_KEYS:
+            try:
+                gen.set_option(k, v)
+            except rvc_amd.RvcmiError as e:
+                if "unknown option" not in str(e):
+                    raise
+                if v:
+                    pytest.skip("dev variant %s is not compiled into this librvcmi.so (RVCMI_DEFINES=RVCMI_DEV_VARIANTS)" % k)
+            continue
         gen.set_option(k, v)
     return gen
 
