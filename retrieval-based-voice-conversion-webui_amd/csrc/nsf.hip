@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -525,8 +525,16 @@ static int rb_stream_mode(const rvcmi_nsf* h) {
     return v == 0 ? 0 : (v == 1 ? 1 : 2);
 }
 
+// Option Y_F16 (default 1): the whole-ResBlock kernels (k_rb_stream ND = 3, k_rb_full) write their output streams Ya[j] as fp16
+// and the next stage's k_ups / k_post read them as such (nsf_kernels.hpp pack4_h).  0 = fp32 streams (round 3).
+static bool y_f16(const rvcmi_nsf* h) {
+    return h->cfg.operand != RVCMI_OPERAND_F32 && h->opt.geti("Y_F16", 1) != 0 && !h->opt.on("RS_V2") && !h->opt.on("RS_V3") &&
+           !h->opt.on("RS_V2X");
+}
+
 // Whole resblocks of a stage on the streaming kernel (ND = 3).  Fills src[j] with the output streams on success.
 static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int L, int B, int nk, const float** src, hipStream_t st) {
+    const bool yh = y_f16(h);
     const int mode = rb_stream_mode(h);
     if (mode == 0 || op == RVCMI_OPERAND_F32 || nk > 3) return false;
     for (int j = 0; j < nk; ++j)
@@ -543,6 +551,7 @@ static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int 
         memset(&d, 0, sizeof(d));
         d.src = h->X0.as<float>();
         d.dst = h->Ya[j].as<float>();
+        d.y_half = yh ? 1 : 0;
         d.k = s.rb[j][0].first.ntaps[0];
         d.k_p = s.rb[j][0].first.ntaps_p;
         d.ct1 = s.rb[j][0].first.ct_stride;
@@ -558,7 +567,7 @@ static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int 
             flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
             bytes += 2.0 * d.k * C * C * 2;
         }
-        bytes += (double)B * L * C * 8;
+        bytes += (double)B * L * C * (yh ? 6 : 8);
     }
     char nm[48];
     snprintf(nm, sizeof(nm), "rb_stream_c%d", C);
@@ -785,6 +794,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
 
     // The running activation is ((y[0] + y[1]) + y[2]) / div  (nsf.py:177-186); stage 0 reads P alone.
     const float* y[3] = {P, nullptr, nullptr};
+    bool yhalf = false;  // y[] are fp16 streams (written by k_rb_stream ND = 3 / k_rb_full under option Y_F16)
     float div = 1.f;
     long L = Te;
     int Cprev = C0;
@@ -830,6 +840,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             ua.in_a = y[0];
             ua.in_b = y[1];
             ua.in_c = y[2];
+            ua.in_half = yhalf ? 1 : 0;
             ua.div = div;
             ua.Lin = (int)Lin;
             ua.cin = s.cin;
@@ -901,7 +912,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             ua.vpw = vpw;
             snprintf(nm, sizeof(nm), "ups_c%d", s.cin);
             const double flops = U.flops_per_pos * (double)Lin * B + 2.0 * s.nk * (double)L * C * B;
-            const double bytes = (double)B * Lin * Cprev * 4 * (y[1] ? (y[2] ? 3 : 2) : 1) + (double)B * L * C * 4;
+            const double bytes = (double)B * Lin * Cprev * (yhalf ? 2 : 4) * (y[1] ? (y[2] ? 3 : 2) : 1) + (double)B * L * C * 4;
             h->prof.launch(nm, flops, bytes, st, [&] {
                 if (op == RVCMI_OPERAND_BF16) launch_ups_t<__bf16>(ua, wv, nj, B, st);
                 else launch_ups_t<_Float16>(ua, wv, nj, B, st);
@@ -916,6 +927,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
         for (int j = 0; j < nk; ++j) maxnd = std::max(maxnd, s.rb[j].size());
         const float* src[RVCMI_MAX_RB];
         for (int j = 0; j < nk; ++j) src[j] = h->X0.as<float>();
+        bool stage_half = false;  // this stage's resblock outputs are fp16 streams
         if (op == RVCMI_OPERAND_F32) {
             snprintf(nm, sizeof(nm), "rb_c%d", C);
             for (int j = 0; j < nk; ++j)
@@ -995,6 +1007,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             }
         } else if (try_rb_stream_full(h, s, op, C, (int)L, B, nk, src, st)) {
             // streaming fused resblocks (rb_stream_kernels.hpp): persistent blocks walk strips of the time axis
+            stage_half = y_f16(h);
         } else if (C <= 64 && maxnd <= 3 && !h->opt.on("NO_RBFULL")) {
             // whole resblocks fused (x resident in registers): ONE launch for the stage   residuals.py:68-85
             snprintf(nm, sizeof(nm), "rb_full_c%d", C);
@@ -1003,6 +1016,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             ra.L = (int)L;
             ra.bstride = L * C;
             ra.dbg = dbg_flags(h);
+            stage_half = y_f16(h);
+            ra.yh = stage_half ? 1 : 0;
             const int R = rbf_rows(C);
             int order[RVCMI_MAX_RB];
             for (int j = 0; j < nk; ++j) order[j] = j;
@@ -1038,7 +1053,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 if (J.tvalid < R / 4) RVCMI_FAIL(RVCMI_ERR_INVALID, "resblock halo too large for the fused kernel");
                 J.ntiles = (int)((L + J.tvalid - 1) / J.tvalid);
                 max_tiles = std::max(max_tiles, J.ntiles);
-                bytes += (double)B * L * C * 8;
+                bytes += (double)B * L * C * (stage_half ? 6 : 8);
                 src[j] = J.dst;
             }
             const size_t nblk = (size_t)max_tiles * nk * B;
@@ -1173,11 +1188,16 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             HIP_CHECK(hipGetLastError());
         }
         for (int j = 0; j < 3; ++j) y[j] = j < nk ? src[j] : nullptr;
+        yhalf = stage_half;
         div = (float)nk;  // x = xs / num_kernels (nsf.py:186) is applied by the consumer
         Cprev = C;
         snprintf(nm, sizeof(nm), "stage%d", i);
         if (want(nm)) {  // the un-divided sum
             const size_t n = (size_t)B * L * C;
+            if (yhalf)
+                hipLaunchKernelGGL(k_sum3h, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const _Float16*)y[0], (const _Float16*)y[1],
+                                   (const _Float16*)y[2], h->X0.as<float>(), n);
+            else
             hipLaunchKernelGGL(k_sum3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y[0], y[1], y[2], h->X0.as<float>(), n);
             return copy_tap_cl(h, h->X0.as<float>(), B, (int)L, C, tr, st);
         }
@@ -1185,10 +1205,10 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
     if (tr) RVCMI_FAIL(RVCMI_ERR_INVALID, "unknown tap '%s'", tr->what);
     // ---- x = tanh(conv_post(leaky_relu(x)))                                    nsf.py:187-189
     const int nkk = c.n_resblock_kernels;
-    h->prof.launch("conv_post", 2.0 * 7 * Cprev * (double)L * B, (double)B * L * (Cprev * nkk + 1) * 4, st, [&] {
+    h->prof.launch("conv_post", 2.0 * 7 * Cprev * (double)L * B, (double)B * L * (Cprev * nkk * (yhalf ? 2 : 4) + 4), st, [&] {
         const size_t smem = (size_t)(7 * Cprev + (POST_TT + 6) * (Cprev + 4)) * 4;
         hipLaunchKernelGGL(k_post, dim3((unsigned)((L + POST_TT - 1) / POST_TT), B), dim3(256), smem, st, y[0], y[1], y[2],
-                           h->post_w.as<float>(), out, (int)L, Cprev, div);
+                           h->post_w.as<float>(), out, (int)L, Cprev, div, yhalf ? 1 : 0);
     });
     HIP_CHECK(hipGetLastError());
 }

@@ -246,6 +246,23 @@ static __global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x,
     x[((size_t)b * L + t) * C + co] += acc;
 }
 
+// Inter-stage streams Ya[j] as fp16 (option Y_F16): the three ResBlock outputs of a stage are only ever read by
+// the next stage's staging loop (k_ups / k_post), which sums them, divides by 3, applies lrelu and -- k_ups -- rounds the result
+// to an MFMA operand anyway.  Stored as fp16 (round to nearest even, saturating) they cost half the HBM bytes on the three
+// HBM-bound consumers and half the store instructions of the producers; the fp32 residual stream INSIDE a ResBlock is untouched.
+__device__ __forceinline__ _Float16 sat_h(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+__device__ __forceinline__ uint2 pack4_h(float a, float b, float c, float d) {
+    using h4 = __attribute__((ext_vector_type(4))) _Float16;
+    h4 o = {sat_h(a), sat_h(b), sat_h(c), sat_h(d)};
+    return __builtin_bit_cast(uint2, o);
+}
+__device__ __forceinline__ void unpack8_h(const uint4 raw, float (&f)[8]) {
+    using h8 = __attribute__((ext_vector_type(8))) _Float16;
+    const h8 h = __builtin_bit_cast(h8, raw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+}
+
 // out[b][t] = tanh(sum_{j,ci} lrelu(x[t-3+j][ci], 0.01) * Wp[j][ci]),  x = ((xa + xb) + xc) / div   (nsf.py:186-189)
 // HBM-bound: the last stage is read exactly once with coalesced float4 loads into an LDS tile whose
 // row stride C+4 floats keeps every row 16-byte aligned and the per-thread row walk (ds_read_b128, consecutive
@@ -255,7 +272,7 @@ constexpr int POST_TT = 256;  // = blockDim: one output sample per thread (a 128
 // grid = resident blocks 41 us, two tiles for every block 46 us -- the launch is not limited by its last half-empty round.
 static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ xa, const float* __restrict__ xb,
                                               const float* __restrict__ xc, const float* __restrict__ Wp /*[7][C]*/,
-                                              float* __restrict__ out, int L, int C, float div) {
+                                              float* __restrict__ out, int L, int C, float div, int in_half) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* w = (float*)smem_raw;          // [7][C]
     float* tile = w + 7 * C;              // [POST_TT + 6][C + 4]
@@ -271,6 +288,61 @@ static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ x
         // was ~8 serial HBM round trips per thread
         constexpr int SB = 5;
         const int total = (POST_TT + 6) * C4;
+        if (in_half) {  // fp16 streams (pack4_h): 8 channels per 16-byte load
+            const int C8 = C >> 3;
+            const int total8 = (POST_TT + 6) * C8;
+            const _Float16 *ha = (const _Float16*)xa, *hb = (const _Float16*)xb, *hc = (const _Float16*)xc;
+            for (int base = threadIdx.x; base < total8; base += SB * 256) {
+                uint4 va[SB], vb[SB], vc[SB];
+                size_t off[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int idx = min(base + u * 256, total8 - 1);
+                    const int r = idx / C8, c8 = idx - r * C8;
+                    const int tc = min(max(t0 - 3 + r, 0), L - 1);
+                    off[u] = boff + (size_t)tc * C + c8 * 8;
+                    va[u] = *(const uint4*)(ha + off[u]);
+                }
+                if (xb) {
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) vb[u] = *(const uint4*)(hb + off[u]);
+                }
+                if (xc) {
+#pragma unroll
+                    for (int u = 0; u < SB; ++u) vc[u] = *(const uint4*)(hc + off[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int idx = base + u * 256;
+                    if (idx < total8) {
+                        const int r = idx / C8, c8 = idx - r * C8;
+                        const int t = t0 - 3 + r;
+                        float v[8], w2[8];
+                        unpack8_h(va[u], v);
+                        if (xb) {
+                            unpack8_h(vb[u], w2);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += w2[e];
+                        }
+                        if (xc) {
+                            unpack8_h(vc[u], w2);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += w2[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float x = v[e];
+                            if (div == 3.f) x = div3_exact(x);
+                            else if (div != 1.f) x = x / div;
+                            x = lrelu(x, 0.01f);
+                            v[e] = (t < 0 || t >= L) ? 0.f : x;
+                        }
+                        *(float4*)(tile + r * S + c8 * 8) = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)(tile + r * S + c8 * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+            }
+        } else
         for (int base = threadIdx.x; base < total; base += SB * 256) {
             float4 va[SB], vb[SB], vc[SB];
             size_t off[SB];
@@ -328,6 +400,12 @@ static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ x
     }
 }
 
+// ... of fp16 streams (Y_F16)
+static __global__ void __launch_bounds__(256) k_sum3h(const _Float16* __restrict__ a, const _Float16* __restrict__ b,
+                                               const _Float16* __restrict__ c, float* __restrict__ y, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = ((float)a[i] + (b ? (float)b[i] : 0.f)) + (c ? (float)c[i] : 0.f);
+}
 // y = (a + b) + c   (debug tap of the stage sum only)
 static __global__ void __launch_bounds__(256) k_sum3(const float* __restrict__ a, const float* __restrict__ b,
                                               const float* __restrict__ c, float* __restrict__ y, size_t n) {
@@ -1201,6 +1279,7 @@ struct UpsArgs {
     const float* in_a;
     const float* in_b;
     const float* in_c;
+    int in_half;  // 1: in_a / in_b / in_c are fp16 streams (pack4_h) with the same [B][Lin][cin] element layout
     float div;
     int Lin, cin;
     long in_bstride;
@@ -1252,7 +1331,22 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
             const int gr = g0 + r;
             const bool ok = gr >= 0 && gr < a.Lin;
             const int grc = min(max(gr, 0), a.Lin - 1);  // clamped address: unconditional loads
-            {
+            if (a.in_half) {  // fp16 streams: one 16-byte load per input
+                const size_t o = boff + (size_t)grc * CIN + c8 * 8;
+                unpack8_h(*(const uint4*)((const _Float16*)a.in_a + o), f[u]);
+                if (a.in_b) {
+                    float t[8];
+                    unpack8_h(*(const uint4*)((const _Float16*)a.in_b + o), t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[u][e] += t[e];
+                }
+                if (a.in_c) {
+                    float t[8];
+                    unpack8_h(*(const uint4*)((const _Float16*)a.in_c + o), t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[u][e] += t[e];
+                }
+            } else {
                 const size_t o = boff + (size_t)grc * CIN + c8 * 8;
                 const float4 l0 = *(const float4*)(a.in_a + o), h0 = *(const float4*)(a.in_a + o + 4);
                 f[u][0] = l0.x; f[u][1] = l0.y; f[u][2] = l0.z; f[u][3] = l0.w; f[u][4] = h0.x; f[u][5] = h0.y; f[u][6] = h0.z; f[u][7] = h0.w;
@@ -1427,6 +1521,7 @@ struct RbFullArgs {
     int L;
     long bstride;
     int dbg;
+    int yh;  // 1: dst streams are fp16 (pack4_h), same element layout
     unsigned long long* ts;  // dbg & 32: per-wave s_memtime stamps [block][wave][16]
 };
 
@@ -1630,7 +1725,47 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
     stamp();  // 10: all pairs done
 
     // ---- store the valid centre of the tile ---------------------------------------------------------------
-    if constexpr (TIO) {
+    if (a.yh) {  // fp16 output stream: half the LDS round trip and half the store instructions
+        _Float16* dsth = (_Float16*)J.dst + (size_t)b * a.bstride;
+        if constexpr (TIO) {
+            constexpr int TSH = C * 2 + 16;
+            constexpr int C8 = C / 8;
+            __syncthreads();  // every wave is done with the operand tiles
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(uint2*)(smem + (size_t)(slab + jt * 32 + (lane & 31)) * TSH + (mi * 32 + 8 * g + half4) * 2) =
+                            pack4_h(xacc[mi][jt][4 * g + 0], xacc[mi][jt][4 * g + 1], xacc[mi][jt][4 * g + 2], xacc[mi][jt][4 * g + 3]);
+            __syncthreads();
+            if (!(a.dbg & 16)) {
+                const int nrow = min(R - 2 * J.HL, a.L - (tg0 + J.HL));
+                const int tot = nrow * C8;
+                for (int i = threadIdx.x; i < tot; i += NT) {
+                    const int r = i / C8, c8 = i - r * C8;
+                    const int row = J.HL + r;
+                    *(uint4*)(dsth + (size_t)(tg0 + row) * C + c8 * 8) = *(const uint4*)(smem + (size_t)row * TSH + c8 * 16);
+                }
+            }
+        } else if (!(a.dbg & 16)) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) {
+                    const int row = slab + jt * 32 + (lane & 31);
+                    const int tg = tg0 + row;
+                    if (row >= J.HL && row < R - J.HL && tg < a.L) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (mi * 32 + 8 * g < C)
+                                *(uint2*)(dsth + (size_t)tg * C + mi * 32 + 8 * g + half4) =
+                                    pack4_h(xacc[mi][jt][4 * g + 0], xacc[mi][jt][4 * g + 1], xacc[mi][jt][4 * g + 2], xacc[mi][jt][4 * g + 3]);
+                    }
+                }
+        }
+    } else if constexpr (TIO) {
         __syncthreads();  // every wave is done with the operand tiles
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)

@@ -16,6 +16,7 @@ struct RbStreamDesc {  // one resblock (ND = 3: all its pairs) or one pair level
     long ct1, ct2;
     int k, k_p;
     int dil[3];
+    int y_half;  // (jobs[0] decides for the launch) dst streams are fp16; only k_rb_stream itself honours it
 };
 
 // CUs of the current device (cached per device).

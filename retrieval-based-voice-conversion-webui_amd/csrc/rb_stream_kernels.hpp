@@ -51,7 +51,8 @@ struct RbStreamArgs {
     long bstride;
     int side_rows;  // rows of the side area (max over jobs)
     int skew;       // k_rb_stream2: the second block of a CU starts `skew * (k + 3)` x 1024 cycles late (0 = together)
-    int flags;      // k_rb_stream2: bit 0 = raise the wave priority inside the K loops
+    int flags;      // k_rb_stream2: bit 0 = raise the wave priority inside the K loops; bit 2 (4) = lean K loop instantiation;
+                    // bit 3 (8) = the dst streams are fp16 (pack4_h, nsf_kernels.hpp), same element layout
     unsigned long long* ts;  // dev only (RVCMI_RS_STAMPS=1): per-wave cycle sums per phase, [block][wave][16]
 };
 
@@ -198,8 +199,18 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
     char* T = M;
     f32x4 xr[KL == 2 ? NCH : 1];
     const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)((size_t)L * C * 4), 0x00020000);
+    const bool yh = (a.flags & 8) != 0;  // block-uniform: fp16 output stream
+    _Float16* dsth = (_Float16*)J.dst + (size_t)b * a.bstride;
     const __amdgpu_buffer_rsrc_t rs_dst =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (size_t)S0 * C), 0, (int)((size_t)max(S1 - S0, 0) * C * 4), 0x00020000);
+        yh ? __builtin_amdgcn_make_buffer_rsrc((void*)(dsth + (size_t)S0 * C), 0, (int)((size_t)max(S1 - S0, 0) * C * 2), 0x00020000)
+           : __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (size_t)S0 * C), 0, (int)((size_t)max(S1 - S0, 0) * C * 4), 0x00020000);
+    // fp16 rows: 2 C bytes = CHR / 2 chunks; thread (g16, c) = (tid / (CHR / 2), tid % (CHR / 2)) owns chunk c of NCH / 2 rows
+    constexpr int CHRH = CHR / 2, NG16 = NT / CHRH, NCHH = R / NG16, TSTRH = C * 2 + 16;
+    static_assert(KL != 2 || (R % NG16 == 0 && (NCHH - 1) * C * 2 < 4096), "fp16 IO chunk geometry");
+    const int g16 = (int)threadIdx.x / CHRH, cchh = (int)threadIdx.x % CHRH;
+    const unsigned ioh_voff = (unsigned)(g16 * NCHH * C * 2 + cchh * 16);
+    const unsigned ioh_lds = lds_address(T) + (unsigned)(g16 * NCHH * TSTRH + cchh * 16);
+    const unsigned dlh_lds = lds_address(T) + (unsigned)(lrow * TSTRH + (ct0 * 32 + half4) * 2);
     const int g8 = (int)threadIdx.x / CHR, cch = (int)threadIdx.x % CHR;
     const unsigned io_voff = (unsigned)(g8 * NCH * C * 4 + cch * 16);           // this thread's chunk of its first row, in bytes
     const unsigned io_lds = lds_address(T) + (unsigned)(g8 * NCH * TSTR + cch * 16);
@@ -427,6 +438,34 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
         if constexpr (KL == 2) {
             const int wout = r0 - 32 * ND + step * R;
             issue_loads(r0 + (step + 1) * R);  // the next step's rows: in flight under the store phase (zeros past the end)
+            if (yh) {
+                using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
+                using lds_u2 = __attribute__((address_space(3))) u32x2_t;
+                using lds_u4 = __attribute__((address_space(3))) u32x4_t;
+                {
+                    unsigned b0 = dlh_lds;
+                    asm volatile("" : "+v"(b0));
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                *(lds_u2*)(size_t)(b0 + (unsigned)(jt * 32 * TSTRH + (mi * 32 + 8 * g) * 2)) = __builtin_bit_cast(
+                                    u32x2_t, pack4_h(xin[mi][jt][4 * g + 0], xin[mi][jt][4 * g + 1], xin[mi][jt][4 * g + 2], xin[mi][jt][4 * g + 3]));
+                }
+                bar();
+                {
+                    unsigned bb = ioh_lds;
+                    unsigned v0 = ioh_voff + (unsigned)((wout - S0) * (C * 2));  // (wraps for rows in front of the strip: dropped)
+                    asm volatile("" : "+v"(bb), "+v"(v0));
+#pragma unroll
+                    for (int it = 0; it < NCHH; ++it) {
+                        const u32x4_t v = *(const lds_u4*)(size_t)(bb + (unsigned)(it * TSTRH));
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_dst, v0 + (unsigned)(it * (C * 2)), 0, 0);
+                    }
+                }
+            } else {
             {
                 unsigned b0 = dl_lds, b1 = dl_lds + (unsigned)(3 * 32 * TSTR);
                 asm volatile("" : "+v"(b0), "+v"(b1));
@@ -456,6 +495,7 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs_dst, v0[it / 8] + (unsigned)((it % 8) * (C * 4)), 0, 0);
                 }
             }
+            }
         } else
         {
             const int wout = r0 - 32 * ND + step * R;
@@ -468,7 +508,8 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const f32x4 v = {xin[mi][jt][4 * g + 0], xin[mi][jt][4 * g + 1], xin[mi][jt][4 * g + 2], xin[mi][jt][4 * g + 3]};
-                            *(f32x4*)(dst + (size_t)tg * C + (ct0 + mi) * 32 + 8 * g + half4) = v;
+                            if (yh) *(uint2*)(dsth + (size_t)tg * C + (ct0 + mi) * 32 + 8 * g + half4) = pack4_h(v[0], v[1], v[2], v[3]);
+                            else *(f32x4*)(dst + (size_t)tg * C + (ct0 + mi) * 32 + 8 * g + half4) = v;
                         }
                 }
             }

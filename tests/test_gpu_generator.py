@@ -277,10 +277,26 @@ def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
     # every streaming ResBlock kernel of the C = 128 stage on the whole clip: k_rb_stream, k_rb_stream3 (half-step slots),
     # k_rb_stream2x (two anti-phased strips per block, both K loops)
     for small in ("1", "kl2", "v3", "v2x", "v2x2"):
-        o = pin(gen, **_rs_opts(small))(zd, fd, gd, noise=nd).cpu()
+        try:
+            pin(gen, **_rs_opts(small))
+        except pytest.skip.Exception:  # a dev variant that is not compiled into this library
+            continue
+        o = gen(zd, fd, gd, noise=nd).cpu()
         assert torch.isfinite(o).all() and rms(o, d["out"]) <= 1e-3, "%s: RMS %.3e vs the reference waveform" % (small, rms(o, d["out"]))
         assert rms(o, out) <= 5e-4
     pin(gen, **{k: None for k in _rs_opts("0")})
+    # inter-stage streams: fp16 (default, option Y_F16) against fp32 (round 3) -- the fp16 streams must stay inside the 5e-4 gate
+    # on this clip and within 15 % of what the fp32 streams give (the operand rounding of 72 convolutions dominates both)
+    o32s = pin(gen, Y_F16=0)(zd, fd, gd, noise=nd).cpu()
+    pin(gen, Y_F16=None)
+    e32s = rms(o32s, d["out"])
+    assert e32s <= 1e-3 and e_ref <= 5e-4 and e_ref <= 1.15 * e32s, "fp16 inter-stage streams %.3e vs fp32 streams %.3e" % (e_ref, e32s)
+    assert 0 < rms(out, o32s) <= 3e-4
+    for k in ("stage1", "stage2", "stage3"):  # the un-divided stage sums read back from the fp16 streams
+        got = gen.debug_tap(k, zd, fd, gd, noise=nd)
+        exp = taps[k] * cfg.num_kernels
+        rel = rms(got, exp) / float(exp.pow(2).mean().sqrt())
+        assert rel <= 2e-3, "%s (fp16 streams): relative RMS %.2e" % (k, rel)
     # exact-fp32 path on the same clip
     gen32 = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp32", max_B=1, max_T=1198)
     assert rms(gen32(zd, fd, gd, noise=nd).cpu(), d["out"]) <= 2e-5
