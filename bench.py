@@ -611,11 +611,21 @@ def main():
             roof["ubench_ceiling"] = {"kloop_tflops": 1505.0, "mfma_only_tflops": 1804.0, "frac_of_kloop_ceiling": ach / 1505e12,
                                       "kind": "constants from a committed micro-benchmark run, NOT measured in this run",
                                       "source": "profiles/r03_ubench_kloop2_issue_model.txt (measured on an MI355X of this pool, round 3)"}
-        scan = [s for s in ivs if s["name"] == "ivf_scan"]
+        def scan_total(stats):
+            """The scan as one unit: the query-major kernel (`ivf_scan`), or the three launches of the list-major path
+            (`ivf_plan` + `ivf_scan` = score tiles + `ivf_select`; round 4) -- time summed, bytes = the SURVEY 8d model of `ivf_scan`."""
+            parts = [s_ for s_ in stats if s_["name"] in ("ivf_plan", "ivf_scan", "ivf_select")]
+            main = [s_ for s_ in parts if s_["name"] == "ivf_scan"]
+            if not main:
+                return []
+            return [dict(main[0], ms=sum(s_["ms"] for s_ in parts), parts={s_["name"]: round(1e3 * s_["ms"] / max(1, s_["launches"]), 2) for s_ in parts})]
+
+        scan = scan_total(ivs)
         if scan and scan[0]["ms"] > 0:
             roof["ivf_scan_hbm"] = {"achieved": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                     "frac": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 8e12,
-                                    "bytes_model": "ntotal / nlist rows per query (lists of equal size)"}
+                                    "bytes_model": "ntotal / nlist rows per query (lists of equal size)",
+                                    "launches_us": scan[0]["parts"]}
             if idx is not None:
                 # what the scan really walks on THIS index: i.i.d. Gaussian rows give very unequal lists and the (equally
                 # random) queries land in the big ones.  Host arithmetic on the inputs, outside every timed region.
@@ -630,7 +640,8 @@ def main():
                     "rows_per_query_model": a.index_n / max(1, len(sizes)), "rows_per_query_scanned": rows / max(1, len(asg)),
                     "largest_list": int(sizes.max()), "scanned_bytes": sb, "scanned_GBps": sb / (ms1 * 1e-3) / 1e9,
                     "unique_list_bytes": float(sizes[np.unique(asg)].sum()) * (4.0 * a.index_d + 8),
-                    "note": "scanned_GBps counts every row a query block reads (mostly L2 hits: many queries share a list)"})
+                    "note": "scanned_bytes = rows of the probed list x queries (what a query-major scan walks, mostly through L2; "
+                            "the list-major path reads a list's rows once per 32-query tile); unique_list_bytes = the rows probed at all"})
             if idx is not None and B == 1 and a.index_d == 768:
                 # side leg, not part of `value`: the same search on an index whose rows have cluster structure (lists of
                 # comparable size, the bytes model above holds), queries drawn from the same mixture
@@ -655,12 +666,12 @@ def main():
                     szc = np.diff(np.asarray(idc["list_offsets"]))
                     asc = synth.assign_nearest(xr[a.index_n:], np.asarray(idc["centroids"]))
                     rows_c = int(szc[asc].sum())
-                    sc = st_c["ivf_scan"]
+                    sc = scan_total(list(st_c.values()))[0]
                     msc = sc["ms"] / sc["launches"]
                     sbc = rows_c * (4.0 * a.index_d + 8)
                     roof["ivf_clustered_index"] = {
                         "what": "same search + blend on a 10000 x 768 index of clustered rows (synth.make_clustered_rows), 599 queries of the same mixture",
-                        "scan_us": 1e3 * msc, "coarse_us": 1e3 * st_c["ivf_coarse"]["ms"] / st_c["ivf_coarse"]["launches"],
+                        "scan_us": 1e3 * msc, "scan_launches_us": sc["parts"], "coarse_us": 1e3 * st_c["ivf_coarse"]["ms"] / st_c["ivf_coarse"]["launches"],
                         "rows_per_query_scanned": rows_c / len(asc), "largest_list": int(szc.max()), "scanned_bytes": sbc,
                         "scanned_GBps": sbc / (msc * 1e-3) / 1e9, "frac_of_8TBps": sbc / (msc * 1e-3) / 8e12}
                 except Exception as e:  # noqa

@@ -8,6 +8,7 @@
 // irrelevant next to the row traffic, and it makes the ranking independent of summation order, which
 // is what allows bit-exact indices against the CPU oracle (ties -> lowest id).
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -190,6 +191,42 @@ __global__ void __launch_bounds__(64 * NWC) k_coarse_gemm(const float* __restric
     }
 }
 
+// One wave's share of a 32 x 32 score tile whose K dimension is split over the block's 4 waves (wave w: chunks w, w + 4, ...
+// of CG_K floats).  `src[s]` = the row this lane stages in slot s (rows 0..31 of the A side, 32..63 of the B side; lane + 64 s
+// = 8 row + float4 column).  DEPTH chunks are requested ahead: a wave walks d / 128 chunks (6 at d = 768), each a dependent
+// memory round trip when fetched one ahead (13 us for a 152-tile launch); with DEPTH = 4 the walk is two round trips.
+// NCH = chunks per wave (compile time: the ring is indexed statically); acc += A * B^T over this wave's chunks.
+template <int NCH, int DEPTH>
+__device__ __forceinline__ void ks_wave_tile(f32x16& acc, const float* const (&src)[8], float* st, int wave, int lane) {
+    constexpr int D = DEPTH < NCH ? DEPTH : NCH;
+    float4 pre[D][8];
+    const int kstep = 4 * CG_K;
+    const int kw = wave * CG_K;
+    const int coff = (lane & 7) * 4;
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) pre[c][s2] = *(const float4*)(src[s2] + kw + c * kstep + coff);
+    const float* qa = st + (lane & 31) * CG_S + (lane >> 5);
+    const float* cb = st + (32 + (lane & 31)) * CG_S + (lane >> 5);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int idx = lane + s2 * 64;
+            float* dst = st + (idx >> 3) * CG_S + (idx & 7) * 4;
+            const float4 v = pre[c % D][s2];
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        if (c + D < NCH) {
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) pre[c % D][s2] = *(const float4*)(src[s2] + kw + (c + D) * kstep + coff);
+        }
+#pragma unroll
+        for (int ks = 0; ks < CG_K / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * ks], cb[2 * ks], acc, 0, 0, 0);
+    }
+}
+
 // Small problems (nlist 256 x 599 queries = 152 tiles): one 32 x 32 tile per block, the K dimension split over 4 waves
 // (wave w takes chunks w, w+4, ...), each with its own staging area and a register prefetch of its next chunk; the four
 // partial accumulators are added in a fixed order through LDS.  The single-wave version walked 24 chunks serially and was
@@ -219,6 +256,16 @@ __global__ void __launch_bounds__(256) k_coarse_gemm_ks(const float* __restrict_
         }
     };
     const int kstep = 4 * CG_K;
+    if (d == 768 || d == 256) {  // the shipped feature widths: deep prefetch ring (ks_wave_tile)
+        const float* src[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int row = (lane + s2 * 64) >> 3;
+            src[s2] = row < 32 ? q + min(q0 + row, nq - 1) * d : cent + min(c0 + (row - 32), nlist - 1) * d;
+        }
+        if (d == 768) ks_wave_tile<6, 4>(acc, src, st, wave, lane);
+        else ks_wave_tile<2, 2>(acc, src, st, wave, lane);
+    } else {
     if (wave * CG_K < d) fetch(wave * CG_K);
     for (int k0 = wave * CG_K; k0 < d; k0 += kstep) {
 #pragma unroll
@@ -233,6 +280,7 @@ __global__ void __launch_bounds__(256) k_coarse_gemm_ks(const float* __restrict_
         const float* cb = st + (32 + (lane & 31)) * CG_S + (lane >> 5);
 #pragma unroll
         for (int ks = 0; ks < CG_K / 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * ks], cb[2 * ks], acc, 0, 0, 0);
+    }
     }
     if (wave > 0) {
 #pragma unroll
@@ -264,10 +312,21 @@ __global__ void __launch_bounds__(256) k_coarse_pick(const float* __restrict__ q
     if (qi >= nq) return;
     const float* row = S + qi * nlist;
     const float* qp = q + qi * d;
-    double qn2 = 0.0;
-    for (int e = lane; e < d; e += 64) qn2 = fma((double)qp[e], (double)qp[e], qn2);
+    // the query slice of this lane (float4 chunks lane, lane + 64, ...; up to 4 of them = d <= 1024 stay in registers) and the
+    // score row are requested together: one memory round trip
+    const int d4 = d >> 2;
+    float4 xq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xq[j] = lane + 64 * j < d4 ? ((const float4*)qp)[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
     float m = INFINITY;
     for (int64_t c = lane; c < nlist; c += 64) m = fminf(m, row[c]);
+    double qn2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qn2 = fma((double)xq[j].x, (double)xq[j].x, qn2); qn2 = fma((double)xq[j].y, (double)xq[j].y, qn2);
+        qn2 = fma((double)xq[j].z, (double)xq[j].z, qn2); qn2 = fma((double)xq[j].w, (double)xq[j].w, qn2);
+    }
+    for (int e = 256 * 4 + lane; e < d; e += 64) qn2 = fma((double)qp[e], (double)qp[e], qn2);  // (d > 1024 only)
     for (int off = 32; off >= 1; off >>= 1) {
         qn2 += __shfl_xor(qn2, off, 64);
         m = fminf(m, __shfl_xor(m, off, 64));
@@ -284,16 +343,44 @@ __global__ void __launch_bounds__(256) k_coarse_pick(const float* __restrict__ q
         const bool cand = c < nlist && row[c] <= lim;
         unsigned long long mask = __ballot(cand);
         while (mask) {
-            const int b = __builtin_ctzll(mask);
+            // two candidates per trip (usually there are one or two in all): both centroids' loads are in flight together
+            const int b0 = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const float* cp = cent + (c0 + b) * d;
-            double acc = 0.0;
-            for (int e = lane; e < d; e += 64) {
-                const double t = (double)qp[e] - (double)cp[e];
-                acc = fma(t, t, acc);
+            const bool two = mask != 0;
+            const int b1 = two ? __builtin_ctzll(mask) : b0;
+            if (two) mask &= mask - 1;
+            const float* cp0 = cent + (c0 + b0) * d;
+            const float* cp1 = cent + (c0 + b1) * d;
+            float4 y0[4], y1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e4 = min(lane + 64 * j, d4 - 1);
+                y0[j] = ((const float4*)cp0)[e4];
+                y1[j] = ((const float4*)cp1)[e4];
             }
-            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-            if (acc < best || (acc == best && c0 + b < besti)) { best = acc; besti = c0 + b; }
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (lane + 64 * j < d4) {
+                    const double x0 = (double)xq[j].x, x1 = (double)xq[j].y, x2 = (double)xq[j].z, x3 = (double)xq[j].w;
+                    double t;
+                    t = x0 - (double)y0[j].x; a0 = fma(t, t, a0); t = x1 - (double)y0[j].y; a0 = fma(t, t, a0);
+                    t = x2 - (double)y0[j].z; a0 = fma(t, t, a0); t = x3 - (double)y0[j].w; a0 = fma(t, t, a0);
+                    t = x0 - (double)y1[j].x; a1 = fma(t, t, a1); t = x1 - (double)y1[j].y; a1 = fma(t, t, a1);
+                    t = x2 - (double)y1[j].z; a1 = fma(t, t, a1); t = x3 - (double)y1[j].w; a1 = fma(t, t, a1);
+                }
+            }
+            for (int e = 256 * 4 + lane; e < d; e += 64) {  // (d > 1024 only)
+                const double t0 = (double)qp[e] - (double)cp0[e], t1 = (double)qp[e] - (double)cp1[e];
+                a0 = fma(t0, t0, a0);
+                a1 = fma(t1, t1, a1);
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                a0 += __shfl_xor(a0, off, 64);
+                a1 += __shfl_xor(a1, off, 64);
+            }
+            if (a0 < best || (a0 == best && c0 + b0 < besti)) { best = a0; besti = c0 + b0; }
+            if (two && (a1 < best || (a1 == best && c0 + b1 < besti))) { best = a1; besti = c0 + b1; }
         }
     }
     if (lane == 0) assign[qi] = besti;
@@ -738,6 +825,10 @@ __global__ void __launch_bounds__(256) k_blend(float* __restrict__ feats, const 
     }
 }
 
+}  // namespace rvcmi
+#include "ivf_lm_kernels.hpp"
+namespace rvcmi {
+
 // ---- index build (web.py:544-563: index.train = k-means for the nlist centroids, index.add = nearest-centroid lists) ----
 // Lloyd update: centroid l <- mean of its members, members in ascending id order, fp64 accumulation (deterministic).
 // One block per list, threads over the dimension.
@@ -791,11 +882,17 @@ struct rvcmi_ivf {
     int cap_nprobe = 0;
     DevBuf assign, P, Dtmp, Itmp, flag, cdist, cscore, qcnt, qperm;
     int64_t cap_chunk = 0;  // queries per coarse-score chunk (bounds the nq x nlist fp32 scratch)
+    // list-major scan (ivf_lm_kernels.hpp): row norms + statistics (once per handle), score scratch and work items (per capacity)
+    DevBuf lm_rn, lm_S, lm_items, lm_n, lm_qinfo;
+    bool lm_ready = false;
+    double lm_vmax = 0.0;      // max |v| over the stored rows (error bound of the fp32 prefilter)
+    int64_t lm_maxlen = 0;     // longest list
+    int64_t lm_cap_items = 0;  // capacity of lm_items
     Profiler prof;
     // dev / test options (common.hpp Options): IVF_COARSE_F64 (brute-force fp64 coarse quantizer), IVF_GENERIC (any-d scan kernel),
     // IVF_STAMPS (prints; syncs), IVF_DBG, IVF_SORT (1 = scan the queries in list-sorted, XCD-contiguous order).  Read from RVCMI_<KEY> once at handle creation; later only rvcmi_ivf_set_option.
     rvcmi::Options opt;
-    rvcmi_ivf() { opt.load_env({"IVF_COARSE_F64", "IVF_GENERIC", "IVF_STAMPS", "IVF_DBG", "IVF_SORT"}); }
+    rvcmi_ivf() { opt.load_env({"IVF_COARSE_F64", "IVF_GENERIC", "IVF_STAMPS", "IVF_DBG", "IVF_SORT", "IVF_LM"}); }
     const float* centroids() const { return (const float*)(blob + hdr.off_centroids); }
     const float4* centroids_t() const { return (const float4*)(blob + hdr.off_centroids_t); }
     const float* cnorm() const { return (const float*)(blob + hdr.off_cnorm); }
@@ -1040,6 +1137,67 @@ static void write_faiss(const rvcmi_ivf* h, const char* path) {
     }
 }
 
+static int num_cus_ivf() {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    static std::atomic<int> cached[64];
+    int v = cached[dev & 63].load();
+    if (!v) {
+        hipDeviceProp_t p;
+        HIP_CHECK(hipGetDeviceProperties(&p, dev));
+        v = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+        cached[dev & 63].store(v);
+    }
+    return v;
+}
+
+// List-major scan: usable for nprobe 1, d a multiple of the MFMA K chunk, list counts / lengths the planner and the selector
+// hold in LDS, and a score scratch (nq x longest list, fp32) of at most 1 GiB; small query counts (a realtime chunk's 16) keep
+// the one-launch query-major kernel.  Option IVF_LM: 0 = never (round-3 path), default 1.
+static bool lm_usable(const rvcmi_ivf* h, int64_t nq) {
+    const BlobHeader& b = h->hdr;
+    if (std::min<int64_t>(b.nprobe, b.nlist) != 1 || (b.d % CG_K) != 0 || b.nlist > LM_MAXL || b.ntotal < 1) return false;
+    if (!h->lm_ready || h->lm_maxlen < 1 || h->lm_maxlen > LM_MAXPITCH) return false;
+    if (nq < 64 || nq >= (1ll << 30)) return false;
+    const int64_t pitch = (int64_t)align_up((uint64_t)h->lm_maxlen, 32);
+    return (double)nq * (double)pitch * 4.0 <= 1073741824.0;
+}
+static void lm_reserve(rvcmi_ivf* h, int64_t nq) {
+    const BlobHeader& b = h->hdr;
+    if (std::min<int64_t>(b.nprobe, b.nlist) != 1 || (b.d % CG_K) != 0 || b.nlist > LM_MAXL || b.ntotal < 1) return;
+    if (!h->lm_ready) {  // once per handle (never inside a stream capture: reserve() runs before the first search)
+        h->lm_rn.alloc((size_t)b.ntotal * 4);
+        h->lm_n.alloc(256);
+        HIP_CHECK(hipMemset(h->lm_n.p, 0, 256));
+        hipLaunchKernelGGL(k_lm_row_norms, dim3((unsigned)((b.ntotal + 3) / 4)), dim3(256), 0, nullptr, h->vecs(), b.ntotal, b.d, h->lm_rn.as<float>());
+        const int64_t m = std::max<int64_t>(b.ntotal, b.nlist);
+        hipLaunchKernelGGL(k_lm_stats, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nullptr, h->lm_rn.as<float>(), b.ntotal, h->list_off(), b.nlist,
+                           h->lm_n.as<unsigned>() + 16);
+        HIP_CHECK(hipGetLastError());
+        unsigned st2[2];
+        HIP_CHECK(hipMemcpy(st2, h->lm_n.as<unsigned>() + 16, 8, hipMemcpyDeviceToHost));
+        float vm2;
+        memcpy(&vm2, &st2[0], 4);
+        h->lm_vmax = std::sqrt((double)vm2) * (1.0 + 1e-6);  // (the norms are fp32-rounded: a hair of head room)
+        h->lm_maxlen = (int64_t)st2[1];
+        static std::atomic<unsigned long long> attr_done{0};
+        const unsigned long long bit = 1ull << (h->device & 63);
+        if (!(attr_done.load() & bit)) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lm_plan), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (LM_MAXL + 1) * 4));
+            attr_done.fetch_or(bit);
+        }
+        h->lm_ready = true;
+    }
+    if (!lm_usable(h, std::max<int64_t>(nq, 64))) return;
+    const int64_t pitch = (int64_t)align_up((uint64_t)h->lm_maxlen, 32);
+    if ((double)nq * (double)pitch * 4.0 > 1073741824.0) return;
+    h->lm_S.alloc((size_t)std::max<int64_t>(nq, 1) * pitch * 4);
+    h->lm_qinfo.alloc((size_t)std::max<int64_t>(nq, 1) * sizeof(LmQuery));
+    // worst case of the planner: every probed list adds at most one partial query tile on top of nq / 32 full ones
+    h->lm_cap_items = (nq / 32 + std::min<int64_t>(nq, b.nlist) + 1) * (pitch / 32);
+    h->lm_items.alloc((size_t)h->lm_cap_items * sizeof(LmItem));
+}
+
 static void reserve(rvcmi_ivf* h, int64_t nq) {
     const int np = (int)std::min<int64_t>(h->hdr.nprobe, h->hdr.nlist);
     const bool have_scores = np > 1 || (h->cscore.p && h->cap_chunk > 0);
@@ -1061,6 +1219,7 @@ static void reserve(rvcmi_ivf* h, int64_t nq) {
     }
     h->cap_nq = nq;
     h->cap_nprobe = np;
+    lm_reserve(h, nq);
 }
 
 struct BlendFuse {
@@ -1116,6 +1275,31 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
             hipLaunchKernelGGL(k_coarse_select, dim3((unsigned)nq), dim3(64), 0, st, h->cdist.as<double>(), b.nlist, np,
                                h->assign.as<int64_t>());
         });
+    }
+    // list-major scan: plan (sort + work items) -> fp32 MFMA score tiles -> per-query exact verification (+ fused blend)
+    if (h->opt.geti("IVF_LM", 1) && !h->opt.on("IVF_GENERIC") && lm_usable(h, nq) && h->lm_S.p && nq <= h->cap_nq) {
+        const int pitch = (int)align_up((uint64_t)h->lm_maxlen, 32);
+        const double rows = (double)b.ntotal / (double)b.nlist;
+        h->prof.launch("ivf_plan", 0.0, (double)nq * 12 + (double)b.nlist * 8, st, [&] {
+            hipLaunchKernelGGL(k_lm_plan, dim3(1), dim3(1024), (size_t)2 * (b.nlist + 1) * 4, st, h->assign.as<int64_t>(), (int)nq, (int)b.nlist,
+                               h->list_off(), h->lm_qinfo.as<LmQuery>(), h->lm_items.as<LmItem>(), h->lm_n.as<int>(), (int)std::min<int64_t>(h->lm_cap_items, 0x7fffffff));
+        });
+        // (flops / bytes: the SURVEY 8d model -- N / nlist rows per query -- as for the query-major kernel, so that the roofline
+        //  lines of the two paths compare)
+        h->prof.launch("ivf_scan", 2.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
+            const int grid = (int)std::min<int64_t>(h->lm_cap_items, (int64_t)num_cus_ivf() * 3);
+            hipLaunchKernelGGL(k_lm_gemm, dim3((unsigned)std::max(grid, 1)), dim3(256), 0, st, q, h->lm_qinfo.as<LmQuery>(), h->vecs(), h->lm_rn.as<float>(),
+                               h->list_off(), h->lm_items.as<LmItem>(), h->lm_n.as<int>(), d, pitch, h->lm_S.as<float>());
+        });
+        h->prof.launch("ivf_select", 3.0 * nq * 12 * d, (double)nq * (12.0 * d * 4 + pitch * 4.0 + d * 8.0), st, [&] {
+            auto kern = d == 768 ? &k_lm_select<3> : (d == 256 ? &k_lm_select<1> : &k_lm_select<0>);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 3) / 4)), dim3(256), (size_t)4 * ((size_t)pitch * 4 + LM_WAVE_EXTRA), st, q, h->lm_qinfo.as<LmQuery>(),
+                               h->ids(), h->vecs(), h->lm_S.as<float>(), (int)nq, (int)b.nlist, d, pitch,
+                               h->lm_vmax, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(), bf ? bf->feats : nullptr, bf ? bf->rate : 0.f,
+                               bf ? bf->omr : 0.f, h->hdr.pos_last);
+        });
+        HIP_CHECK(hipGetLastError());
+        return bf != nullptr;
     }
     // list-sorted, XCD-contiguous query order for the specialised scans (see k_qsort_hist)
     const int* perm = nullptr;

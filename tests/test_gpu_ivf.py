@@ -35,10 +35,21 @@ def test_search_ids_bit_exact_and_distances(n, d, nq, gpu):
     Dt, It = h.search(torch.from_numpy(q).to(gpu), 8)
     assert Dt.is_cuda and np.array_equal(It.cpu().numpy(), Ir)
     # queries scanned in the list-sorted, XCD-contiguous order (k_qsort_*, opt-in) instead of arrival order: identical results
+    h.set_option("IVF_LM", 0)  # (the list-sorted order is an option of the query-major kernel)
     h.set_option("IVF_SORT", 1)
     D0, I0 = h.search(q, 8)
     h.set_option("IVF_SORT", None)
     assert np.array_equal(I0, Ir) and np.array_equal(D0, Dr)
+    # query-major kernel (round 3, IVF_LM=0) and list-major path (default from 64 queries on): the same bits, and the profiler
+    # names say which one ran
+    for lm in (0, None):
+        h.set_option("IVF_LM", lm)
+        h.profile(True)
+        D1, I1 = h.search(q, 8)
+        names = {st["name"] for st in h.profile_read()}
+        h.profile(False)
+        assert np.array_equal(I1, Ir) and np.array_equal(D1, Dr)
+        assert ("ivf_select" in names) == (lm is None and nq >= 64 and d % 32 == 0), names
 
 
 @pytest.mark.parametrize("nprobe", [2, 9])
@@ -87,6 +98,55 @@ def test_short_lists_empty_lists_empty_queries_and_ties(gpu):
 
     with pytest.raises(rvc_amd.RvcmiError):
         h.search(q, 9)  # k > 8
+
+
+def test_list_major_scan_edge_cases(gpu):
+    """The list-major path (ivf_lm_kernels.hpp: plan -> fp32 MFMA score tiles -> fp64 verification of everything inside the
+    rigorous margin) on the cases the tile logic can get wrong: lists shorter than k (padding -1 / FLT_MAX), an EMPTY probed list,
+    lists of exactly 32 / 33 / 65 rows (tile edges), more than 32 queries on one list (several query tiles), exact duplicate rows
+    (distance ties -> lowest id) and an exact hit; against the oracle and against the query-major kernel, fused blend included."""
+    rng = np.random.default_rng(31)
+    d = 32
+    sizes = np.array([3, 0, 32, 33, 65, 1, 8, 9, 200, 7], dtype=np.int64)
+    nlist, n = len(sizes), int(sizes.sum())
+    cent = (rng.standard_normal((nlist, d)) * 6).astype(np.float32)
+    off = np.zeros(nlist + 1, np.int64)
+    np.cumsum(sizes, out=off[1:])
+    vecs = np.concatenate([cent[l] + rng.standard_normal((int(sizes[l]), d)).astype(np.float32) for l in range(nlist)]).astype(np.float32)
+    vecs[off[8] + 5] = vecs[off[8] + 4]        # duplicate rows inside the 200-row list
+    vecs[off[8] + 150] = vecs[off[8] + 4]
+    ids = rng.permutation(n).astype(np.int64)
+    idx = dict(d=d, ntotal=n, nlist=nlist, nprobe=1, centroids=cent, list_offsets=off, ids=ids, vecs=vecs)
+    pos = np.empty(n, np.int64)
+    pos[ids] = np.arange(n)
+    idx["xb"] = vecs[pos]
+    per = [5, 4, 10, 40, 70, 3, 9, 33, 90, 6]  # queries aimed at every list (the empty one included), two lists get > 32
+    q = np.concatenate([cent[l] + 0.7 * rng.standard_normal((per[l], d)).astype(np.float32) for l in range(nlist)]).astype(np.float32)
+    q[-1] = vecs[off[8] + 4]                   # an exact hit on the triplicated row
+    q = q[rng.permutation(len(q))]
+    assert len(q) >= 64
+    h = make(idx, gpu)
+    Dr, Ir = ivf_oracle.search(idx, q, 8)
+    assert (Ir == -1).any() and (Ir[:, 0] == -1).any()
+    for lm in (None, 0):
+        h.set_option("IVF_LM", lm)
+        h.profile(True)
+        D, I = h.search(q, 8)
+        names = {st["name"] for st in h.profile_read()}
+        h.profile(False)
+        assert ("ivf_select" in names) == (lm is None)
+        assert np.array_equal(I, Ir), "IVF_LM=%s: %d id mismatches" % (lm, int((I != Ir).sum()))
+        assert np.array_equal(D, Dr)
+        for k in (1, 5):
+            Dk, Ik = h.search(q, k)
+            assert np.array_equal(Ik, Ir[:, :k]) and np.array_equal(Dk, Dr[:, :k])
+        got = h.search_blend(torch.from_numpy(q).to(gpu), 0.75).cpu().numpy()
+        exp = ivf_oracle.search_blend(idx, q, 0.75)
+        ok = ~np.isnan(exp).any(1)
+        assert np.array_equal(np.isnan(got).any(1), ~ok) and np.abs(got[ok] - exp[ok]).max() <= 1e-5
+        kept = h.search_blend(torch.from_numpy(q).to(gpu), 0.75, skip_if_short=True).cpu().numpy()
+        assert np.array_equal(kept, q)  # some list is shorter than k: the realtime guard skips the whole call
+    h.set_option("IVF_LM", None)
 
 
 def test_search_blend_matches_pipeline_arithmetic(gpu):

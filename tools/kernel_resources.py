@@ -4,7 +4,7 @@ import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "retrieval-based-voice-conversion-webui_amd", "csrc")
-KEEP = ("k_rb_pair", "k_rb_full", "k_rb_stream", "k_frame_rms", "k_change_rms", "k_ups", "k_conv_mfma", "k_post", "k_scan", "k_coarse", "k_blend", "k_fr_", "k_sola", "k_f0_post",
+KEEP = ("k_lm_", "k_rb_pair", "k_rb_full", "k_rb_stream", "k_frame_rms", "k_change_rms", "k_ups", "k_conv_mfma", "k_post", "k_scan", "k_coarse", "k_blend", "k_fr_", "k_sola", "k_f0_post",
         "k_rmvpe", "k_phase_scan", "k_sine")
 with tempfile.TemporaryDirectory() as tmp:
     for src in ("nsf.hip", "rb_stream.hip", "ivf.hip", "front.hip", "glue.hip"):
