@@ -112,8 +112,14 @@ int rvcmi_nsf_destroy(rvcmi_nsf* h);
  *              only harmonic there is, so it never reaches the output.)
  *   n_res      -1 = none; otherwise the realtime "return_length2" resample target, nsf.py:155-162
  *   out_dev    [B, T_out*upp] fp32, T_out = n_res if n_res >= 0 else T
+ *   lengths_dev  NULL, or int32 [B] on the device with 1 <= lengths[b] <= T: a RAGGED batch.  Item b is
+ *              computed exactly as a separate call with T = lengths[b] on its first lengths[b] frames (lengths[b] * upp
+ *              noise samples) would compute it: every layer zero-pads its input behind the item's own last row, so the
+ *              segments of a long file (infer/modules/vc/pipeline.py:205-209, 301-343) and the utterances of a folder
+ *              (infer/modules/vc/modules.py:201-266 vc_multi) convert in ONE call with the waveform of sequential calls.
+ *              Output samples [lengths[b] * upp, T * upp) of item b are zero.  Not combinable with n_res.
  */
-int rvcmi_nsf_forward(rvcmi_nsf* h, int B, int T, const float* x_dev, const float* f0_dev,
+int rvcmi_nsf_forward(rvcmi_nsf* h, int B, int T, const int* lengths_dev, const float* x_dev, const float* f0_dev,
                       const float* g_dev, const float* noise_dev, int n_res, float* out_dev,
                       void* stream);
 

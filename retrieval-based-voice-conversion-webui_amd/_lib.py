@@ -61,7 +61,7 @@ SYMBOLS = [
     ("rvcmi_version", C.c_int, []),
     ("rvcmi_nsf_create", C.c_int, [C.POINTER(NsfConfig), C.POINTER(Tensor), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("rvcmi_nsf_destroy", C.c_int, [_P]),
-    ("rvcmi_nsf_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P]),
+    ("rvcmi_nsf_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     ("rvcmi_nsf_upp", C.c_int, [_P]),
     ("rvcmi_nsf_workspace_bytes", C.c_size_t, [_P]),
     ("rvcmi_nsf_debug_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_char_p, _P, C.c_size_t,

@@ -533,7 +533,8 @@ static bool y_f16(const rvcmi_nsf* h) {
 }
 
 // Whole resblocks of a stage on the streaming kernel (ND = 3).  Fills src[j] with the output streams on success.
-static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int L, int B, int nk, const float** src, hipStream_t st) {
+static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int L, int B, int nk, const float** src, hipStream_t st,
+                               const int* lens, int lm) {
     const bool yh = y_f16(h);
     const int mode = rb_stream_mode(h);
     if (mode == 0 || op == RVCMI_OPERAND_F32 || nk > 3) return false;
@@ -552,6 +553,8 @@ static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int 
         d.src = h->X0.as<float>();
         d.dst = h->Ya[j].as<float>();
         d.y_half = yh ? 1 : 0;
+        d.lens = lens;
+        d.lmul = lm;
         d.k = s.rb[j][0].first.ntaps[0];
         d.k_p = s.rb[j][0].first.ntaps_p;
         d.ct1 = s.rb[j][0].first.ct_stride;
@@ -579,6 +582,7 @@ static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int 
 }
 
 static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const char* name, hipStream_t st) {
+    if (!a.cf_stride) a.cf_stride = a.Lin;
     a.cin = L.cin;
     a.cout = L.cout;
     a.bias = L.bias.as<float>();
@@ -720,9 +724,12 @@ static void copy_tap_cl(rvcmi_nsf* h, const float* src_cl, int B, int L, int C, 
     tr->done = true;
 }
 
-static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float* f0, const float* g,
+// `lens`: optional device array [B] of valid frames per item (1 <= lens[b] <= T): a ragged batch, every item computed exactly as
+// a separate call of its own length (nsf_kernels.hpp item_rows); the output rows behind an item's end are zero.
+static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float* x, const float* f0, const float* g,
                         const float* noise, int n_res, float* out, hipStream_t st, TapRequest* tr) {
     if (!h || !x || (!out && !tr)) RVCMI_FAIL(RVCMI_ERR_INVALID, "null argument");
+    if (lens && n_res >= 0) RVCMI_FAIL(RVCMI_ERR_INVALID, "lengths and n_res (the realtime interpolation) cannot be combined");
     const rvcmi_nsf_config& c = h->cfg;
     if (c.use_f0 && !f0) RVCMI_FAIL(RVCMI_ERR_INVALID, "f0 is required for an NSF (use_f0) generator");
     if (B < 1 || T < 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "B and T must be positive");
@@ -740,7 +747,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
     const float* har = nullptr;
     if (c.use_f0) {
         h->prof.launch("phase_scan", 0, (double)B * T * 8, st, [&] {
-            hipLaunchKernelGGL(k_phase_scan, dim3(B), dim3(256), 0, st, f0, h->phase.as<float>(), T, (float)c.sr, (float)upp);
+            hipLaunchKernelGGL(k_phase_scan, dim3(B), dim3(256), 0, st, f0, h->phase.as<float>(), T, (float)c.sr, (float)upp, lens);
         });
         const size_t total = (size_t)B * T * upp;
         h->prof.launch("sine_source", 0, (double)total * (noise ? 8 : 4), st, [&] {
@@ -788,6 +795,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
         a.out_bstride = (long)Te * C0;
         a.out_C = C0;
         a.cb = (g && c.gin_channels) ? h->condv.as<float>() : nullptr;
+        a.lens = lens;
+        a.lmul_in = a.lmul_q = 1;
         run_conv(h, h->pre, a, B, "conv_pre", st);
     }
     if (want("pre")) return copy_tap_cl(h, P, B, Te, C0, tr, st);
@@ -798,9 +807,12 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
     float div = 1.f;
     long L = Te;
     int Cprev = C0;
+    int lm = 1;  // rows per frame at the current stage (ragged batches: item rows = lens[b] * lm)
     for (int i = 0; i < c.n_ups; ++i) {
         Stage& s = h->stages[i];
         const long Lin = L;
+        const int lm_prev = lm;
+        lm *= s.u;
         L = Lin * s.u;
         const int C = s.cout;
         const int nk = (int)s.rb.size();
@@ -821,6 +833,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 a.out_bstride = L * C;
                 a.out_C = C;
                 a.out_mul = s.u;
+                a.lens = lens;
+                a.lmul_in = a.lmul_q = lm_prev;
                 snprintf(nm, sizeof(nm), "ups_c%d", s.cin);
                 run_conv(h, s.up, a, B, nm, st);
             }
@@ -829,7 +843,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 snprintf(nm, sizeof(nm), "noise_conv_c%d", C);
                 h->prof.launch(nm, 2.0 * s.nk * n * B, (double)B * n * 8, st, [&] {
                     hipLaunchKernelGGL(k_noise_add, dim3((unsigned)((n + 255) / 256), 1, B), dim3(256), 0, st, h->X0.as<float>(),
-                                       har, s.noise_w.as<float>(), s.noise_b.as<float>(), (int)L, C, Te * upp, s.nk, s.ns, s.npad);
+                                       har, s.noise_w.as<float>(), s.noise_b.as<float>(), (int)L, C, Te * upp, s.nk, s.ns, s.npad, lens, lm, upp);
                 });
             }
         } else {  // ups + bias + noise conv in one MFMA kernel, X0 written once      nsf.py:171-174
@@ -841,6 +855,10 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             ua.in_b = y[1];
             ua.in_c = y[2];
             ua.in_half = yhalf ? 1 : 0;
+            ua.lens = lens;
+            ua.lmul = lm_prev;
+            ua.lhmul = upp;
+            ua.Lh_stride = Te * upp;
             ua.div = div;
             ua.Lin = (int)Lin;
             ua.cin = s.cin;
@@ -874,6 +892,9 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 na.out = h->NZ.p;
                 na.out_bstride = L * C;
                 na.out_C = C;
+                na.lens = lens;
+                na.lmul_in = upp;
+                na.lmul_q = lm;
                 snprintf(nm, sizeof(nm), "noise_mfma_c%d", C);
                 run_conv(h, s.nz, na, B, nm, st);
                 ua.addend = h->NZ.as<float>();
@@ -939,6 +960,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     a.Lin = (int)L;
                     a.in_mode = IN_F32_ACT;
                     a.Lq = (int)L;
+                    a.lens = lens;
+                    a.lmul_in = a.lmul_q = lm;
                     a.out_mode = OUT_ACT;
                     a.out = h->H.p;
                     a.out_bstride = L * C;
@@ -950,6 +973,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     a.Lin = (int)L;
                     a.in_mode = IN_OP_RAW;
                     a.Lq = (int)L;
+                    a.lens = lens;
+                    a.lmul_in = a.lmul_q = lm;
                     a.out_mode = OUT_F32;
                     a.out = dst;
                     a.out_bstride = L * C;
@@ -978,6 +1003,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     a.Lin = (int)L;
                     a.in_mode = IN_F32_ACT;
                     a.Lq = (int)L;
+                    a.lens = lens;
+                    a.lmul_in = a.lmul_q = lm;
                     a.out_mode = OUT_ACT;
                     a.out = hbuf;
                     a.out_bstride = L * C;
@@ -990,6 +1017,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                     a.Lin = (int)L;
                     a.in_mode = IN_OP_RAW;
                     a.Lq = (int)L;
+                    a.lens = lens;
+                    a.lmul_in = a.lmul_q = lm;
                     a.out_mode = OUT_F32;
                     a.out = dst;
                     a.out_bstride = L * C;
@@ -1005,7 +1034,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 run_conv_jobs(h, L1, a1, nj, B, nm, st);
                 run_conv_jobs(h, L2, a2, nj, B, nm, st);
             }
-        } else if (try_rb_stream_full(h, s, op, C, (int)L, B, nk, src, st)) {
+        } else if (try_rb_stream_full(h, s, op, C, (int)L, B, nk, src, st, lens, lm)) {
             // streaming fused resblocks (rb_stream_kernels.hpp): persistent blocks walk strips of the time axis
             stage_half = y_f16(h);
         } else if (C <= 64 && maxnd <= 3 && !h->opt.on("NO_RBFULL")) {
@@ -1014,6 +1043,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
             RbFullArgs ra;
             memset(&ra, 0, sizeof(ra));
             ra.L = (int)L;
+            ra.lens = lens;
+            ra.lmul = lm;
             ra.bstride = L * C;
             ra.dbg = dbg_flags(h);
             stage_half = y_f16(h);
@@ -1100,6 +1131,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                 const int only_j = jmajor ? (int)(pass / maxnd) : -1;
                 RbPairArgs ra;
                 memset(&ra, 0, sizeof(ra));
+                ra.lens = lens;
+                ra.lmul = lm;
                 ra.L = (int)L;
                 ra.bstride = L * C;
                 ra.dbg = dbg_flags(h);
@@ -1155,6 +1188,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
                         memset(&sd[q], 0, sizeof(sd[q]));
                         sd[q].src = J.src; sd[q].dst = J.dst; sd[q].w1[0] = J.w1; sd[q].w2[0] = J.w2; sd[q].b1[0] = J.b1; sd[q].b2[0] = J.b2;
                         sd[q].ct1 = J.ct1; sd[q].ct2 = J.ct2; sd[q].k = J.k; sd[q].k_p = J.k_p; sd[q].dil[0] = J.dil;
+                        sd[q].lens = lens; sd[q].lmul = lm;
                     }
                     char nms[48];
                     snprintf(nms, sizeof(nms), "rb_stream1_c%d", C);
@@ -1208,7 +1242,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float*
     h->prof.launch("conv_post", 2.0 * 7 * Cprev * (double)L * B, (double)B * L * (Cprev * nkk * (yhalf ? 2 : 4) + 4), st, [&] {
         const size_t smem = (size_t)(7 * Cprev + (POST_TT + 6) * (Cprev + 4)) * 4;
         hipLaunchKernelGGL(k_post, dim3((unsigned)((L + POST_TT - 1) / POST_TT), B), dim3(256), smem, st, y[0], y[1], y[2],
-                           h->post_w.as<float>(), out, (int)L, Cprev, div, yhalf ? 1 : 0);
+                           h->post_w.as<float>(), out, (int)L, Cprev, div, yhalf ? 1 : 0, lens, lm);
     });
     HIP_CHECK(hipGetLastError());
 }
@@ -1228,9 +1262,9 @@ int rvcmi_nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights, i
 int rvcmi_nsf_destroy(rvcmi_nsf* h) {
     return guarded([&] { delete h; });
 }
-int rvcmi_nsf_forward(rvcmi_nsf* h, int B, int T, const float* x, const float* f0, const float* g, const float* noise,
-                      int n_res, float* out, void* stream) {
-    return guarded([&] { nsf_forward(h, B, T, x, f0, g, noise, n_res, out, (hipStream_t)stream, nullptr); });
+int rvcmi_nsf_forward(rvcmi_nsf* h, int B, int T, const int* lengths, const float* x, const float* f0, const float* g,
+                      const float* noise, int n_res, float* out, void* stream) {
+    return guarded([&] { nsf_forward(h, B, T, lengths, x, f0, g, noise, n_res, out, (hipStream_t)stream, nullptr); });
 }
 int rvcmi_nsf_upp(const rvcmi_nsf* h) { return h ? h->upp : RVCMI_ERR_INVALID; }
 size_t rvcmi_nsf_workspace_bytes(const rvcmi_nsf* h) { return h ? h->ws_bytes : 0; }
@@ -1245,7 +1279,7 @@ int rvcmi_nsf_debug_forward(rvcmi_nsf* h, int B, int T, const float* x, const fl
         tr.out_host = out_host;
         tr.capacity = capacity_floats;
         tr.shape = shape_out;
-        nsf_forward(h, B, T, x, f0, g, noise, n_res, nullptr, (hipStream_t)stream, &tr);
+        nsf_forward(h, B, T, nullptr, x, f0, g, noise, n_res, nullptr, (hipStream_t)stream, &tr);
         if (!tr.done) RVCMI_FAIL(RVCMI_ERR_INVALID, "tap '%s' was not produced", what);
     });
 }

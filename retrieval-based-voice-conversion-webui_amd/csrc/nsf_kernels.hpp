@@ -27,6 +27,15 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// Ragged batches (rvcmi_nsf_forward `lengths`): item b of a batch holds lens[b] <= T valid frames and is computed EXACTLY as a
+// separate call of that length would compute it -- every layer zero-pads its input beyond the item's own last row (the padded
+// batch of the reference lets the rows behind a short item leak into its tail through every receptive field).  Each kernel
+// replaces its row count by the item's: rows(lens, b, mul, Lmax) = lens[b] * mul (mul = the stage's upsampling factor so far);
+// buffer strides stay those of the longest item.
+__device__ __forceinline__ int item_rows(const int* __restrict__ lens, int b, int mul, int Lmax) {
+    return lens ? min(Lmax, lens[b] * mul) : Lmax;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Sine source (generators.py:148-194) + source module (nsf.py:57-61)
 // ------------------------------------------------------------------------------------------------
@@ -37,14 +46,15 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 // on exact rounding boundaries.  One block of 256 threads per utterance (the frames' slow fmod / divide chain is spread
 // over 4 waves: 15 -> ~5 us for a 10 s clip; the block-level scan goes through LDS).
 static __global__ void __launch_bounds__(256) k_phase_scan(const float* __restrict__ f0, float* __restrict__ phase,
-                                                   int T, float sr, float upp) {
+                                                   int T, float sr, float upp, const int* __restrict__ lens) {
 #pragma clang fp contract(off)
     __shared__ double wsum[4];
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* f = f0 + (size_t)b * T;
     float* ph = phase + (size_t)b * T;
-    const int n = T - 1;  // increments come from frames 0..T-2
+    // (ragged batch: the item's own frame count sets the thread partition, so the fp64 prefix sums are those of a separate call)
+    const int n = item_rows(lens, b, 1, T) - 1;  // increments come from frames 0..T-2
     const int per = (n + 255) / 256;
     const int beg = min(n, tid * per);
     const int end = min(n, beg + per);
@@ -148,6 +158,9 @@ struct ConvArgs {
     const float* in_c;
     long in_bstride;   // elements per batch item
     int Lin;           // valid input rows
+    int cf_stride;     // IN_F32_CF: elements between channels (= the longest item's Lin)
+    const int* lens;   // ragged batch (item_rows): Lin = lens[b] * lmul_in, Lq = lens[b] * lmul_q; nullptr = every item full length
+    int lmul_in, lmul_q;
     int cin;
     int in_mode;
     int hs, hpad;      // IN_HAR: frame length (= noise-conv stride) and left padding; Lin counts SAMPLES of har
@@ -184,6 +197,8 @@ struct ConvArgs {
 // One thread per (q, co); co fastest so that weight reads and stores coalesce.
 static __global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
     const int b = blockIdx.z;
+    a.Lin = item_rows(a.lens, b, a.lmul_in, a.Lin);
+    a.Lq = item_rows(a.lens, b, a.lmul_q, a.Lq);
     const int ph = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)a.Lq * a.cout) return;
@@ -199,7 +214,7 @@ static __global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
         if (r < 0 || r >= a.Lin) continue;
         const float* wj = W + (size_t)j * a.cin * a.cout + co;
         if (a.in_mode == IN_F32_CF) {
-            for (int ci = 0; ci < a.cin; ++ci) acc = fmaf(in[(size_t)ci * a.Lin + r], wj[(size_t)ci * a.cout], acc);
+            for (int ci = 0; ci < a.cin; ++ci) acc = fmaf(in[(size_t)ci * a.cf_stride + r], wj[(size_t)ci * a.cout], acc);
         } else if (a.in_mode == IN_F32_ACT) {
             const float* row = in + (size_t)r * a.cin;
             const float* rowb = a.in_b ? a.in_b + (size_t)b * a.in_bstride + (size_t)r * a.cin : nullptr;
@@ -230,10 +245,12 @@ static __global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
 // x[b][t][co] += bn[co] + sum_j har[b][t*s - pad + j] * Wn[j][co]      (nsf.py:173-174)
 static __global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x, const float* __restrict__ har,
                                                    const float* __restrict__ Wn /*[k][C]*/, const float* __restrict__ bn,
-                                                   int L, int C, int Lh, int k, int s, int pad) {
+                                                   int L, int C, int Lh, int k, int s, int pad, const int* __restrict__ lens, int lmul,
+                                                   int lhmul) {
     const int b = blockIdx.z;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)L * C) return;
+    if (i >= (size_t)item_rows(lens, b, lmul, L) * C) return;
+    const int Lhb = item_rows(lens, b, lhmul, Lh);
     const int t = (int)(i / C);
     const int co = (int)(i - (size_t)t * C);
     const float* h = har + (size_t)b * Lh;
@@ -241,7 +258,7 @@ static __global__ void __launch_bounds__(256) k_noise_add(float* __restrict__ x,
     const int base = t * s - pad;
     for (int j = 0; j < k; ++j) {
         int r = base + j;
-        if (r >= 0 && r < Lh) acc = fmaf(h[r], Wn[(size_t)j * C + co], acc);
+        if (r >= 0 && r < Lhb) acc = fmaf(h[r], Wn[(size_t)j * C + co], acc);
     }
     x[((size_t)b * L + t) * C + co] += acc;
 }
@@ -272,7 +289,8 @@ constexpr int POST_TT = 256;  // = blockDim: one output sample per thread (a 128
 // grid = resident blocks 41 us, two tiles for every block 46 us -- the launch is not limited by its last half-empty round.
 static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ xa, const float* __restrict__ xb,
                                               const float* __restrict__ xc, const float* __restrict__ Wp /*[7][C]*/,
-                                              float* __restrict__ out, int L, int C, float div, int in_half) {
+                                              float* __restrict__ out, int Lmax, int C, float div, int in_half,
+                                              const int* __restrict__ lens, int lmul) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* w = (float*)smem_raw;          // [7][C]
     float* tile = w + 7 * C;              // [POST_TT + 6][C + 4]
@@ -280,10 +298,15 @@ static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ x
     const int S = C + 4;
     for (int i = threadIdx.x; i < 7 * C; i += 256) w[i] = Wp[i];
     const int C4 = C >> 2;
-    const size_t boff = (size_t)b * L * C;
-    const int ntiles = (L + POST_TT - 1) / POST_TT;
+    const int L = item_rows(lens, b, lmul, Lmax);  // rows of this item (strides: Lmax); rows [L, Lmax) of the output are zeroed
+    const size_t boff = (size_t)b * Lmax * C;
+    const int ntiles = (Lmax + POST_TT - 1) / POST_TT;
     for (int ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
         const int t0 = ti * POST_TT;
+        if (t0 >= L) {  // block-uniform: a tile behind the item's end
+            if (t0 + (int)threadIdx.x < Lmax) out[(size_t)b * Lmax + t0 + threadIdx.x] = 0.f;
+            continue;
+        }
         // batched, unconditional (clamped) loads: the former per-chunk `if (in range) { load; if (xb) load; if (xc) load }` loop
         // was ~8 serial HBM round trips per thread
         constexpr int SB = 5;
@@ -394,7 +417,9 @@ static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ x
                     acc = fmaf(xv.w, wv.w, acc);
                 }
             }
-            out[(size_t)b * L + t] = tanhf(acc);
+            out[(size_t)b * Lmax + t] = tanhf(acc);
+        } else if (t < Lmax) {
+            out[(size_t)b * Lmax + t] = 0.f;
         }
         __syncthreads();  // the tile is restaged by the next iteration
     }
@@ -500,7 +525,7 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
                 const int c8 = idx / rows, r = idx - c8 * rows;
                 const int grc = min(max(g0 + r, 0), a.Lin - 1);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[u][e] = ip[(size_t)(c8 * 8 + e) * a.Lin + grc];
+                for (int e = 0; e < 8; ++e) f[u][e] = ip[(size_t)(c8 * 8 + e) * a.cf_stride + grc];
             }
 #pragma unroll
             for (int u = 0; u < SBC; ++u) {
@@ -614,9 +639,9 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
                     v[e] = to_op<OpT>(lrelu(x, a.slope_in));
                 }
             } else {  // IN_F32_CF
-                const float* p = (const float*)a.in + (size_t)b * a.in_bstride + (size_t)(c8 * 8) * a.Lin + gr;
+                const float* p = (const float*)a.in + (size_t)b * a.in_bstride + (size_t)(c8 * 8) * a.cf_stride + gr;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(p[(size_t)e * a.Lin]);
+                for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(p[(size_t)e * a.cf_stride]);
             }
         }
         *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
@@ -959,6 +984,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int b, char* s
 template <typename OpT, int CIN, int MI, int NJ, int WCO>
 static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    a.Lin = item_rows(a.lens, (int)blockIdx.z, a.lmul_in, a.Lin);
+    a.Lq = item_rows(a.lens, (int)blockIdx.z, a.lmul_q, a.Lq);
     conv_mfma_body<OpT, CIN, MI, NJ, WCO>(a, (int)blockIdx.z, smem);
 }
 
@@ -975,7 +1002,10 @@ static __global__ void __launch_bounds__(256) k_conv_mfma_jobs(ConvJobs js) {
     const int j = (int)blockIdx.z % js.njobs, b = (int)blockIdx.z / js.njobs;
     // a weight ring of 4 groups (12 k-steps in flight): with one MFMA per k-step (NJ = 1) the default 2 groups cover 4 k-steps =
     // ~260 cycles, less than one L2 round trip, and the K loop ran at the latency of the weight loads (28 us per launch)
-    conv_mfma_body<OpT, CIN, MI, NJ, WCO, 4, true>(js.job[j], b, smem);
+    ConvArgs a = js.job[j];
+    a.Lin = item_rows(a.lens, b, a.lmul_in, a.Lin);
+    a.Lq = item_rows(a.lens, b, a.lmul_q, a.Lq);
+    conv_mfma_body<OpT, CIN, MI, NJ, WCO, 4, true>(a, b, smem);
 }
 
 // Branch-free helpers.  lrelu as max(x, slope*x) (0 < slope < 1); row masking by AND-ing the value bits so that
@@ -1076,6 +1106,8 @@ struct RbJob {
 struct RbPairArgs {
     RbJob job[4];
     int L;
+    const int* lens;  // ragged batch (item_rows)
+    int lmul;
     long bstride;
     int dbg;  // timing ablations only (RVCMI_DBG): 2 skip conv1, 4 skip conv2, 16 skip store, 32 phase stamps
     unsigned long long* ts;
@@ -1108,6 +1140,8 @@ static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArg
     const RbJob& J = a.job[bjob];
     if (btile >= J.ntiles) return;
     const int b = blockIdx.z;
+    a.L = item_rows(a.lens, b, a.lmul, a.L);
+    if (btile * J.tt2 >= a.L) return;  // (ragged batch) a tile behind the item's end: block-uniform, before any barrier
     const int p2 = (J.k - 1) / 2;
     const int p1 = J.dil * (J.k - 1) / 2;
     const int t0 = btile * J.tt2;          // first output time of this tile
@@ -1296,6 +1330,9 @@ struct UpsArgs {
     const float* addend;  // optional [B][Lin*u][cout] fp32 added in the epilogue (noise conv done by the MFMA conv)
     const float* har;  // [B][Lh] or nullptr (no-f0 generator / addend in use)
     int Lh;
+    int Lh_stride;     // elements between the items of har (= the longest item's Lh)
+    const int* lens;   // ragged batch (item_rows): Lin = lens[b] * lmul, Lh = lens[b] * lhmul
+    int lmul, lhmul;
     const float* Wn;   // [nk][cout]
     const float* bn;
     int nk, ns, npad;
@@ -1317,6 +1354,9 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.z;
     const int q0 = blockIdx.x * TQ;
+    a.Lin = item_rows(a.lens, b, a.lmul, a.Lin);
+    a.Lh = item_rows(a.lens, b, a.lhmul, a.Lh);
+    if (q0 >= a.Lin) return;  // (ragged batch) a tile behind the item's end: block-uniform, before the barrier
     const int g0 = q0 + a.lo;
     const size_t boff = (size_t)b * a.in_bstride;
 
@@ -1390,7 +1430,7 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
     const int us = a.u * a.ns;
     if (a.nz_k1) {
         const long hbase = (long)q0 * us - a.npad;
-        const float* hp = a.har + (size_t)b * a.Lh;
+        const float* hp = a.har + (size_t)b * a.Lh_stride;
         const int span = TQ * us + 16;
         for (int i = threadIdx.x; i < span; i += 256) {
             const long idx = hbase + i;
@@ -1404,7 +1444,7 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
     const int wv = wave % WV, wt = wave / WV;
     const int tw0 = wt * NJ * 32;
     const char* lds_lane = smem + (size_t)(tw0 + (lane & 31)) * STRIDE + (lane >> 5) * 16;
-    const float* har = (a.har && !a.nz_k1) ? a.har + (size_t)b * a.Lh : nullptr;  // VALU noise path only
+    const float* har = (a.har && !a.nz_k1) ? a.har + (size_t)b * a.Lh_stride : nullptr;  // VALU noise path only
     float* out = a.out + (size_t)b * a.out_bstride;
 
     for (int i = 0; i < a.vpw; ++i) {
@@ -1519,6 +1559,8 @@ struct RbFullJob {
 struct RbFullArgs {
     RbFullJob job[3];
     int L;
+    const int* lens;  // ragged batch (item_rows)
+    int lmul;
     long bstride;
     int dbg;
     int yh;  // 1: dst streams are fp16 (pack4_h), same element layout
@@ -1547,7 +1589,9 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
     const RbFullJob& J = a.job[blockIdx.y];
     if ((int)blockIdx.x >= J.ntiles) return;
     const int b = blockIdx.z;
+    a.L = item_rows(a.lens, b, a.lmul, a.L);
     const int tg0 = blockIdx.x * J.tvalid - J.HL;  // global time of tile row 0
+    if (tg0 + J.HL >= a.L) return;  // (ragged batch) no valid row of this tile lies inside the item: block-uniform, before any barrier
     const float* src = J.src + (size_t)b * a.bstride;
     float* dst = J.dst + (size_t)b * a.bstride;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

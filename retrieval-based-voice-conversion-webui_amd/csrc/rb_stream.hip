@@ -364,6 +364,9 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
     // k_rb_stream with the lean K loop (kconv) and the coalesced step IO; its buffer descriptors address an utterance's rows with
     // 32-bit byte offsets, so utterances of 2 GiB or more per stream (349 s of audio at C = 128) keep the D-layout form
     if (g.ver == 1 && opt.geti("RS_KL", RS_KL_DEFAULT) == 2 && (double)L * C * 4.0 < 2147483648.0) a.flags = 4;
+    a.lens = jobs[0].lens;
+    a.lmul = jobs[0].lmul;
+    if (a.lens && g.ver != 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: ragged batches are implemented by k_rb_stream only");
     if (jobs[0].y_half) {
         if (g.ver != 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: fp16 output streams are implemented by k_rb_stream only");
         a.flags |= 8;

@@ -17,6 +17,8 @@ struct RbStreamDesc {  // one resblock (ND = 3: all its pairs) or one pair level
     int k, k_p;
     int dil[3];
     int y_half;  // (jobs[0] decides for the launch) dst streams are fp16; only k_rb_stream itself honours it
+    const int* lens;  // (jobs[0]) ragged batch: item b holds lens[b] * lmul rows (nsf_kernels.hpp item_rows); nullptr = all L
+    int lmul;
 };
 
 // CUs of the current device (cached per device).

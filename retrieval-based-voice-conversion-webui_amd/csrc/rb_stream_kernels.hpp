@@ -48,6 +48,8 @@ struct RbStreamArgs {
     int njobs;
     int B;          // utterances; the grid is (sum of nstrips) * B blocks
     int L;
+    const int* lens;  // ragged batch (nsf_kernels.hpp item_rows)
+    int lmul;
     long bstride;
     int side_rows;  // rows of the side area (max over jobs)
     int skew;       // k_rb_stream2: the second block of a CU starts `skew * (k + 3)` x 1024 cycles late (0 = together)
@@ -107,9 +109,10 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
     if (b >= a.B) return;
     const float* src = J.src + (size_t)b * a.bstride;
     float* dst = J.dst + (size_t)b * a.bstride;
-    const int L = a.L;
+    const int L = item_rows(a.lens, b, a.lmul, a.L);
     const int S0 = strip * J.strip_len;
     const int S1 = min(L, S0 + J.strip_len);
+    if (S0 >= L) return;  // (ragged batch) a strip behind the item's end: block-uniform, before any barrier
     const int p2 = (J.k - 1) / 2;
     int HL = ND * p2;
 #pragma unroll

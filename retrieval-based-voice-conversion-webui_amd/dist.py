@@ -75,3 +75,49 @@ def broadcast_index(index, src: int = 0, device=None, group=None):
     if rank == src:
         return index
     return IVFFlatHIP.from_blob(buf)
+
+
+def convert_batch(paths, convert_one, index=None, src: int = 0, group=None, gather: bool = True, device=None):
+    """``VC.vc_multi`` (infer/modules/vc/modules.py:201-266: one ``vc_single`` per file of a folder, sequentially) across the
+    ranks of one node.  Rank r converts the contiguous shard ``shard_range(len(paths), r, world)`` of ``paths`` -- the same list
+    on every rank -- by calling ``convert_one(path, index)`` (e.g. ``lambda p, ix: vc.vc_single(sid, p, ..., file_index=ix, ...)``
+    or a closure over ``Pipeline.pipeline``); files are independent, so there is NO data-path collective.
+
+    ``index``: an ``IVFFlatHIP`` on rank ``src`` (None elsewhere) is replicated with ONE broadcast of its blob over RCCL/xGMI
+    (``broadcast_index``) before the first file; any other value (a path every rank reads itself, None) is passed through.
+
+    Returns ``[(path, result)]`` for THIS rank's shard, in order; with ``gather=True`` rank ``src`` instead gets the results of ALL
+    files in the order of ``paths`` (one ``gather_object`` of the per-rank host results at the very end -- the reference's
+    ``infos`` list) and the other ranks their own shard.  An exception inside ``convert_one`` becomes that file's result (the
+    reference appends the traceback text to ``infos`` and goes on), so one bad file never stalls the other ranks.
+    Without an initialised process group it is the plain sequential loop."""
+    import traceback
+
+    paths = list(paths)
+    on = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if on else 0
+    world = dist.get_world_size(group) if on else 1
+    if on and world > 1:
+        from .ivf import IVFFlatHIP
+
+        flag = torch.zeros(1, dtype=torch.int64, device=device if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")))
+        if rank == src and isinstance(index, IVFFlatHIP):
+            flag[0] = 1
+        dist.broadcast(flag, src=src, group=group)
+        if int(flag.item()):
+            index = broadcast_index(index, src=src, device=device, group=group)
+    lo, hi = shard_range(len(paths), rank, world)
+    mine = []
+    for p in paths[lo:hi]:
+        try:
+            mine.append((p, convert_one(p, index)))
+        except Exception:  # noqa  (modules.py:196-199: vc_single returns the traceback text instead of raising)
+            mine.append((p, traceback.format_exc()))
+    if not (on and world > 1 and gather):
+        return mine
+    parts = [None] * world if rank == src else None
+    dist.gather_object(mine, parts, dst=src, group=group)
+    if rank != src:
+        return mine
+    return [pr for part in parts for pr in part]

@@ -187,9 +187,13 @@ class FrontHIP(torch.nn.Module):
 
 
 def infer_hip(net_g, front: FrontHIP, phone, phone_lengths, sid, pitch=None, pitchf=None, skip_head=None,
-              return_length=None, return_length2=None, *, noise_zp=None, noise_dec=None):
+              return_length=None, return_length2=None, *, noise_zp=None, noise_dec=None, ragged: bool = False):
     """``SynthesizerTrnMsNSFsid.infer`` (synthesizers.py:160-203) with enc_p / flow / dec all on the HIP path.
-    Same arguments, same RNG consumption (randn_like(m_p), then the generator's two draws)."""
+    Same arguments, same RNG consumption (randn_like(m_p), then the generator's two draws).
+
+    ``ragged=True`` (not in the reference): the batch items are independent utterances of ``phone_lengths`` frames and each one
+    must come out as a SEPARATE call would produce it -- the generator is told the lengths (every conv zero-pads behind the item's
+    own end).  The reference's padded batch, ``ragged=False``, lets the rows behind a short item leak into its last frames."""
     g = net_g.emb_g(sid).unsqueeze(-1)
     T = phone.shape[1]
     if skip_head is not None and return_length is not None:
@@ -205,10 +209,13 @@ def infer_hip(net_g, front: FrontHIP, phone, phone_lengths, sid, pitch=None, pit
     # the reference's dispatch and its error (synthesizers.py:190-201)
     from .nsf import GeneratorHIP, NSFGeneratorHIP
 
+    rag = {"lengths": phone_lengths} if ragged else {}
+    if ragged and (skip_head is not None or return_length2 is not None):
+        raise ValueError("ragged batches and the realtime partial decode cannot be combined")
     if pitchf is not None and isinstance(net_g.dec, NSFGeneratorHIP):
-        return net_g.dec(z, pitchf, g=g, n_res=return_length2, **({"noise": noise_dec} if noise_dec is not None else {}))
+        return net_g.dec(z, pitchf, g=g, n_res=return_length2, **rag, **({"noise": noise_dec} if noise_dec is not None else {}))
     if isinstance(net_g.dec, GeneratorHIP):
-        return net_g.dec(z, g=g, n_res=return_length2)
+        return net_g.dec(z, g=g, n_res=return_length2, **rag)
     if not isinstance(net_g.dec, (NSFGeneratorHIP, GeneratorHIP)) and callable(net_g.dec):  # a foreign dec (tests' stand-ins)
         if pitchf is not None:
             return net_g.dec(z, pitchf, g=g, n_res=return_length2, **({"noise": noise_dec} if noise_dec is not None else {}))

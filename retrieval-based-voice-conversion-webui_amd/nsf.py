@@ -151,7 +151,7 @@ class _HipGenerator(torch.nn.Module):
         return self
 
     # -- forward -------------------------------------------------------------------------------
-    def _run(self, x, f0, g, n_res, noise, tap: Optional[str] = None):
+    def _run(self, x, f0, g, n_res, noise, tap: Optional[str] = None, lengths=None):
         if x.dim() != 3 or x.shape[1] != self.cfg["inter_channels"]:
             raise ValueError("x must be [B, %d, T], got %s" % (self.cfg["inter_channels"], tuple(x.shape)))
         B, _, T = x.shape
@@ -176,6 +176,18 @@ class _HipGenerator(torch.nn.Module):
             if gf.shape[1] != self.cfg.get("gin_channels", 0):
                 raise ValueError("g must carry %d channels" % self.cfg.get("gin_channels", 0))
         Te = T if n_res is None else int(n_res)
+        ln = None
+        if lengths is not None:
+            # a ragged batch: item b = a separate call of lengths[b] frames (include/rvcmi.h rvcmi_nsf_forward).  Host values are
+            # validated here; a device tensor is taken as is (no sync) -- the caller vouches for 1 <= lengths[b] <= T
+            if n_res is not None or tap is not None:
+                raise ValueError("lengths cannot be combined with n_res / debug taps")
+            lt = torch.as_tensor(lengths)
+            if tuple(lt.shape) != (B,):
+                raise ValueError("lengths must hold %d values" % B)
+            if lt.device.type != "cuda" and (int(lt.min()) < 1 or int(lt.max()) > T):
+                raise ValueError("lengths must lie in [1, %d]" % T)
+            ln = lt.to(dev, torch.int32).contiguous()
         self._ensure(B, max(T, Te))
         stream = torch.cuda.current_stream(dev).cuda_stream
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
@@ -184,7 +196,7 @@ class _HipGenerator(torch.nn.Module):
         with torch.cuda.device(dev):
             if tap is None:
                 out = torch.empty(B, 1, Te * self.upp, device=dev, dtype=torch.float32)
-                _lib.check(L.rvcmi_nsf_forward(self._handle, B, T, ptr(xf), ptr(f0f), ptr(gf), ptr(nf), nr, ptr(out),
+                _lib.check(L.rvcmi_nsf_forward(self._handle, B, T, ptr(ln), ptr(xf), ptr(f0f), ptr(gf), ptr(nf), nr, ptr(out),
                                                C.c_void_p(stream)))
                 return out.to(out_dtype)
             cap = B * max(self.cfg["upsample_initial_channel"] * Te, Te * self.upp * 256)
@@ -228,8 +240,10 @@ class NSFGeneratorHIP(_HipGenerator):
     """``net_g.dec`` for f0 models -- signature of rvc/layers/nsf.py:145."""
 
     def forward(self, x: torch.Tensor, f0: torch.Tensor, g: Optional[torch.Tensor] = None,
-                n_res: Optional[int] = None, *, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return self._run(x, f0, g, n_res, noise)
+                n_res: Optional[int] = None, *, noise: Optional[torch.Tensor] = None, lengths=None) -> torch.Tensor:
+        """``lengths`` (keyword, not in the reference's signature): [B] valid frames per item -- a ragged batch whose items come
+        out exactly as separate calls of those lengths would (segments of a long file, utterances of a folder, in one launch)."""
+        return self._run(x, f0, g, n_res, noise, lengths=lengths)
 
     def debug_tap(self, what: str, x, f0, g=None, n_res=None, noise=None) -> torch.Tensor:
         return self._run(x, f0, g, n_res, noise, tap=what)
@@ -247,8 +261,8 @@ class NSFGeneratorHIP(_HipGenerator):
 class GeneratorHIP(_HipGenerator):
     """``net_g.dec`` for no-f0 models -- signature of rvc/layers/generators.py:70."""
 
-    def forward(self, x: torch.Tensor, g: Optional[torch.Tensor] = None, n_res: Optional[int] = None) -> torch.Tensor:
-        return self._run(x, None, g, n_res, None)
+    def forward(self, x: torch.Tensor, g: Optional[torch.Tensor] = None, n_res: Optional[int] = None, *, lengths=None) -> torch.Tensor:
+        return self._run(x, None, g, n_res, None, lengths=lengths)
 
     def debug_tap(self, what: str, x, g=None, n_res=None) -> torch.Tensor:
         return self._run(x, None, g, n_res, None, tap=what)

@@ -52,9 +52,9 @@ def _is_hip_index(index) -> bool:
     return isinstance(index, IVFFlatHIP)
 
 
-def vc_device(self, model, net_g, sid, audio0, pitch, pitchf, times, index, index_rate, version, protect) -> torch.Tensor:
-    """``Pipeline.vc`` up to (not including) its final ``.data.cpu().float().numpy()``: returns the converted segment as a
-    1-D device tensor.  ``audio0``: numpy or tensor (16 kHz segment, padded); ``index``: an ``IVFFlatHIP`` or None."""
+def features_device(self, model, audio0, pitch, pitchf, times, index, index_rate, version, protect):
+    """``Pipeline.vc`` from HuBERT to the tensor handed to ``net_g.infer`` (pipeline.py:90-159): features on the GPU, retrieval
+    blend + x2 + protect mix in one launch.  Returns (feats [1, p_len, d], pitch [1, p_len] or None, pitchf or None, p_len)."""
     from time import time
 
     from . import glue
@@ -79,14 +79,89 @@ def vc_device(self, model, net_g, sid, audio0, pitch, pitchf, times, index, inde
     use_index = index is not None and index_rate != 0
     feats = glue.retrieve_blend_expand(feats, index if use_index else None, float(index_rate), pitchf if use_f0 else None,
                                        float(protect) if use_f0 else 0.5, p_len)
+    times[0] += time() - t0
+    return feats, (pitch if use_f0 else None), (pitchf if use_f0 else None), p_len
+
+
+def vc_device(self, model, net_g, sid, audio0, pitch, pitchf, times, index, index_rate, version, protect) -> torch.Tensor:
+    """``Pipeline.vc`` up to (not including) its final ``.data.cpu().float().numpy()``: returns the converted segment as a
+    1-D device tensor.  ``audio0``: numpy or tensor (16 kHz segment, padded); ``index``: an ``IVFFlatHIP`` or None."""
+    from time import time
+
+    dev = torch.device(self.device)
+    feats, pitch, pitchf, p_len = features_device(self, model, audio0, pitch, pitchf, times, index, index_rate, version, protect)
     t1 = time()
     plen_t = torch.tensor([p_len], device=dev).long()
     with torch.no_grad():
-        audio1 = net_g.infer(feats, plen_t, sid, pitch=pitch, pitchf=pitchf)[0, 0] if use_f0 else net_g.infer(feats, plen_t, sid)[0, 0]
-    t2 = time()
-    times[0] += t1 - t0
-    times[2] += t2 - t1
+        audio1 = net_g.infer(feats, plen_t, sid, pitch=pitch, pitchf=pitchf)[0, 0] if pitch is not None else net_g.infer(feats, plen_t, sid)[0, 0]
+    times[2] += time() - t1
     return audio1.data
+
+
+# ---- all segments of a file in ONE ``net_g.infer`` call ------------------------------------------------------------------------------
+# The reference converts the segments of a long input one ``vc`` call after the other (pipeline.py:301-343); they are independent
+# once f0 is known.  With the ragged-batch entry of the generator (include/rvcmi.h rvcmi_nsf_forward ``lengths``: every item computed
+# exactly as a separate call of its own length) they go through the front and the generator as one batch.  The noise of item b is
+# drawn as the b-th sequential call would have drawn it (randn(1, 192, T_b); rand(1, 1, 1); randn(1, T_b * upp, 1)), so a seeded run
+# consumes the generator exactly like the sequential pipeline.  Frames per call are bounded (``MAX_BATCH_FRAMES``) so that the workspace of
+# an hour-long file stays a few GB; segments beyond the bound go into further calls.
+MAX_BATCH_FRAMES = 32768
+
+
+def _ragged_capable(net_g) -> bool:
+    from .front import infer_hip
+
+    inf = getattr(net_g, "infer", None)
+    return bool(getattr(inf, "_rvcmi_ragged", False)) or getattr(inf, "func", None) is infer_hip
+
+
+def infer_segments(net_g, sid, items, times=None):
+    """``items``: list of (feats [1, T_b, d], pitch [1, T_b] or None, pitchf [1, T_b] or None, T_b) as ``features_device`` returns them.
+    -> list of 1-D device tensors (the waveform of every item, ``T_b * upp`` samples), from as few ``net_g.infer`` calls as
+    ``MAX_BATCH_FRAMES`` allows.  Bit-identical to one call per item with the kernel family pinned; the launcher's own per-shape choices
+    may differ between a batch and a single clip by operand rounding."""
+    from time import time
+
+    t0 = time()
+    outs = [None] * len(items)
+    dev = items[0][0].device
+    use_f0 = items[0][1] is not None
+    upp = int(getattr(net_g.dec, "upp"))
+    IC = int(net_g.dec.cfg["inter_channels"])
+    start = 0
+    while start < len(items):
+        end, frames = start, 0
+        while end < len(items) and (end == start or frames + items[end][3] <= MAX_BATCH_FRAMES):
+            frames += items[end][3]
+            end += 1
+        grp = items[start:end]
+        B, Tm = len(grp), max(it[3] for it in grp)
+        d = int(grp[0][0].shape[2])
+        phone = torch.zeros(B, Tm, d, device=dev, dtype=grp[0][0].dtype)
+        pitch = torch.ones(B, Tm, device=dev, dtype=torch.long) if use_f0 else None
+        pitchf = torch.zeros(B, Tm, device=dev, dtype=grp[0][2].dtype) if use_f0 else None
+        nzp = torch.zeros(B, IC, Tm, device=dev, dtype=grp[0][0].dtype)
+        ndec = torch.zeros(B, Tm * upp, device=dev, dtype=grp[0][2].dtype) if use_f0 else None
+        for b, (f, pt, pf, Tb) in enumerate(grp):
+            phone[b, :Tb] = f[0]
+            nzp[b, :, :Tb] = torch.randn(1, IC, Tb, device=dev, dtype=f.dtype)[0]       # randn_like(m_p)        synthesizers.py:182
+            if use_f0:
+                pitch[b, :Tb], pitchf[b, :Tb] = pt[0], pf[0]
+                torch.rand(1, 1, 1, device=dev)                                          # rand_ini               generators.py:164
+                ndec[b, :Tb * upp] = torch.randn(1, Tb * upp, 1, device=dev, dtype=pf.dtype)[0, :, 0]  # generators.py:192
+        lens = torch.tensor([it[3] for it in grp], device=dev).long()
+        sidb = sid.reshape(-1)[:1].expand(B).contiguous()
+        with torch.no_grad():
+            if use_f0:
+                o = net_g.infer(phone, lens, sidb, pitch=pitch, pitchf=pitchf, noise_zp=nzp, noise_dec=ndec, ragged=True)
+            else:
+                o = net_g.infer(phone, lens, sidb, noise_zp=nzp, ragged=True)
+        for b, it in enumerate(grp):
+            outs[start + b] = o[b, 0, : it[3] * upp].data
+        start = end
+    if times is not None:
+        times[2] += time() - t0
+    return outs
 
 
 def vc_hip(self, model, net_g, sid, audio0, pitch, pitchf, times, index, big_npy, index_rate, version, protect):
@@ -208,10 +283,17 @@ def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, fi
     times[1] += time() - t1
     w = self.window
     segs, s, t = [], 0, None
+    # segments of a long input: one net_g.infer call for all of them when the synthesizer is the HIP one (infer_segments above);
+    # RVCMI_PIPELINE_BATCH=0 (or a foreign net_g) keeps the reference's call-per-segment order
+    batch = _ragged_capable(net_g) and os.environ.get("RVCMI_PIPELINE_BATCH", "1") != "0" and len(opt_ts) > 0
+    items = []
 
     def convert(a0, lo, hi):
         pt = pitch[:, lo:hi] if if_f0 else None
         pf = pitchf[:, lo:hi] if if_f0 else None
+        if batch:
+            items.append(features_device(self, model, a0, pt, pf, times, index, index_rate, version, protect))
+            return
         o = vc_device(self, model, net_g, sid, a0, pt, pf, times, index, index_rate, version, protect)
         segs.append(o[self.t_pad_tgt: o.shape[0] - self.t_pad_tgt].float())
 
@@ -220,6 +302,8 @@ def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, fi
         convert(audio_pad[s: t + self.t_pad2 + w], s // w, (t + self.t_pad2) // w)
         s = t
     convert(audio_pad[t:], (t // w) if t is not None else 0, None)
+    if batch:
+        segs = [o[self.t_pad_tgt: o.shape[0] - self.t_pad_tgt].float() for o in infer_segments(net_g, sid, items, times)]
     audio_opt = torch.cat(segs).contiguous()
     if rms_mix_rate != 1:
         a16 = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32), device=dev)

@@ -120,6 +120,52 @@ def test_multi_rank_broadcast_and_sharding_gloo():
     mp.spawn(_gloo_worker, args=(2, _free_port(), 67), nprocs=2, join=True)
 
 
+def _convert_batch_worker(rank, world, port, n_files):
+    import torch.distributed as dist
+
+    from rvc_amd.dist import convert_batch, shard_range
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    paths = ["clip_%02d.wav" % i for i in range(n_files)]
+    seen = []
+
+    def fake_convert(path, index):  # stands for vc_single: (info, (sr, audio)); one file fails like a corrupt input would
+        seen.append(path)
+        if path == "clip_03.wav":
+            raise ValueError("cannot decode %s" % path)
+        return "Success", (48000, np.full(4, int(path[5:7]), np.int16)), rank, index
+
+    res = convert_batch(paths, fake_convert, index="added.index", gather=True, device=torch.device("cpu"))
+    lo, hi = shard_range(n_files, rank, world)
+    assert seen == paths[lo:hi], "rank %d converted %s" % (rank, seen)          # exactly its contiguous shard, in order
+    if rank == 0:
+        assert [p for p, _ in res] == paths                                      # all files, input order
+        for i, (p, r) in enumerate(res):
+            if p == "clip_03.wav":
+                assert isinstance(r, str) and "cannot decode clip_03.wav" in r    # the traceback text, not an exception
+                continue
+            owner = next(k for k in range(world) if shard_range(n_files, k, world)[0] <= i < shard_range(n_files, k, world)[1])
+            assert r[0] == "Success" and r[2] == owner and r[3] == "added.index" and int(r[1][1][0]) == i
+    else:
+        assert [p for p, _ in res] == paths[lo:hi]
+    own = convert_batch(paths, lambda p, ix: p.upper(), gather=False, device=torch.device("cpu"))
+    assert own == [(p, p.upper()) for p in paths[lo:hi]]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_convert_batch_shards_files_over_ranks_gloo():
+    """``rvc_amd.dist.convert_batch`` = vc_multi (infer/modules/vc/modules.py:201-266) over the ranks of a node: contiguous shards,
+    a per-file failure becomes that file's result, rank 0 ends up with every result in input order; world 1 = the plain loop."""
+    import torch.multiprocessing as mp
+
+    from rvc_amd.dist import convert_batch
+
+    assert convert_batch(["a", "b"], lambda p, ix: (p, ix), index=7) == [("a", ("a", 7)), ("b", ("b", 7))]
+    mp.spawn(_convert_batch_worker, args=(2, _free_port(), 7), nprocs=2, join=True)
+
+
 def _run_bench(args, env_extra=None, timeout=300):
     import subprocess
     import sys

@@ -410,6 +410,73 @@ def test_webui_defaults_through_the_rebound_pipeline(rvc_tree, gpu, tmp_path, mo
         rvc_amd.read_index(path, device="cpu")
 
 
+def test_segments_of_a_file_in_one_batched_call_equal_the_sequential_pipeline(rvc_tree, gpu, tmp_path, monkeypatch):
+    """``Pipeline.pipeline`` on the three-segment fixture with every segment in ONE ``net_g.infer`` call (ragged batch,
+    ``rvc_amd.pipeline.infer_segments``) against the call-per-segment order of the reference (RVCMI_PIPELINE_BATCH=0): bit-equal
+    waveforms with the ResBlock kernel family pinned, both within 1e-3 of what the REAL reference pipeline returned, and the same
+    number of draws from the seeded generator (the noise of item b is drawn as the b-th sequential call would draw it)."""
+    import rvc_amd
+
+    d, cfg, pl, pipe, net_g, audio, pitch, pitchf = _pipeline_fixture(gpu, rvc_tree, tmp_path)
+    noise = synth.infer_noise([int(x) for x in d["seg_frames"]], cfg.upp)
+    # un-shim: the fixture bound a per-call noise injector; this test needs the HIP partial itself plus a batch-aware injector
+    import functools
+
+    from rvc_amd.front import infer_hip
+
+    base = functools.partial(infer_hip, net_g, net_g._rvcmi_front)
+    calls = []
+
+    def infer_with_reference_noise(phone, lengths, sid, *a, **k):
+        B = phone.shape[0]
+        lens = [int(x) for x in lengths.tolist()]
+        calls.append(lens)
+        first = sum(len(c) for c in calls[:-1])
+        Tm = phone.shape[1]
+        nz = torch.zeros(B, 192, Tm)
+        nd = torch.zeros(B, Tm * cfg.upp)
+        for b, n in enumerate(lens):
+            z_b, d_b = noise[first + b]
+            assert z_b.shape[2] == n
+            nz[b, :, :n], nd[b, :n * cfg.upp] = z_b[0], d_b[0]
+        k["noise_zp"], k["noise_dec"] = nz.to(gpu), nd.to(gpu)
+        return base(phone, lengths, sid, *a, **k)
+
+    infer_with_reference_noise._rvcmi_ragged = True
+    net_g.infer = infer_with_reference_noise
+    for key, val in (("RB_STREAM", 0), ("NO_RB_SPLIT", 1)):  # same kernel family for B = 3 and B = 1
+        net_g.dec.set_option(key, val)
+    hub = synth.FakeHubert(768, int(d["seed"]))
+    args = (hub, net_g, int(d["sid"]), None, None, 0, (pitch, pitchf), "", 0.75, 2, 3, cfg.sr, 0, 1, "v2", float(d["protect"]))
+
+    def run():
+        a = list(args)
+        a[3], a[4] = audio.copy(), [0, 0, 0]
+        del calls[:]
+        return pipe.pipeline(*a)
+
+    monkeypatch.setenv("RVCMI_PIPELINE_BATCH", "1")
+    out_b = run()
+    assert calls == [[int(x) for x in d["seg_frames"]]], calls  # ONE call, three ragged items
+    monkeypatch.setenv("RVCMI_PIPELINE_BATCH", "0")
+    out_s = run()
+    assert calls == [[int(x)] for x in d["seg_frames"]]
+    assert np.array_equal(out_b, out_s), "batched vs sequential segments: max diff %g" % float(np.abs(out_b - out_s).max())
+    for o in (out_b, out_s):
+        assert rms(o / 32768.0, d["out"] / 32768.0) <= 1e-3
+    # without injected noise: the batched path draws item b's noise as the b-th sequential call would -- same seed, same waveform,
+    # same generator state afterwards
+    net_g.infer = base
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RVCMI_PIPELINE_BATCH", mode)
+        torch.manual_seed(5)
+        o = run()
+        res.append((o, torch.cuda.get_rng_state(gpu).clone()))
+    assert np.array_equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert not np.array_equal(res[0][0], out_b)  # (different noise than the reference's CPU draws)
+
+
 def test_front_at_benchmark_size_matches_the_reference_modules(gpu):
     """enc_p + z_p + flow^-1 at T = 1198 (global attention over the whole 10 s clip) against the REFERENCE modules' own output
     (fixture bigfront_v2_B1_T1198_z), not only against the oracle restatement."""

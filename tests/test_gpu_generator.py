@@ -434,3 +434,51 @@ def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu):
     pin(gen, RB_STREAM=0)  # and the tile kernels on the same input agree with it to operand rounding
     out0 = gen(zd, fd, gd, noise=nd).cpu()
     assert rms(out0, ref) <= 1e-3 and rms(out0, out) <= 5e-4
+
+
+# ---- ragged batches: rvcmi_nsf_forward `lengths` -----------------------------------------------------------------
+@pytest.mark.parametrize("family", ["tiles", "stream", "fp32"])
+def test_ragged_batch_items_equal_separate_calls_bit_for_bit(family, gpu):
+    """Four utterances of different lengths in ONE call with ``lengths``: every item must be BIT-equal to a separate call of its
+    own length (each layer zero-pads behind the item's own end; the padded batch of the reference would leak the rows behind a
+    short item into its tail) -- with the ResBlock kernel family pinned, as for the equal-length batches above -- and the rows
+    behind an item's end must be zero.  Lengths chosen to end inside a tile, on a tile edge, after a single frame's worth of rows;
+    the longest item doubles as the un-ragged reference (item 0 == the same call without ``lengths``)."""
+    import rvc_amd
+
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    w = synth.make_dec_weights(cfg, 99)
+    lens = [300, 137, 64, 1, 256] if family != "fp32" else [40, 17, 1]
+    B, T = len(lens), max(lens)
+    zs, fs, gs, ns = [], [], [], []
+    for b in range(B):
+        z, f0, g = synth.make_dec_inputs(cfg, 1, T, 500 + b)
+        zs.append(z), fs.append(torch.roll(f0, 11 * b, dims=1)), gs.append(g)
+        ns.append(nsf_oracle.reference_noise(1, T, cfg.upp, 900 + b))
+    Z, F, G, N = torch.cat(zs).to(gpu), torch.cat(fs).to(gpu), torch.cat(gs).to(gpu), torch.cat(ns).to(gpu)
+    for b, n in enumerate(lens):
+        Z[b, :, n:] = 0  # what z * x_mask hands the decoder
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp32" if family == "fp32" else "fp16", max_B=B, max_T=T)
+    if family != "fp32":
+        pin(gen, RB_STREAM=1 if family == "stream" else 0, NO_RB_SPLIT=1)
+    out = gen(Z, F, G, noise=N, lengths=torch.tensor(lens))
+    assert out.shape == (B, 1, T * cfg.upp) and torch.isfinite(out).all()
+    full = gen(Z, F, G, noise=N)
+    assert torch.equal(full[0], out[0])  # the longest item: nothing is masked
+    for b, n in enumerate(lens):
+        one = gen(Z[b:b + 1, :, :n].contiguous(), F[b:b + 1, :n].contiguous(), G[b:b + 1].contiguous(),
+                  noise=N[b:b + 1, :n * cfg.upp].contiguous())
+        assert torch.equal(one[0, 0], out[b, 0, :n * cfg.upp]), "item %d (%d frames) differs from its separate call: rms %.3e" % (
+            b, n, rms(one[0, 0].cpu(), out[b, 0, :n * cfg.upp].cpu()))
+        assert not out[b, 0, n * cfg.upp:].any()
+        if n < T and n > 8:  # ... and the padded batch (no lengths) is NOT that: its tail is contaminated -- the reason for the argument
+            assert not torch.equal(full[b, 0, :n * cfg.upp], out[b, 0, :n * cfg.upp])
+    # the oracle (= the reference's arithmetic) on one short item, run alone
+    with torch.no_grad():
+        n = lens[1]
+        ref = nsf_oracle.generator_forward(cfg, w, zs[1][:, :, :n], fs[1][:, :n], gs[1], ns[1][:, :n * cfg.upp])
+    assert rms(out[1:2, :, :n * cfg.upp].cpu(), ref) <= (2e-5 if family == "fp32" else 1e-3)
+    with pytest.raises(ValueError):
+        gen(Z, F, G, noise=N, lengths=torch.tensor([T + 1] + lens[1:]))
+    with pytest.raises(ValueError):
+        gen(Z, F, G, 10, noise=N, lengths=torch.tensor(lens))
