@@ -197,11 +197,10 @@ struct ConvArgs {
 // One thread per (q, co); co fastest so that weight reads and stores coalesce.
 static __global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
     const int b = blockIdx.z;
-    a.Lin = item_rows(a.lens, b, a.lmul_in, a.Lin);
-    a.Lq = item_rows(a.lens, b, a.lmul_q, a.Lq);
+    const int Linb = item_rows(a.lens, b, a.lmul_in, a.Lin), Lqb = item_rows(a.lens, b, a.lmul_q, a.Lq);
     const int ph = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)a.Lq * a.cout) return;
+    if (i >= (size_t)Lqb * a.cout) return;
     const int q = (int)(i / a.cout);
     const int co = (int)(i - (size_t)q * a.cout);
     const int in_off = a.nphase > 1 ? a.ph_in_off[ph] : a.in_off;
@@ -211,7 +210,7 @@ static __global__ void __launch_bounds__(256) k_conv_f32(ConvArgs a) {
     float acc = a.bias ? a.bias[co] : 0.f;
     for (int j = 0; j < ntaps; ++j) {
         const int r = q + in_off + j * a.dstep;
-        if (r < 0 || r >= a.Lin) continue;
+        if (r < 0 || r >= Linb) continue;
         const float* wj = W + (size_t)j * a.cin * a.cout + co;
         if (a.in_mode == IN_F32_CF) {
             for (int ci = 0; ci < a.cin; ++ci) acc = fmaf(in[(size_t)ci * a.cf_stride + r], wj[(size_t)ci * a.cout], acc);
@@ -510,6 +509,7 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
     constexpr int STRIDE = Tile<CIN>::STRIDE;
     constexpr int C8 = CIN / 8;
     const int tid = threadIdx.x;
+    const int Linb = item_rows(a.lens, b, a.lmul_in, a.Lin);  // ragged batch: this item's input rows
     if (a.in_mode == IN_F32_CF) {
         // channel-first input (the caller's [B][C][T], nsf.py:164): consecutive lanes walk TIME so that every load
         // instruction is one contiguous run per channel; 8 channels x SBC chunks in flight per thread (the row-major
@@ -523,7 +523,7 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
             for (int u = 0; u < SBC; ++u) {
                 const int idx = min(base + u * 256, total - 1);
                 const int c8 = idx / rows, r = idx - c8 * rows;
-                const int grc = min(max(g0 + r, 0), a.Lin - 1);
+                const int grc = min(max(g0 + r, 0), Linb - 1);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[u][e] = ip[(size_t)(c8 * 8 + e) * a.cf_stride + grc];
             }
@@ -533,7 +533,7 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
                 if (idx < total) {
                     const int c8 = idx / rows, r = idx - c8 * rows;
                     const int gr = g0 + r;
-                    const bool ok = gr >= 0 && gr < a.Lin;
+                    const bool ok = gr >= 0 && gr < Linb;
                     frag v;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = ok ? to_op<OpT>(f[u][e]) : (OpT)0.f;
@@ -557,7 +557,7 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
             for (int u = 0; u < SB; ++u) {
                 const int idx = min(base + u * 256, total - 1);
                 const int r = idx / C8, c8 = idx - r * C8;
-                const int grc = min(max(g0 + r, 0), a.Lin - 1);
+                const int grc = min(max(g0 + r, 0), Linb - 1);
                 if (raw) {
                     vr[u] = *(const frag*)((const OpT*)a.in + (size_t)b * a.in_bstride + (size_t)grc * CIN + c8 * 8);
                 } else {
@@ -572,7 +572,7 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
                 if (idx < total) {
                     const int r = idx / C8, c8 = idx - r * C8;
                     const int gr = g0 + r;
-                    const bool ok = gr >= 0 && gr < a.Lin;
+                    const bool ok = gr >= 0 && gr < Linb;
                     frag v;
                     if (raw) {
                         v = vr[u];
@@ -608,13 +608,13 @@ __device__ __forceinline__ void stage_tile(char* smem, const ConvArgs& a, int b,
             if (c8 * 8 < a.hs) {
                 const float* hp = (const float*)a.in + (size_t)b * a.in_bstride;
                 const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 lo = (base >= 0 && base + 4 <= a.Lin) ? *(const float4*)(hp + base) : z4;
-                const float4 hi = (base + 4 >= 0 && base + 8 <= a.Lin) ? *(const float4*)(hp + base + 4) : z4;
+                const float4 lo = (base >= 0 && base + 4 <= Linb) ? *(const float4*)(hp + base) : z4;
+                const float4 hi = (base + 4 >= 0 && base + 8 <= Linb) ? *(const float4*)(hp + base + 4) : z4;
                 const float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = to_op<OpT>(f[e]);
             }
-        } else if (gr >= 0 && gr < a.Lin) {
+        } else if (gr >= 0 && gr < Linb) {
             if (a.in_mode == IN_OP_RAW) {
                 v = *(const frag*)((const OpT*)a.in + (size_t)b * a.in_bstride + (size_t)gr * CIN + c8 * 8);
             } else if (a.in_mode == IN_F32_ACT) {
@@ -956,7 +956,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int b, char* s
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             const int q = q0 + tw0 + jt * 32 + (lane & 31);
-            if (q >= a.Lq) continue;
+            if (q >= item_rows(a.lens, b, a.lmul_q, a.Lq)) continue;
             const size_t orow = (size_t)q * a.out_mul + out_add;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -984,8 +984,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, int b, char* s
 template <typename OpT, int CIN, int MI, int NJ, int WCO>
 static __global__ void __launch_bounds__(256) k_conv_mfma(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    a.Lin = item_rows(a.lens, (int)blockIdx.z, a.lmul_in, a.Lin);
-    a.Lq = item_rows(a.lens, (int)blockIdx.z, a.lmul_q, a.Lq);
     conv_mfma_body<OpT, CIN, MI, NJ, WCO>(a, (int)blockIdx.z, smem);
 }
 
@@ -1002,10 +1000,7 @@ static __global__ void __launch_bounds__(256) k_conv_mfma_jobs(ConvJobs js) {
     const int j = (int)blockIdx.z % js.njobs, b = (int)blockIdx.z / js.njobs;
     // a weight ring of 4 groups (12 k-steps in flight): with one MFMA per k-step (NJ = 1) the default 2 groups cover 4 k-steps =
     // ~260 cycles, less than one L2 round trip, and the K loop ran at the latency of the weight loads (28 us per launch)
-    ConvArgs a = js.job[j];
-    a.Lin = item_rows(a.lens, b, a.lmul_in, a.Lin);
-    a.Lq = item_rows(a.lens, b, a.lmul_q, a.Lq);
-    conv_mfma_body<OpT, CIN, MI, NJ, WCO, 4, true>(a, b, smem);
+    conv_mfma_body<OpT, CIN, MI, NJ, WCO, 4, true>(js.job[j], b, smem);
 }
 
 // Branch-free helpers.  lrelu as max(x, slope*x) (0 < slope < 1); row masking by AND-ing the value bits so that
@@ -1140,8 +1135,8 @@ static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArg
     const RbJob& J = a.job[bjob];
     if (btile >= J.ntiles) return;
     const int b = blockIdx.z;
-    a.L = item_rows(a.lens, b, a.lmul, a.L);
-    if (btile * J.tt2 >= a.L) return;  // (ragged batch) a tile behind the item's end: block-uniform, before any barrier
+    const int Lb = item_rows(a.lens, b, a.lmul, a.L);  // (a local: writing to the by-value argument struct sends it to scratch)
+    if (btile * J.tt2 >= Lb) return;  // (ragged batch) a tile behind the item's end: block-uniform, before any barrier
     const int p2 = (J.k - 1) / 2;
     const int p1 = J.dil * (J.k - 1) / 2;
     const int t0 = btile * J.tt2;          // first output time of this tile
@@ -1185,11 +1180,11 @@ static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArg
             const int r = idx / C8;
             const int c8 = idx - r * C8;
             const int gr = x0 + r;
-            const int grc = min(max(gr, 0), a.L - 1);
+            const int grc = min(max(gr, 0), Lb - 1);
             const float4* p = (const float4*)(src + (size_t)grc * C + c8 * 8);
             lo[u] = p[0];
             hi[u] = p[1];
-            if (gr < 0 || gr >= a.L) {
+            if (gr < 0 || gr >= Lb) {
                 lo[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 hi[u] = lo[u];
             }
@@ -1240,12 +1235,12 @@ static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArg
 
     // ---- 3. h = lrelu(conv1 + b1) -> OpT, in place over X (zero outside the utterance: conv2 pads ITS input) ----
     {
-        const bool interior = h0 >= 0 && h0 + ROWS <= a.L;  // block-uniform: no masking needed
+        const bool interior = h0 >= 0 && h0 + ROWS <= Lb;  // block-uniform: no masking needed
         unsigned rowmask[NJ];
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             const int th = h0 + slab + jt * 32 + (lane & 31);
-            rowmask[jt] = (th >= 0 && th < a.L) ? 0xffffffffu : 0u;
+            rowmask[jt] = (th >= 0 && th < Lb) ? 0xffffffffu : 0u;
         }
         char* hw = smem + (size_t)(slab + (lane & 31)) * STRIDE + (ct0 * 32 + half4) * 2;
         if (interior) publish_operand<OpT, C, MI, NJ, STRIDE, false>(hw, acc, rowmask, ct0 * 32);
@@ -1267,8 +1262,8 @@ static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArg
     for (int jt = 0; jt < NJ; ++jt) {
         const int o = slab + jt * 32 + (lane & 31);
         const int t = t0 + o;
-        const bool valid = o < J.tt2 && t < a.L;
-        const int tc = min(t, a.L - 1);
+        const bool valid = o < J.tt2 && t < Lb;
+        const int tc = min(t, Lb - 1);
         f32x4 r[MI][4];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -1354,9 +1349,8 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.z;
     const int q0 = blockIdx.x * TQ;
-    a.Lin = item_rows(a.lens, b, a.lmul, a.Lin);
-    a.Lh = item_rows(a.lens, b, a.lhmul, a.Lh);
-    if (q0 >= a.Lin) return;  // (ragged batch) a tile behind the item's end: block-uniform, before the barrier
+    const int Linb = item_rows(a.lens, b, a.lmul, a.Lin), Lhb = item_rows(a.lens, b, a.lhmul, a.Lh);  // (locals: see k_rb_pair)
+    if (q0 >= Linb) return;  // (ragged batch) a tile behind the item's end: block-uniform, before the barrier
     const int g0 = q0 + a.lo;
     const size_t boff = (size_t)b * a.in_bstride;
 
@@ -1369,8 +1363,8 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
             const int r = idx / C8;
             const int c8 = idx - r * C8;
             const int gr = g0 + r;
-            const bool ok = gr >= 0 && gr < a.Lin;
-            const int grc = min(max(gr, 0), a.Lin - 1);  // clamped address: unconditional loads
+            const bool ok = gr >= 0 && gr < Linb;
+            const int grc = min(max(gr, 0), Linb - 1);  // clamped address: unconditional loads
             if (a.in_half) {  // fp16 streams: one 16-byte load per input
                 const size_t o = boff + (size_t)grc * CIN + c8 * 8;
                 unpack8_h(*(const uint4*)((const _Float16*)a.in_a + o), f[u]);
@@ -1434,7 +1428,7 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
         const int span = TQ * us + 16;
         for (int i = threadIdx.x; i < span; i += 256) {
             const long idx = hbase + i;
-            har16[i] = (idx >= 0 && idx < a.Lh) ? to_op<OpT>(hp[idx]) : (OpT)0.f;
+            har16[i] = (idx >= 0 && idx < Lhb) ? to_op<OpT>(hp[idx]) : (OpT)0.f;
         }
     }
     __syncthreads();
@@ -1485,8 +1479,8 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             const int q = q0 + tw0 + jt * 32 + (lane & 31);
-            const bool valid = q < a.Lin;
-            const int t = min(q, a.Lin - 1) * a.u + r;  // clamped: loads below stay unconditional
+            const bool valid = q < Linb;
+            const int t = min(q, Linb - 1) * a.u + r;  // clamped: loads below stay unconditional
             // noise conv for this output row: nv[mi][g] (4 channels each) += har[t*s - pad + j] * Wn[j][co]
             f32x4 nv[MI][4];
 #pragma unroll
@@ -1500,7 +1494,7 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
                 const int hb = t * a.ns - a.npad;
                 for (int j = 0; j < a.nk; ++j) {
                     const int hi = hb + j;
-                    const float hv = (hi >= 0 && hi < a.Lh) ? har[hi] : 0.f;
+                    const float hv = (hi >= 0 && hi < Lhb) ? har[hi] : 0.f;
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1589,9 +1583,9 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
     const RbFullJob& J = a.job[blockIdx.y];
     if ((int)blockIdx.x >= J.ntiles) return;
     const int b = blockIdx.z;
-    a.L = item_rows(a.lens, b, a.lmul, a.L);
+    const int Lb = item_rows(a.lens, b, a.lmul, a.L);  // (a local: see k_rb_pair)
     const int tg0 = blockIdx.x * J.tvalid - J.HL;  // global time of tile row 0
-    if (tg0 + J.HL >= a.L) return;  // (ragged batch) no valid row of this tile lies inside the item: block-uniform, before any barrier
+    if (tg0 + J.HL >= Lb) return;  // (ragged batch) no valid row of this tile lies inside the item: block-uniform, before any barrier
     const float* src = J.src + (size_t)b * a.bstride;
     float* dst = J.dst + (size_t)b * a.bstride;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1609,12 +1603,12 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
 
     // Rows of this lane's NJ column tiles that lie outside the utterance must read as zero in every operand tile
     // (each conv zero-pads ITS input).  Interior tiles (the vast majority) skip the masking altogether.
-    const bool interior = tg0 >= 0 && tg0 + R <= a.L;  // block-uniform
+    const bool interior = tg0 >= 0 && tg0 + R <= Lb;  // block-uniform
     unsigned rowmask[NJ];
 #pragma unroll
     for (int jt = 0; jt < NJ; ++jt) {
         const int tg = tg0 + slab + jt * 32 + (lane & 31);
-        rowmask[jt] = (tg >= 0 && tg < a.L) ? 0xffffffffu : 0u;
+        rowmask[jt] = (tg >= 0 && tg < Lb) ? 0xffffffffu : 0u;
     }
 
     // ---- load x into the accumulator layout ---------------------------------------------------------------
@@ -1639,9 +1633,9 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
             const int idx = (int)threadIdx.x + u * NT;
             const int row = idx / C4, c4 = idx - row * C4;
             const int tg = tg0 + row;
-            const int tgc = min(max(tg, 0), a.L - 1);
+            const int tgc = min(max(tg, 0), Lb - 1);
             v[u] = *(const float4*)(src + (size_t)tgc * C + c4 * 4);
-            if (tg < 0 || tg >= a.L) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows outside the utterance read as zero
+            if (tg < 0 || tg >= Lb) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows outside the utterance read as zero
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -1667,7 +1661,7 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
 #pragma unroll
         for (int jt = 0; jt < NJ; ++jt) {
             const int tg = tg0 + slab + jt * 32 + (lane & 31);
-            const int tgc = min(max(tg, 0), a.L - 1);
+            const int tgc = min(max(tg, 0), Lb - 1);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (mi * 32 + 8 * g < C) {  // folds to a constant once the loops are unrolled
@@ -1785,7 +1779,7 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
                             pack4_h(xacc[mi][jt][4 * g + 0], xacc[mi][jt][4 * g + 1], xacc[mi][jt][4 * g + 2], xacc[mi][jt][4 * g + 3]);
             __syncthreads();
             if (!(a.dbg & 16)) {
-                const int nrow = min(R - 2 * J.HL, a.L - (tg0 + J.HL));
+                const int nrow = min(R - 2 * J.HL, Lb - (tg0 + J.HL));
                 const int tot = nrow * C8;
                 for (int i = threadIdx.x; i < tot; i += NT) {
                     const int r = i / C8, c8 = i - r * C8;
@@ -1800,7 +1794,7 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
                 for (int jt = 0; jt < NJ; ++jt) {
                     const int row = slab + jt * 32 + (lane & 31);
                     const int tg = tg0 + row;
-                    if (row >= J.HL && row < R - J.HL && tg < a.L) {
+                    if (row >= J.HL && row < R - J.HL && tg < Lb) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
                             if (mi * 32 + 8 * g < C)
@@ -1822,7 +1816,7 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
                 }
         __syncthreads();
         if (!(a.dbg & 16)) {
-            const int nrow = min(R - 2 * J.HL, a.L - (tg0 + J.HL));  // valid rows of this tile that lie inside the utterance
+            const int nrow = min(R - 2 * J.HL, Lb - (tg0 + J.HL));  // valid rows of this tile that lie inside the utterance
             const int tot = nrow * C4;
             for (int i = threadIdx.x; i < tot; i += NT) {
                 const int r = i / C4, c4 = i - r * C4;
@@ -1837,7 +1831,7 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
             for (int jt = 0; jt < NJ; ++jt) {
                 const int row = slab + jt * 32 + (lane & 31);
                 const int tg = tg0 + row;
-                if (row >= J.HL && row < R - J.HL && tg < a.L) {
+                if (row >= J.HL && row < R - J.HL && tg < Lb) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if (mi * 32 + 8 * g < C) {  // folds to a constant once the loops are unrolled
