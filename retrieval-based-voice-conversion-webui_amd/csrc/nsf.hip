@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -532,6 +532,14 @@ static bool y_f16(const rvcmi_nsf* h) {
            !h->opt.on("RS_V2X");
 }
 
+// Option X0_F16 (default 1, only together with Y_F16): at the stages whose ResBlocks run on k_rb_full (C <= 64: the two HBM-heaviest
+// stages of every shipped config) the ups output X0 -- read three times, once per ResBlock -- is stored as fp16 too.  Unlike the Y
+// streams this rounds the START of the fp32 residual stream (relative 2^-11 once per stage; the stream itself stays fp32 inside the
+// kernels): +1.1e-4 RMS on the full-clip golden, measured on the oracle and gated by the same 5e-4 test.  0 = fp32 X0.
+static bool x0_f16(const rvcmi_nsf* h, int C, size_t maxnd) {
+    return y_f16(h) && h->opt.geti("X0_F16", 1) != 0 && C <= 64 && maxnd <= 3 && !h->opt.on("NO_RBFULL");
+}
+
 // Whole resblocks of a stage on the streaming kernel (ND = 3).  Fills src[j] with the output streams on success.
 static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int L, int B, int nk, const float** src, hipStream_t st,
                                const int* lens, int lm) {
@@ -816,6 +824,9 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
         L = Lin * s.u;
         const int C = s.cout;
         const int nk = (int)s.rb.size();
+        size_t maxnd0 = 0;
+        for (int j = 0; j < nk; ++j) maxnd0 = std::max(maxnd0, s.rb[j].size());
+        const bool x0h = op != RVCMI_OPERAND_F32 && x0_f16(h, C, maxnd0);  // X0 of this stage is fp16 (consumer: k_rb_full)
         char nm[48];
         if (op == RVCMI_OPERAND_F32) {
             {  // x = ups[i](leaky_relu(x, 0.1))                                nsf.py:171-172
@@ -878,6 +889,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             ua.lo = lo;
             ua.bias = U.bias.as<float>();
             ua.out = h->X0.as<float>();
+            ua.out_half = x0h ? 1 : 0;
             ua.out_bstride = L * C;
             if (c.use_f0 && s.nz_mfma) {  // noise_convs[i](har) as a 2-tap MFMA conv over frames -> NZ, added in k_ups' epilogue
                 ConvArgs na = base_args();
@@ -933,7 +945,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             ua.vpw = vpw;
             snprintf(nm, sizeof(nm), "ups_c%d", s.cin);
             const double flops = U.flops_per_pos * (double)Lin * B + 2.0 * s.nk * (double)L * C * B;
-            const double bytes = (double)B * Lin * Cprev * (yhalf ? 2 : 4) * (y[1] ? (y[2] ? 3 : 2) : 1) + (double)B * L * C * 4;
+            const double bytes = (double)B * Lin * Cprev * (yhalf ? 2 : 4) * (y[1] ? (y[2] ? 3 : 2) : 1) + (double)B * L * C * (x0h ? 2 : 4);
             h->prof.launch(nm, flops, bytes, st, [&] {
                 if (op == RVCMI_OPERAND_BF16) launch_ups_t<__bf16>(ua, wv, nj, B, st);
                 else launch_ups_t<_Float16>(ua, wv, nj, B, st);
@@ -941,7 +953,14 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             HIP_CHECK(hipGetLastError());
         }
         snprintf(nm, sizeof(nm), "up%d", i);
-        if (want(nm)) return copy_tap_cl(h, h->X0.as<float>(), B, (int)L, C, tr, st);
+        if (want(nm)) {
+            if (x0h) {  // widen the fp16 X0 for the tap
+                const size_t n = (size_t)B * L * C;
+                hipLaunchKernelGGL(k_h2f, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const _Float16*)h->X0.p, h->Ya[0].as<float>(), n);
+                return copy_tap_cl(h, h->Ya[0].as<float>(), B, (int)L, C, tr, st);
+            }
+            return copy_tap_cl(h, h->X0.as<float>(), B, (int)L, C, tr, st);
+        }
 
         // resblocks[i*nk + j](x), j < nk                                         nsf.py:175-185
         size_t maxnd = 0;
@@ -1049,6 +1068,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             ra.dbg = dbg_flags(h);
             stage_half = y_f16(h);
             ra.yh = stage_half ? 1 : 0;
+            ra.xh = x0h ? 1 : 0;
             const int R = rbf_rows(C);
             int order[RVCMI_MAX_RB];
             for (int j = 0; j < nk; ++j) order[j] = j;
@@ -1084,7 +1104,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
                 if (J.tvalid < R / 4) RVCMI_FAIL(RVCMI_ERR_INVALID, "resblock halo too large for the fused kernel");
                 J.ntiles = (int)((L + J.tvalid - 1) / J.tvalid);
                 max_tiles = std::max(max_tiles, J.ntiles);
-                bytes += (double)B * L * C * (stage_half ? 6 : 8);
+                bytes += (double)B * L * C * ((stage_half ? 2 : 4) + (x0h ? 2 : 4));
                 src[j] = J.dst;
             }
             const size_t nblk = (size_t)max_tiles * nk * B;

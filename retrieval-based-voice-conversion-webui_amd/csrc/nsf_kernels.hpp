@@ -430,6 +430,10 @@ static __global__ void __launch_bounds__(256) k_sum3h(const _Float16* __restrict
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = ((float)a[i] + (b ? (float)b[i] : 0.f)) + (c ? (float)c[i] : 0.f);
 }
+static __global__ void __launch_bounds__(256) k_h2f(const _Float16* __restrict__ a, float* __restrict__ y, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = (float)a[i];
+}
 // y = (a + b) + c   (debug tap of the stage sum only)
 static __global__ void __launch_bounds__(256) k_sum3(const float* __restrict__ a, const float* __restrict__ b,
                                               const float* __restrict__ c, float* __restrict__ y, size_t n) {
@@ -1321,6 +1325,7 @@ struct UpsArgs {
     int tile_rows;
     const float* bias;
     float* out;
+    int out_half;  // 1: X0 is written as fp16 (pack4_h; option X0_F16, stages whose ResBlocks run on k_rb_full), same element layout
     long out_bstride;
     const float* addend;  // optional [B][Lin*u][cout] fp32 added in the epilogue (noise conv done by the MFMA conv)
     const float* har;  // [B][Lh] or nullptr (no-f0 generator / addend in use)
@@ -1338,7 +1343,10 @@ struct UpsArgs {
 };
 
 template <typename OpT, int CIN, int MI, int WV, int NJ = 4>
-static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks per CU: one block stages / stores while the other multiplies
+#ifndef UPS_OCC
+#define UPS_OCC 2
+#endif
+static __global__ void __launch_bounds__(256, UPS_OCC) k_ups(UpsArgs a) {  // 2 blocks per CU: one block stages / stores while the other multiplies
     using TL = Tile<CIN>;
     using frag = typename Op<OpT>::frag;
     constexpr int STRIDE = TL::STRIDE;
@@ -1354,6 +1362,28 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
     const int g0 = q0 + a.lo;
     const size_t boff = (size_t)b * a.in_bstride;
 
+    // nz_k1: the excitation samples this block's output rows can touch -- requested FIRST (two per thread cover the usual spans),
+    // together with this wave's bias vectors: with the tile's own loads they are ONE memory round trip instead of three dependent
+    // ones (a block is ~4 round trips long; measured 20 us per 64-row tile at 3 blocks per CU)
+    const int us = a.u * a.ns;
+    const long hbase = (long)q0 * us - a.npad;
+    const int hspan = TQ * us + 16;
+    float hpre[2] = {0.f, 0.f};
+#ifdef UPS_NO_PRELOAD  // dev A/B: the round-3 order (har and bias loads behind the tile staging / the K loop)
+    constexpr bool UPS_PRE = false;
+#else
+    constexpr bool UPS_PRE = true;
+#endif
+    if (a.nz_k1 && UPS_PRE) {
+        const float* hp = a.har + (size_t)b * a.Lh_stride;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long idx = hbase + (int)threadIdx.x + 256 * j;
+            const long idc = min(max(idx, 0L), (long)Lhb - 1);
+            const float v = hp[idc];
+            hpre[j] = (idx >= 0 && idx < Lhb && (int)threadIdx.x + 256 * j < hspan) ? v : 0.f;
+        }
+    }
     const int total = a.tile_rows * C8;
     for (int base = threadIdx.x; base < total; base += SB * 256) {
         float f[SB][8];
@@ -1421,12 +1451,14 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
     }
     // nz_k1: fp16 copy of the excitation samples every output row of this block can touch (zero outside the signal)
     OpT* har16 = (OpT*)(smem + (size_t)a.tile_rows * STRIDE);
-    const int us = a.u * a.ns;
     if (a.nz_k1) {
-        const long hbase = (long)q0 * us - a.npad;
         const float* hp = a.har + (size_t)b * a.Lh_stride;
-        const int span = TQ * us + 16;
-        for (int i = threadIdx.x; i < span; i += 256) {
+        if (UPS_PRE) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if ((int)threadIdx.x + 256 * j < hspan) har16[threadIdx.x + 256 * j] = to_op<OpT>(hpre[j]);
+        }
+        for (int i = threadIdx.x + (UPS_PRE ? 512 : 0); i < hspan; i += 256) {  // (spans beyond 512 samples: large noise strides)
             const long idx = hbase + i;
             har16[i] = (idx >= 0 && idx < Lhb) ? to_op<OpT>(hp[idx]) : (OpT)0.f;
         }
@@ -1454,6 +1486,8 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
         const OpT* wlane = (const OpT*)a.w + a.ph_w_off[r] + (size_t)ct0 * a.ct_stride + lane * 8;
+        // (requesting the epilogue's bias vectors here, before the K loop, costs 78 registers = one resident block per CU:
+        //  ups_c128 65 -> 78 us on one lease, ABAB.  Occupancy, not the number of dependent round trips, is what this kernel lives on.)
 // (a 4-group weight ring for the one-tile waves: 148 -> 200 VGPRs, 3 -> 2 blocks per CU; C_in 256 unchanged, 128 slower)
         if (!(a.dbg & 2)) conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.ct_stride, a.ntaps_p, a.ph_in_off[r] - a.lo, -1);
         if (a.nz_k1) {  // + noise_convs[i](har): one k-step, B = the row's 16-sample window (nsf.py:173-174)
@@ -1517,7 +1551,8 @@ static __global__ void __launch_bounds__(256, 2) k_ups(UpsArgs a) {  // 2 blocks
                         if (har) v += nv[mi][g] + *(const f32x4*)(a.bn + co);  // x + (noise_conv + its bias), nsf.py:173-174
                         else if (addend) v += nv[mi][g];                       // the addend already carries the noise bias
                         else if (a.nz_k1) v += *(const f32x4*)(a.bn + co);
-                        *(f32x4*)(out + (size_t)t * a.cout + co) = v;
+                        if (a.out_half) *(uint2*)((_Float16*)a.out + (size_t)b * a.out_bstride + (size_t)t * a.cout + co) = pack4_h(v[0], v[1], v[2], v[3]);
+                        else *(f32x4*)(out + (size_t)t * a.cout + co) = v;
                     }
             }
         }
@@ -1558,6 +1593,7 @@ struct RbFullArgs {
     long bstride;
     int dbg;
     int yh;  // 1: dst streams are fp16 (pack4_h), same element layout
+    int xh;  // 1: src (X0, the start of the fp32 residual stream) is fp16 (option X0_F16)
     unsigned long long* ts;  // dbg & 32: per-wave s_memtime stamps [block][wave][16]
 };
 
@@ -1625,7 +1661,63 @@ static __global__ void __launch_bounds__(64 * NWV, OCC) k_rb_full(RbFullArgs a) 
     static_assert(!TIO || (size_t)R * TS <= (size_t)(XROWS + HROWS) * STRIDE, "transposition tile must fit the X | H regions");
     static_assert(!TIO || (R * C4) % NT == 0, "whole batches of row chunks");
     f32x16 xacc[MI][NJ];
-    if constexpr (TIO) {
+    if (a.xh) {  // fp16 X0: half the bytes through HBM and through the LDS transposition
+        const _Float16* srch = (const _Float16*)J.src + (size_t)b * a.bstride;
+        if constexpr (TIO) {
+            constexpr int C8 = C / 8, TSH = C * 2 + 16;
+            static_assert((R * C8) % NT == 0, "whole batches of fp16 row chunks");
+            constexpr int PERH = R * C8 / NT;
+            uint4 v[PERH];
+#pragma unroll
+            for (int u = 0; u < PERH; ++u) {
+                const int idx = (int)threadIdx.x + u * NT;
+                const int row = idx / C8, c8 = idx - row * C8;
+                const int tg = tg0 + row;
+                const int tgc = min(max(tg, 0), Lb - 1);
+                v[u] = *(const uint4*)(srch + (size_t)tgc * C + c8 * 8);
+                if (tg < 0 || tg >= Lb) v[u] = make_uint4(0u, 0u, 0u, 0u);  // rows outside the utterance read as zero
+            }
+#pragma unroll
+            for (int u = 0; u < PERH; ++u) {
+                const int idx = (int)threadIdx.x + u * NT;
+                const int row = idx / C8, c8 = idx - row * C8;
+                *(uint4*)(smem + (size_t)row * TSH + c8 * 16) = v[u];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        using h4 = __attribute__((ext_vector_type(4))) _Float16;
+                        const h4 q = *(const h4*)(smem + (size_t)(slab + jt * 32 + (lane & 31)) * TSH + (mi * 32 + 8 * g + half4) * 2);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] = (float)q[e];
+                    }
+            __syncthreads();  // the guard zeroing and the first publish below overwrite the tile
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) {
+                    const int tg = tg0 + slab + jt * 32 + (lane & 31);
+                    const int tgc = min(max(tg, 0), Lb - 1);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (mi * 32 + 8 * g < C) {
+                            using h4 = __attribute__((ext_vector_type(4))) _Float16;
+                            const h4 q = *(const h4*)(srch + (size_t)tgc * C + mi * 32 + 8 * g + half4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] = mask_bits((float)q[e], rowmask[jt]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) xacc[mi][jt][4 * g + e] = 0.f;
+                        }
+                    }
+                }
+        }
+    } else if constexpr (TIO) {
         constexpr int PER = R * C4 / NT;
         float4 v[PER];
 #pragma unroll

@@ -440,7 +440,8 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
         // ---- store the rows of this strip ------------------------------------------------------------------------------
         if constexpr (KL == 2) {
             const int wout = r0 - 32 * ND + step * R;
-            issue_loads(r0 + (step + 1) * R);  // the next step's rows: in flight under the store phase (zeros past the end)
+            if (step + 1 < nsteps) issue_loads(r0 + (step + 1) * R);  // the next step's rows: in flight under the store phase (not past the strip's last step:
+                                                                       // those rows belong to the next strip's block, 1.5x the algorithmic traffic in round 3)
             if (yh) {
                 using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
                 using lds_u2 = __attribute__((address_space(3))) u32x2_t;

@@ -1,0 +1,28 @@
+#!/bin/bash
+# One GPU session that refreshes every artefact of a round: tools/gpu_round.sh r04   (run through gpurun; ~10 min)
+TAG=${1:-r04}
+mkdir -p gpurun_out
+python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/${TAG}_pytest_gpu_tail.txt; cat gpurun_out/${TAG}_pytest_gpu_tail.txt
+python __graft_entry__.py smoke 2>&1 | tail -1
+python bench.py > gpurun_out/${TAG}_bench_b1_T1198.json 2> gpurun_out/${TAG}_bench_b1.err; tail -1 gpurun_out/${TAG}_bench_b1.err
+python bench.py --batch 64 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/${TAG}_bench_b64_T1198.json 2>/dev/null
+python bench.py --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/${TAG}_bench_b16_T1198.json 2>/dev/null
+python bench.py --whole --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/${TAG}_bench_whole_b16_T1198.json 2>/dev/null
+python bench.py --stream > gpurun_out/${TAG}_bench_stream_v1_40k.json 2>/dev/null
+bash tools/profile.sh $TAG > gpurun_out/prof_${TAG}.log 2>&1; tail -1 gpurun_out/prof_${TAG}.log
+python - $TAG <<'PY'
+import json, sys
+tag = sys.argv[1]
+for f in ("bench_b1_T1198", "bench_b64_T1198", "bench_b16_T1198", "bench_whole_b16_T1198"):
+    try:
+        d = json.load(open("gpurun_out/%s_%s.json" % (tag, f))); r = d.get("roofline") or {}
+        print(f, round(d["ms_per_step"], 4), round(d["value"], 1), d.get("repeats", {}).get("ms_per_step_median"), r.get("frac"), r.get("traffic"))
+    except Exception as e:
+        print(f, "FAILED", e)
+try:
+    d = json.load(open("gpurun_out/%s_bench_stream_v1_40k.json" % tag)); print("stream", d["hot_path"], d["whole_chunk"]["p50_ms"], d["whole_chunk"]["p99_ms"])
+    d = json.load(open("gpurun_out/%s_bench_b1_T1198.json" % tag))
+    print("whole", d["whole_infer"]["ms_per_step"], d["whole_infer"]["value"], "torch", d["gpu_torch_baseline"]["fp16"]["ms_per_clip"], d["gpu_torch_baseline"]["fp32"]["ms_per_clip"], "cpu", d["cpu_baseline"]["value"])
+except Exception as e:
+    print("FAILED", e)
+PY

@@ -47,6 +47,13 @@ import re
 
 
 def logical(name):
+    for kn, lg in (("k_lm_gemm", "ivf_lm_gemm"), ("k_lm_select", "ivf_lm_select"), ("k_lm_plan", "ivf_lm_plan"), ("k_coarse_gemm_ks", "ivf_coarse_gemm"),
+                   ("k_coarse_pick", "ivf_coarse_pick"), ("k_scan_v", "ivf_scan_query_major"), ("k_post", "conv_post")):
+        if kn in name:
+            return lg
+    m = re.search(r"k_upsI\w+?Li(\d+)E", name)
+    if m:
+        return "ups_c%s" % m.group(1)
     m = re.search(r"k_rb_(pair|full|stream)I\w+?Li(\d+)E", name)
     if not m:
         return None
