@@ -19,13 +19,15 @@
 
 namespace rvcmi {
 
-struct LmItem {
+struct LmItem {  // 16 bytes: one store / one load
     int list;  // probed list
     int q0;    // first sorted query position of the tile
-    int nq;    // queries in the tile (1..32)
     int r0;    // first row of the tile inside the list
-    int nr;    // rows in the tile (1..32)
+    int nqr;   // queries in the tile (1..32) | rows in the tile (1..32) << 8
+    __host__ __device__ int nq() const { return nqr & 0xff; }
+    __host__ __device__ int nr() const { return nqr >> 8; }
 };
+static_assert(sizeof(LmItem) == 16, "LmItem is stored and loaded as one 16-byte word");
 
 constexpr int LM_MAXL = 16384;     // lists the one-block planner counts in LDS (2 x 4 B each)
 constexpr int LM_MAXPITCH = 2048;  // longest list the selector stages in LDS (4 waves x 8 KB)
@@ -64,6 +66,13 @@ __global__ void __launch_bounds__(1024) k_lm_plan(const int64_t* __restrict__ as
     int* cnt = (int*)smem_raw;
     int* off = cnt + (nlist + 1);
     const int n1 = nlist + 1;  // bucket nlist: queries without a list (assign < 0)
+#ifdef LM_PLAN_STAMPS
+    unsigned long long pst[8]; int psn = 0;
+#define LM_PST() do { __syncthreads(); if (psn < 8) pst[psn++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LM_PST() do {} while (0)
+#endif
+    LM_PST();
     const int per = (n1 + 1023) / 1024;
     const int b = min(n1, (int)threadIdx.x * per), e = min(n1, b + per);
     // the lengths of this thread's lists, requested before anything else (their latency runs under the counting pass)
@@ -80,6 +89,7 @@ __global__ void __launch_bounds__(1024) k_lm_plan(const int64_t* __restrict__ as
         atomicAdd(&cnt[(l < 0 || l >= nlist) ? nlist : (int)l], 1);
     }
     __syncthreads();
+    LM_PST();  // 1: counted
     // exclusive scan of cnt -> off (thread t owns the contiguous chunk [b, e))
     auto block_scan = [&](int s) {  // exclusive prefix of s over the 1024 threads: wave scans + the 16 wave totals (two barriers)
         const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -105,6 +115,7 @@ __global__ void __launch_bounds__(1024) k_lm_plan(const int64_t* __restrict__ as
         }
     }
     __syncthreads();
+    LM_PST();  // 2: scanned
     for (int i = threadIdx.x; i < nq; i += 1024) {  // scatter (order inside a list: whatever the atomics give; results do not depend on it)
         const int64_t l = assign[i];
         const bool has = l >= 0 && l < nlist;
@@ -112,24 +123,47 @@ __global__ void __launch_bounds__(1024) k_lm_plan(const int64_t* __restrict__ as
         qinfo[atomicAdd(&off[has ? (int)l : nlist], 1)] = LmQuery{i, (int)(le - lb), (long long)lb};
     }
     __syncthreads();  // off[l] is now the END of list l's range in the sorted order
-    // work items: list l with cnt queries and len rows -> ceil(cnt / 32) x ceil(len / 32) tiles
+    LM_PST();  // 3: scattered
+    // work items: list l with cnt queries and len rows -> ceil(cnt / 32) x ceil(len / 32) tiles.  A thread knows the item range of each
+    // of its lists; the EMISSION is wave-cooperative -- for every list with items (ballot over the wave's lanes) its parameters are
+    // broadcast from the owning lane and the 64 lanes write the items side by side.  (One thread writing its lists' items alone was 13k of
+    // the planner's 20k cycles for one clip -- 39 serial single-lane stores for the longest list -- and 3.2M cycles for 64 clips.)
+    int nt[LM_PER], st0[LM_PER];
     int s = 0;
 #pragma unroll
-    for (int j = 0; j < LM_PER; ++j)
-        if (b + j < e && b + j < nlist) s += ((cnt[b + j] + 31) / 32) * ((lenr[j] + 31) / 32);
+    for (int j = 0; j < LM_PER; ++j) {
+        nt[j] = (b + j < e && b + j < nlist && lenr[j] > 0) ? ((cnt[b + j] + 31) / 32) * ((lenr[j] + 31) / 32) : 0;
+        s += nt[j];
+    }
     int run = block_scan(s);
 #pragma unroll
     for (int j = 0; j < LM_PER; ++j) {
-        const int l = b + j;
-        if (l >= e || l >= nlist) continue;
-        const int c = cnt[l], q0 = off[l] - c, len = lenr[j];
-        if (c == 0 || len == 0) continue;
-        for (int qt = 0; qt < (c + 31) / 32; ++qt)
-            for (int rt = 0; rt < (len + 31) / 32; ++rt) {
-                if (run < max_items) items[run] = LmItem{l, q0 + qt * 32, min(32, c - qt * 32), rt * 32, min(32, len - rt * 32)};
-                ++run;
-            }
+        st0[j] = run;
+        run += nt[j];
     }
+    const int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < LM_PER; ++j) {
+        if (j >= per) break;  // (block-uniform)
+        const int lj = min(b + j, nlist - 1);
+        const int cj = cnt[lj], q0j = off[lj] - cj;
+        unsigned long long mask = __ballot(nt[j] > 0);
+        while (mask) {
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int l = __builtin_amdgcn_readlane(lj, k), c = __builtin_amdgcn_readlane(cj, k), q0 = __builtin_amdgcn_readlane(q0j, k);
+            const int len = __builtin_amdgcn_readlane(lenr[j], k), n = __builtin_amdgcn_readlane(nt[j], k), base = __builtin_amdgcn_readlane(st0[j], k);
+            const int nrt = (len + 31) / 32;
+            for (int i = ln; i < n; i += 64) {
+                const int qt = i / nrt, rt = i - qt * nrt;
+                if (base + i < max_items) items[base + i] = LmItem{l, q0 + qt * 32, rt * 32, min(32, c - qt * 32) | (min(32, len - rt * 32) << 8)};
+            }
+        }
+    }
+    LM_PST();  // 4: items
+#ifdef LM_PLAN_STAMPS
+    if (threadIdx.x == 0) printf("[lm plan] nq %d nlist %d: count %llu scan %llu scatter %llu items %llu\n", nq, nlist, pst[1] - pst[0], pst[2] - pst[1], pst[3] - pst[2], pst[4] - pst[3]);
+#endif
     if (threadIdx.x == 1023) *nitems = min(run, max_items);  // (the host sizes `items` for the worst case: never truncated)
 }
 
@@ -146,6 +180,7 @@ __global__ void __launch_bounds__(256) k_lm_gemm(const float* q, const LmQuery* 
     for (int it = blockIdx.x; it < n; it += gridDim.x) {
         const LmItem I = items[it];
         const int64_t rbase = list_off[I.list] + I.r0;
+        const int Inq = I.nq(), Inr = I.nr();
         float* st = St[wave];
         f32x16 acc;
 #pragma unroll
@@ -155,7 +190,7 @@ __global__ void __launch_bounds__(256) k_lm_gemm(const float* q, const LmQuery* 
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int row = (lane + s * 64) >> 3;
-            src[s] = row < 32 ? q + (int64_t)qinfo[I.q0 + min(row, I.nq - 1)].qi * d : vecs + (rbase + min(row - 32, I.nr - 1)) * d;
+            src[s] = row < 32 ? q + (int64_t)qinfo[I.q0 + min(row, Inq - 1)].qi * d : vecs + (rbase + min(row - 32, Inr - 1)) * d;
         }
         if (d == 768) ks_wave_tile<6, 4>(acc, src, st, wave, lane);       // (ivf.hip: deep prefetch ring over this wave's K chunks)
         else if (d == 256) ks_wave_tile<2, 2>(acc, src, st, wave, lane);
@@ -184,13 +219,13 @@ __global__ void __launch_bounds__(256) k_lm_gemm(const float* q, const LmQuery* 
         __syncthreads();
         if (wave == 0) {
             const int c = lane & 31;
-            if (c < I.nr) {
+            if (c < Inr) {
                 const float rnc = rn[rbase + c];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float dot = ((acc[r] + Red[0][r * 64 + lane]) + Red[1][r * 64 + lane]) + Red[2][r * 64 + lane];
                     const int qr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (qr < I.nq) S[(int64_t)(I.q0 + qr) * pitch + I.r0 + c] = rnc - 2.f * dot;
+                    if (qr < Inq) S[(int64_t)(I.q0 + qr) * pitch + I.r0 + c] = rnc - 2.f * dot;
                 }
             }
         }
