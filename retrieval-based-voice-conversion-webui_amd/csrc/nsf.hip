@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -420,12 +420,25 @@ static void set_lds_rb() {
 }
 
 template <typename OpT, int CIN, int MI, int WV>
-static void launch_ups_inst(const UpsArgs& a, int nj, int B, hipStream_t st) {
+static void launch_ups_inst(UpsArgs a, int nj, int B, hipStream_t st) {
     const int TQ = 32 * nj * (4 / WV);
-    const size_t smem = (size_t)a.tile_rows * Tile<CIN>::STRIDE + (a.nz_k1 ? (size_t)(TQ * a.u * a.ns + 16) * 2 : 0);
+    size_t smem = (size_t)a.tile_rows * Tile<CIN>::STRIDE + (a.nz_k1 ? (size_t)(TQ * a.u * a.ns + 16) * 2 : 0);
     if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "upsampler LDS tile too large (%zu B)", smem);
     const int per_block = WV * a.vpw;
     dim3 grid((a.Lin + TQ - 1) / TQ, (a.nvt + per_block - 1) / per_block, B);
+    // row-wise output through an LDS tile when the block owns whole rows (all phases and channels) and the tile keeps the block small
+    // enough for three per CU; (cout * esz) must be whole 16-byte chunks
+    {
+        const int esz = a.out_half ? 2 : 4;
+        const size_t ot = (size_t)TQ * a.u * ((size_t)a.cout * esz + 16);
+        smem = (smem + 15) / 16 * 16;
+        if (a.out_tr && grid.y == 1 && (a.cout * esz) % 16 == 0 && smem + ot <= 52 * 1024) {
+            a.out_tr_off = (int)smem;
+            smem += ot;
+        } else {
+            a.out_tr = 0;
+        }
+    }
     if (nj == 4) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 4>), grid, dim3(256), smem, st, a);
     else if (nj == 2) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 2>), grid, dim3(256), smem, st, a);
     else hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 1>), grid, dim3(256), smem, st, a);
@@ -890,6 +903,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             ua.bias = U.bias.as<float>();
             ua.out = h->X0.as<float>();
             ua.out_half = x0h ? 1 : 0;
+            ua.out_tr = h->opt.geti("UPS_TR", 1) != 0 ? 1 : 0;  // (the launcher clears it where the block does not own whole rows)
             ua.out_bstride = L * C;
             if (c.use_f0 && s.nz_mfma) {  // noise_convs[i](har) as a 2-tap MFMA conv over frames -> NZ, added in k_ups' epilogue
                 ConvArgs na = base_args();

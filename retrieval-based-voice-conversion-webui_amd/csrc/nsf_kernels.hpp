@@ -1326,6 +1326,10 @@ struct UpsArgs {
     const float* bias;
     float* out;
     int out_half;  // 1: X0 is written as fp16 (pack4_h; option X0_F16, stages whose ResBlocks run on k_rb_full), same element layout
+    int out_tr;    // 1: the block owns WHOLE output rows (every phase, every channel: gridDim.y == 1) and stores them row-wise through an LDS
+                   //    tile at byte offset out_tr_off of the dynamic LDS: each D-layout store touched 8 (fp16) / 16 (fp32) bytes of 32 rows --
+                   //    16 partial writes per 128-byte line, 1.6 TB/s -- the row-wise stores write whole lines
+    int out_tr_off;
     long out_bstride;
     const float* addend;  // optional [B][Lin*u][cout] fp32 added in the epilogue (noise conv done by the MFMA conv)
     const float* har;  // [B][Lh] or nullptr (no-f0 generator / addend in use)
@@ -1551,10 +1555,27 @@ static __global__ void __launch_bounds__(256, UPS_OCC) k_ups(UpsArgs a) {  // 2 
                         if (har) v += nv[mi][g] + *(const f32x4*)(a.bn + co);  // x + (noise_conv + its bias), nsf.py:173-174
                         else if (addend) v += nv[mi][g];                       // the addend already carries the noise bias
                         else if (a.nz_k1) v += *(const f32x4*)(a.bn + co);
-                        if (a.out_half) *(uint2*)((_Float16*)a.out + (size_t)b * a.out_bstride + (size_t)t * a.cout + co) = pack4_h(v[0], v[1], v[2], v[3]);
+                        if (a.out_tr) {  // row (q - q0) * u + r of the block's output tile; row pitch = cout elements + 16 bytes
+                            const int orow = (tw0 + jt * 32 + (lane & 31)) * a.u + r;
+                            char* ot = smem + a.out_tr_off;
+                            if (a.out_half) *(uint2*)(ot + (size_t)orow * (a.cout * 2 + 16) + co * 2) = pack4_h(v[0], v[1], v[2], v[3]);
+                            else *(f32x4*)(ot + (size_t)orow * (a.cout * 4 + 16) + co * 4) = v;
+                        } else if (a.out_half) *(uint2*)((_Float16*)a.out + (size_t)b * a.out_bstride + (size_t)t * a.cout + co) = pack4_h(v[0], v[1], v[2], v[3]);
                         else *(f32x4*)(out + (size_t)t * a.cout + co) = v;
                     }
             }
+        }
+    }
+    if (a.out_tr) {  // (block-uniform) whole rows out of the LDS tile: 16 bytes per lane, consecutive lanes = consecutive chunks of a row
+        __syncthreads();
+        const int esz = a.out_half ? 2 : 4;
+        const int pitch = a.cout * esz + 16, cpr = a.cout * esz / 16;  // bytes per tile row, 16-byte chunks per row
+        const int nrows = min(TQ, Linb - q0) * a.u;                    // rows of this tile inside the item
+        const char* ot = smem + a.out_tr_off;
+        char* og = (char*)a.out + ((size_t)b * a.out_bstride + (size_t)q0 * a.u * a.cout) * esz;
+        for (int i = threadIdx.x; i < nrows * cpr; i += 256) {
+            const int row = i / cpr, c = i - row * cpr;
+            *(uint4*)(og + ((size_t)row * cpr + c) * 16) = *(const uint4*)(ot + (size_t)row * pitch + c * 16);
         }
     }
 }
