@@ -393,3 +393,57 @@ def test_realtime_pitch_cache_and_frame_arithmetic():
     assert p.shape == (1, 100) and np.allclose(f[0].numpy(), cf[-100:] * 29 / 25)
     with pytest.raises(ValueError):
         pc.update(torch.zeros(3, dtype=torch.long), torch.zeros(3), 1600)
+
+
+def test_infer_segments_batches_pads_and_draws_noise_like_sequential_calls():
+    """``rvc_amd.pipeline.infer_segments`` (host logic, CPU tensors, a recording stand-in for ``net_g.infer``): segments are grouped into
+    as few ragged batches as MAX_BATCH_FRAMES allows, padded with zeros / pitch 1, every item's noise is drawn in the order and shapes of
+    sequential ``infer`` calls (randn(1, 192, T); rand(1, 1, 1); randn(1, T * upp, 1)), and each output is cut to its own length."""
+    import types
+
+    import rvc_amd.pipeline as pl
+
+    upp, IC, d = 4, 192, 8
+    calls = []
+
+    def infer(phone, lengths, sid, pitch=None, pitchf=None, noise_zp=None, noise_dec=None, ragged=False):
+        assert ragged and phone.shape[0] == lengths.numel() == sid.numel()
+        calls.append(dict(lens=lengths.tolist(), phone=phone.clone(), pitch=pitch.clone(), pitchf=pitchf.clone(), nz=noise_zp.clone(), nd=noise_dec.clone()))
+        B, T = phone.shape[:2]
+        out = torch.zeros(B, 1, T * upp)
+        for b in range(B):
+            out[b, 0] = 100.0 * (len(calls) - 1) + b + torch.arange(T * upp) / 1000.0
+        return out
+
+    infer._rvcmi_ragged = True
+    net_g = types.SimpleNamespace(infer=infer, dec=types.SimpleNamespace(upp=upp, cfg={"inter_channels": IC}))
+    assert pl._ragged_capable(net_g) and not pl._ragged_capable(types.SimpleNamespace(infer=lambda *a, **k: None))
+    lens = [5, 9, 3, 7]
+    items = []
+    for i, T in enumerate(lens):
+        items.append((torch.full((1, T, d), float(i + 1)), torch.full((1, T), 10 + i, dtype=torch.long), torch.full((1, T), 100.0 + i), T))
+    old = pl.MAX_BATCH_FRAMES
+    try:
+        pl.MAX_BATCH_FRAMES = 15  # 5 + 9 fit, + 3 does not; then 3 + 7
+        torch.manual_seed(77)
+        outs = pl.infer_segments(net_g, torch.tensor([3]), items)
+    finally:
+        pl.MAX_BATCH_FRAMES = old
+    assert [c["lens"] for c in calls] == [[5, 9], [3, 7]]
+    torch.manual_seed(77)  # the sequential draws, item by item
+    k = 0
+    for c in calls:
+        Tm = max(c["lens"])
+        assert c["phone"].shape == (len(c["lens"]), Tm, d)
+        for b, T in enumerate(c["lens"]):
+            nz = torch.randn(1, IC, T)
+            torch.rand(1, 1, 1)
+            nd = torch.randn(1, T * upp, 1)
+            assert torch.equal(c["nz"][b, :, :T], nz[0]) and not c["nz"][b, :, T:].any()
+            assert torch.equal(c["nd"][b, :T * upp], nd[0, :, 0]) and not c["nd"][b, T * upp:].any()
+            assert (c["phone"][b, :T] == k + 1).all() and not c["phone"][b, T:].any()
+            assert (c["pitch"][b, :T] == 10 + k).all() and (c["pitch"][b, T:] == 1).all() and (c["pitchf"][b, :T] == 100.0 + k).all()
+            k += 1
+    for i, (o, T) in enumerate(zip(outs, lens)):
+        call, b = (0, i) if i < 2 else (1, i - 2)
+        assert o.shape == (T * upp,) and torch.equal(o, 100.0 * call + b + torch.arange(T * upp) / 1000.0)
