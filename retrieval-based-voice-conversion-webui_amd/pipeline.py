@@ -103,8 +103,8 @@ def vc_device(self, model, net_g, sid, audio0, pitch, pitchf, times, index, inde
 # once f0 is known.  With the ragged-batch entry of the generator (include/rvcmi.h rvcmi_nsf_forward ``lengths``: every item computed
 # exactly as a separate call of its own length) they go through the front and the generator as one batch.  The noise of item b is
 # drawn as the b-th sequential call would have drawn it (randn(1, 192, T_b); rand(1, 1, 1); randn(1, T_b * upp, 1)), so a seeded run
-# consumes the generator exactly like the sequential pipeline.  Frames per call are bounded (``MAX_BATCH_FRAMES``) so that the workspace of
-# an hour-long file stays a few GB; segments beyond the bound go into further calls.
+# consumes the generator exactly like the sequential pipeline.  Padded frames per call (items x longest item) are bounded (``MAX_BATCH_FRAMES``) so that
+# the workspace of an hour-long file stays a few GB; segments beyond the bound go into further calls.
 MAX_BATCH_FRAMES = 32768
 
 
@@ -130,9 +130,10 @@ def infer_segments(net_g, sid, items, times=None):
     IC = int(net_g.dec.cfg["inter_channels"])
     start = 0
     while start < len(items):
-        end, frames = start, 0
-        while end < len(items) and (end == start or frames + items[end][3] <= MAX_BATCH_FRAMES):
-            frames += items[end][3]
+        # the workspace of a call is B x T_max frames (padded), so THAT is what the bound applies to, not the sum of the lengths
+        end, tmax = start, 0
+        while end < len(items) and (end == start or (end - start + 1) * max(tmax, items[end][3]) <= MAX_BATCH_FRAMES):
+            tmax = max(tmax, items[end][3])
             end += 1
         grp = items[start:end]
         B, Tm = len(grp), max(it[3] for it in grp)

@@ -424,7 +424,7 @@ def test_infer_segments_batches_pads_and_draws_noise_like_sequential_calls():
         items.append((torch.full((1, T, d), float(i + 1)), torch.full((1, T), 10 + i, dtype=torch.long), torch.full((1, T), 100.0 + i), T))
     old = pl.MAX_BATCH_FRAMES
     try:
-        pl.MAX_BATCH_FRAMES = 15  # 5 + 9 fit, + 3 does not; then 3 + 7
+        pl.MAX_BATCH_FRAMES = 18  # padded frames: 2 x 9 fit, 3 x 9 do not; then 2 x 7
         torch.manual_seed(77)
         outs = pl.infer_segments(net_g, torch.tensor([3]), items)
     finally:
