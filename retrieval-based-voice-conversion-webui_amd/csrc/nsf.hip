@@ -947,6 +947,11 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             const long blocks4 = (long)((Lin + 128 * (4 / wv) - 1) / (128 * (4 / wv))) * B;
             if (blocks4 < 2048 && s.cin >= 128) nj = s.cin >= 512 ? 2 : 1;
             else if (blocks4 < 2048 && s.cin == 64) nj = 2;  // (us at B = 1 after the staging fix: 84 / 75 / 89 for NJ 4 / 2 / 1)
+            // large grids (round 4, fp16 inputs + row-wise stores; us per clip at B = 16 for NJ 4 / 1 / 2, ABAB: C_in 128: 77 / 67 / 83,
+            // 64: 70 / 73 / 55): the short tiles win there too -- they also keep the output tile inside the row-wise store's LDS budget
+            else if (s.cin >= 512) nj = 2;   // (C_in 512: 22 vs 29 us for NJ 2 / 4; C_in 256 keeps NJ = 4: 52 vs 57)
+            else if (s.cin == 128) nj = 1;
+            else if (s.cin == 64) nj = 2;
             if (h->opt.has("UPS_NJ")) {
                 const int v = h->opt.geti("UPS_NJ", nj);
                 if (v == 1 || v == 2 || v == 4) nj = v;
