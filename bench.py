@@ -396,6 +396,23 @@ def emit(line: dict) -> None:
     out.flush()
 
 
+def _list_major_bytes(sizes, asg, d, ms_per_search):
+    """What the list-major launches move for THIS assignment of queries to lists (host arithmetic, outside every timed region): a work
+    item = (list, 32 sorted queries, 32 rows) stages its 32 query rows and its 32 list rows, so a list's rows are read once per
+    32-query tile and a query once per 32-row tile of its list; plus the fp32 score scratch (written by the tiles, read by the
+    selector), ~12 verified candidate rows and the 8 gathered rows of the blend per query."""
+    import numpy as np
+
+    cnt = np.bincount(asg, minlength=len(sizes)).astype(np.int64)
+    qt, rt = (cnt + 31) // 32, (sizes + 31) // 32
+    tile = float((qt * sizes + rt * cnt).sum()) * 4.0 * d
+    scratch = 2.0 * float((cnt * sizes).sum()) * 4.0
+    sel = float(len(asg)) * (12 + 8 + 2) * 4.0 * d
+    tot = tile + scratch + sel
+    return {"list_major_bytes": {"tiles": tile, "score_scratch": scratch, "select_and_blend": sel, "total": tot},
+            "list_major_GBps": tot / (ms_per_search * 1e-3) / 1e9, "work_items": int((qt * rt).sum())}
+
+
 def main():
     global _REAL_STDOUT
     a = parse()
@@ -624,7 +641,10 @@ def main():
         if scan and scan[0]["ms"] > 0:
             roof["ivf_scan_hbm"] = {"achieved": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                     "frac": scan[0]["bytes"] / (scan[0]["ms"] * 1e-3) / 8e12,
-                                    "bytes_model": "ntotal / nlist rows per query (lists of equal size)",
+                                    "bytes_model": "SURVEY 8d ALGORITHMIC bytes: ntotal / nlist rows per query (lists of equal size) -- a "
+                                                   "model-equivalent throughput that compares the two scan designs, NOT the traffic the "
+                                                   "list-major launches perform (see list_major_bytes / the PMC traffic)",
+                                    "path": "list-major (plan + score tiles + select)" if "ivf_plan" in scan[0]["parts"] else "query-major",
                                     "launches_us": scan[0]["parts"]}
             if idx is not None:
                 # what the scan really walks on THIS index: i.i.d. Gaussian rows give very unequal lists and the (equally
@@ -640,6 +660,7 @@ def main():
                     "rows_per_query_model": a.index_n / max(1, len(sizes)), "rows_per_query_scanned": rows / max(1, len(asg)),
                     "largest_list": int(sizes.max()), "scanned_bytes": sb, "scanned_GBps": sb / (ms1 * 1e-3) / 1e9,
                     "unique_list_bytes": float(sizes[np.unique(asg)].sum()) * (4.0 * a.index_d + 8),
+                    **_list_major_bytes(sizes, asg, a.index_d, ms1),
                     "note": "scanned_bytes = rows of the probed list x queries (what a query-major scan walks, mostly through L2; "
                             "the list-major path reads a list's rows once per 32-query tile); unique_list_bytes = the rows probed at all"})
             if idx is not None and B == 1 and a.index_d == 768:
@@ -742,7 +763,13 @@ def main():
             "per_gpu": value / world,
             "n_gpus": dist.get_world_size() if use_dist else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.operand + " MFMA operands, fp32 accumulate/residual; fp64 IVF distances" if a.operand != "fp32" else "fp32",
+            # what the arithmetic is, not a precision claim: MFMA operands AND (round 4, options Y_F16 / X0_F16, default on) the
+            # inter-stage streams in HBM -- the three ResBlock outputs of stages 1-3 and the ups output X0 of stages 2-3 -- are fp16;
+            # accumulators, biases, the residual stream INSIDE a ResBlock, the excitation and conv_post are fp32
+            "dtype": ("%s MFMA operands%s, fp32 accumulate / in-block residual; fp32 MFMA prefilter + fp64 verified IVF distances" % (
+                a.operand, "" if os.environ.get("RVCMI_Y_F16", "1") == "0" else (
+                    " + fp16 inter-stage streams (ResBlock outputs%s)" % ("" if os.environ.get("RVCMI_X0_F16", "1") == "0" else ", ups output at C <= 64")))
+                      ) if a.operand != "fp32" else "fp32 (fp32 MFMA, fp32 streams)",
             "data": "synthetic (seeded weights, features, f0, noise, index; no checkpoints offline)",
             "config": {"workload": "BASELINE configs[%d]: v2/48k, %d x 10 s clip(s) per GPU, T=%d frames, 599 queries/clip, "
                                    "IVF %dx%d nlist=%d nprobe=1 k=8 index_rate=%.2f" % (

@@ -38,7 +38,10 @@
 extern "C" {
 #endif
 
-#define RVCMI_VERSION 1
+/* ABI version.  2: rvcmi_nsf_forward takes lengths_dev as its 4th argument (ragged batches).  A binding must compare
+ * rvcmi_version() with the RVCMI_VERSION it was written against before its first call: a v1 caller on a v2 library would
+ * shift every pointer by one.                                                                                              */
+#define RVCMI_VERSION 2
 
 typedef enum {
     RVCMI_OK = 0,

@@ -72,6 +72,54 @@ def search(index: dict, q: np.ndarray, k: int = 8, nprobe: int | None = None) ->
     return D, I
 
 
+def _c_lib():
+    """oracle/libivf_oracle.so (oracle/ivf_scan.c: the plain-C second restatement; OpenMP over queries), built on demand."""
+    import ctypes as C
+    import os
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    so, src = os.path.join(here, "libivf_oracle.so"), os.path.join(here, "ivf_scan.c")
+    if not os.path.exists(so):
+        subprocess.run(["gcc", "-O3", "-mavx2", "-mfma", "-fopenmp", "-shared", "-fPIC", "-o", so, src, "-lm"], check=True)
+    return C.CDLL(so)
+
+
+def search_c(index: dict, q: np.ndarray, k: int = 8, nprobe: int | None = None, f32: bool = False):
+    """``search`` through the C restatement (fp64 definition unless ``f32``): the checker for query counts the numpy loops above
+    would take minutes on (BASELINE configs[2] / [3]: 38 336 queries per call).  -> (D, I, P): P = list-major row positions."""
+    import ctypes as C
+
+    lib = _c_lib()
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    nprobe = int(index.get("nprobe", 1) if nprobe is None else nprobe)
+    nq, d = q.shape
+    D = np.empty((nq, k), np.float32)
+    I = np.empty((nq, k), np.int64)
+    P = np.empty((nq, k), np.int64)
+    arrs = [np.ascontiguousarray(index["centroids"], np.float32), np.ascontiguousarray(index["list_offsets"], np.int64),
+            np.ascontiguousarray(index["ids"], np.int64), np.ascontiguousarray(index["vecs"], np.float32)]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.ivf_search(vp(q), C.c_int64(nq), C.c_int(d), vp(arrs[0]), C.c_int64(index["nlist"]), C.c_int(nprobe), vp(arrs[1]), vp(arrs[2]),
+                   vp(arrs[3]), C.c_int(k), vp(D), vp(I), vp(P), C.c_int(1 if f32 else 0))
+    return D, I, P
+
+
+def blend_c(index: dict, feats: np.ndarray, D: np.ndarray, P: np.ndarray, index_rate: float) -> np.ndarray:
+    """pipeline.py:129-138 through the C restatement (numpy's fp32 operation order) -> the blended copy of ``feats``."""
+    import ctypes as C
+
+    lib = _c_lib()
+    out = np.ascontiguousarray(feats, dtype=np.float32).copy()
+    nq, d = out.shape
+    vecs = np.ascontiguousarray(index["vecs"], np.float32)
+    pos_last = int(np.nonzero(index["ids"] == index["ntotal"] - 1)[0][0])  # numpy's big_npy[-1] for an id of -1
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.ivf_blend(vp(out), C.c_int64(nq), C.c_int(d), vp(np.ascontiguousarray(D)), vp(np.ascontiguousarray(P)), C.c_int(D.shape[1]), vp(vecs),
+                  C.c_int64(pos_last), C.c_float(index_rate), C.c_float(1.0 - index_rate))
+    return out
+
+
 def reconstruct_n(index: dict, i0: int = 0, n: int | None = None) -> np.ndarray:
     """``index.reconstruct_n(0, ntotal)``: rows back in id order (pipeline.py:215)."""
     n = index["ntotal"] - i0 if n is None else n

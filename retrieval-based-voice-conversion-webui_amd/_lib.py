@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["nsf.hip", "rb_stream.hip", "ivf.hip", "front.hip", "glue.hip"]
 
 RVCMI_MAX_UPS, RVCMI_MAX_RB, RVCMI_MAX_DIL = 8, 4, 4
+RVCMI_VERSION = 2  # include/rvcmi.h; the argument lists of SYMBOLS below are those of this ABI version
 OPERANDS = {"fp32": 0, "f32": 0, "bf16": 1, "fp16": 2, "f16": 2}
 
 
@@ -178,6 +179,10 @@ def lib() -> C.CDLL:
             f = getattr(l, name)  # AttributeError if the header and the library drift apart
             f.restype = res
             f.argtypes = args
+        v = l.rvcmi_version()
+        if v != RVCMI_VERSION:  # a stale .so against a newer header shifts pointer arguments: garbage reads, not an error
+            raise RvcmiError("%s implements ABI version %d, this binding is written against %d (include/rvcmi.h); rebuild with "
+                             "`python __graft_entry__.py build`" % (LIB_PATH, v, RVCMI_VERSION))
         _lib = l
     return _lib
 

@@ -888,6 +888,8 @@ struct rvcmi_ivf {
     double lm_vmax = 0.0;      // max |v| over the stored rows (error bound of the fp32 prefilter)
     int64_t lm_maxlen = 0;     // longest list
     int64_t lm_cap_items = 0;  // capacity of lm_items
+    int64_t lm_cap_nq = 0;     // queries lm_S / lm_qinfo / lm_items are sized for (0: not reserved -- the list-major kernels never run)
+    bool lm_warned = false;    // the one-time "large call on the query-major scan" diagnostic was printed
     Profiler prof;
     // dev / test options (common.hpp Options): IVF_COARSE_F64 (brute-force fp64 coarse quantizer), IVF_GENERIC (any-d scan kernel),
     // IVF_STAMPS (prints; syncs), IVF_DBG, IVF_SORT (1 = scan the queries in list-sorted, XCD-contiguous order).  Read from RVCMI_<KEY> once at handle creation; later only rvcmi_ivf_set_option.
@@ -1154,14 +1156,23 @@ static int num_cus_ivf() {
 // List-major scan: usable for nprobe 1, d a multiple of the MFMA K chunk, list counts / lengths the planner and the selector
 // hold in LDS, and a score scratch (nq x longest list, fp32) of at most 1 GiB; small query counts (a realtime chunk's 16) keep
 // the one-launch query-major kernel.  Option IVF_LM: 0 = never (round-3 path), default 1.
-static bool lm_usable(const rvcmi_ivf* h, int64_t nq) {
+// Returns nullptr when the list-major kernels can take a call of nq queries, else the reason they cannot (printed once per handle
+// for calls of 64 queries or more: such a call silently costs the 34x row re-reads of the query-major scan otherwise).
+static const char* lm_unusable_reason(const rvcmi_ivf* h, int64_t nq) {
     const BlobHeader& b = h->hdr;
-    if (std::min<int64_t>(b.nprobe, b.nlist) != 1 || (b.d % CG_K) != 0 || b.nlist > LM_MAXL || b.ntotal < 1) return false;
-    if (!h->lm_ready || h->lm_maxlen < 1 || h->lm_maxlen > LM_MAXPITCH) return false;
-    if (nq < 64 || nq >= (1ll << 30)) return false;
+    if (nq < 64) return "fewer than 64 queries";
+    if (std::min<int64_t>(b.nprobe, b.nlist) != 1) return "nprobe > 1";
+    if ((b.d % CG_K) != 0) return "d is not a multiple of 32";
+    if (b.nlist > LM_MAXL) return "more than 16384 lists (the one-block planner counts them in LDS)";
+    if (b.ntotal < 1) return "empty index";
+    if (!h->lm_ready || h->lm_maxlen < 1) return "list statistics not reserved";
+    if (h->lm_maxlen > LM_MAXPITCH) return "a list of more than 2048 rows (the selector stages a score row in LDS)";
+    if (nq >= (1ll << 30)) return "2^30 queries or more";
     const int64_t pitch = (int64_t)align_up((uint64_t)h->lm_maxlen, 32);
-    return (double)nq * (double)pitch * 4.0 <= 1073741824.0;
+    if ((double)nq * (double)pitch * 4.0 > 1073741824.0) return "score scratch (queries x longest list x 4 B) above 1 GiB";
+    return nullptr;
 }
+static bool lm_usable(const rvcmi_ivf* h, int64_t nq) { return lm_unusable_reason(h, nq) == nullptr; }
 static void lm_reserve(rvcmi_ivf* h, int64_t nq) {
     const BlobHeader& b = h->hdr;
     if (std::min<int64_t>(b.nprobe, b.nlist) != 1 || (b.d % CG_K) != 0 || b.nlist > LM_MAXL || b.ntotal < 1) return;
@@ -1188,20 +1199,31 @@ static void lm_reserve(rvcmi_ivf* h, int64_t nq) {
         }
         h->lm_ready = true;
     }
+    // (declining to allocate must also retire an earlier, smaller reservation: reserve() raises cap_nq to the new value, and a later
+    //  search with nq <= cap_nq would otherwise run the list-major kernels on buffers sized for fewer queries)
+    h->lm_cap_nq = 0;
     if (!lm_usable(h, std::max<int64_t>(nq, 64))) return;
     const int64_t pitch = (int64_t)align_up((uint64_t)h->lm_maxlen, 32);
-    if ((double)nq * (double)pitch * 4.0 > 1073741824.0) return;
     h->lm_S.alloc((size_t)std::max<int64_t>(nq, 1) * pitch * 4);
     h->lm_qinfo.alloc((size_t)std::max<int64_t>(nq, 1) * sizeof(LmQuery));
     // worst case of the planner: every probed list adds at most one partial query tile on top of nq / 32 full ones
     h->lm_cap_items = (nq / 32 + std::min<int64_t>(nq, b.nlist) + 1) * (pitch / 32);
     h->lm_items.alloc((size_t)h->lm_cap_items * sizeof(LmItem));
+    h->lm_cap_nq = std::max<int64_t>(nq, 1);
 }
 
 static void reserve(rvcmi_ivf* h, int64_t nq) {
     const int np = (int)std::min<int64_t>(h->hdr.nprobe, h->hdr.nlist);
     const bool have_scores = np > 1 || (h->cscore.p && h->cap_chunk > 0);
-    if (nq <= h->cap_nq && np <= h->cap_nprobe && h->flag.p && have_scores) return;
+    if (nq <= h->cap_nq && np <= h->cap_nprobe && h->flag.p && have_scores) {
+        // the list-major scratch has a capacity of its own: a reserve above its 1 GiB bound retires it (lm_reserve), a later call
+        // that fits gets it back at its own size
+        if (h->lm_ready && nq > h->lm_cap_nq && lm_usable(h, nq)) {
+            DeviceGuard dg(h->device);
+            lm_reserve(h, nq);
+        }
+        return;
+    }
     DeviceGuard dg(h->device);
     nq = std::max<int64_t>(nq, h->cap_nq);
     h->assign.alloc((size_t)std::max<int64_t>(nq, 1) * np * 8);
@@ -1277,7 +1299,16 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
         });
     }
     // list-major scan: plan (sort + work items) -> fp32 MFMA score tiles -> per-query exact verification (+ fused blend)
-    if (h->opt.geti("IVF_LM", 1) && !h->opt.on("IVF_GENERIC") && lm_usable(h, nq) && h->lm_S.p && nq <= h->cap_nq) {
+    const bool lm_wanted = h->opt.geti("IVF_LM", 1) && !h->opt.on("IVF_GENERIC");
+    if (lm_wanted && nq >= 64 && !h->lm_warned) {
+        const char* why = lm_unusable_reason(h, nq);
+        if (why) {
+            h->lm_warned = true;
+            fprintf(stderr, "[rvcmi] ivf search: %lld queries run on the query-major scan (every probed list is re-read per query) because the "
+                    "list-major kernels do not take this call: %s.  Printed once per index.\n", (long long)nq, why);
+        }
+    }
+    if (lm_wanted && lm_usable(h, nq) && h->lm_S.p && nq <= h->lm_cap_nq) {
         const int pitch = (int)align_up((uint64_t)h->lm_maxlen, 32);
         const double rows = (double)b.ntotal / (double)b.nlist;
         h->prof.launch("ivf_plan", 0.0, (double)nq * 12 + (double)b.nlist * 8, st, [&] {

@@ -541,8 +541,7 @@ static int rb_stream_mode(const rvcmi_nsf* h) {
 // Option Y_F16 (default 1): the whole-ResBlock kernels (k_rb_stream ND = 3, k_rb_full) write their output streams Ya[j] as fp16
 // and the next stage's k_ups / k_post read them as such (nsf_kernels.hpp pack4_h).  0 = fp32 streams (round 3).
 static bool y_f16(const rvcmi_nsf* h) {
-    return h->cfg.operand != RVCMI_OPERAND_F32 && h->opt.geti("Y_F16", 1) != 0 && !h->opt.on("RS_V2") && !h->opt.on("RS_V3") &&
-           !h->opt.on("RS_V2X");
+    return h->cfg.operand != RVCMI_OPERAND_F32 && h->opt.geti("Y_F16", 1) != 0;
 }
 
 // Option X0_F16 (default 1, only together with Y_F16): at the stages whose ResBlocks run on k_rb_full (C <= 64: the two HBM-heaviest

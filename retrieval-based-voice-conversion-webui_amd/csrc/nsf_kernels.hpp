@@ -32,8 +32,10 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 // batch of the reference lets the rows behind a short item leak into its tail through every receptive field).  Each kernel
 // replaces its row count by the item's: rows(lens, b, mul, Lmax) = lens[b] * mul (mul = the stage's upsampling factor so far);
 // buffer strides stay those of the longest item.
+// (clamped on BOTH sides: a device-resident lengths tensor is not validated on the host -- no sync -- and lens[b] <= 0 would make the
+//  clamped staging loads `min(max(row, 0), rows - 1)` read row -1 of the stream, out of bounds for item 0)
 __device__ __forceinline__ int item_rows(const int* __restrict__ lens, int b, int mul, int Lmax) {
-    return lens ? min(Lmax, lens[b] * mul) : Lmax;
+    return lens ? max(min(Lmax, lens[b] * mul), min(Lmax, mul)) : Lmax;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,17 +12,8 @@
 #include "common.hpp"
 #include "rb_stream.hpp"
 #include "rb_stream_kernels.hpp"
-// k_rb_stream2 / 2x / 3 (two blocks per CU, anti-phased groups, half-step slots): parity-green and measured SLOWER than
-// k_rb_stream in round 3.  Kept as dev variants: compiled only with RVCMI_DEFINES="RVCMI_DEV_VARIANTS", not part
-// of the product library or the default GPU suite; their schedule models stay tested (tools/model_rb_stream.py).
-#ifdef RVCMI_DEV_VARIANTS
-#include "rb_stream2_kernels.hpp"
-#include "rb_stream3_kernels.hpp"
-#else
-namespace rvcmi {  // geometry constants of the dev variants that the (shared) strip planner names
-constexpr int RS2_STRIDE = 256, RS2_HEAD = 52, RS2_SLACK = 3, RS3_XROWS = 52 + 192 + 3, RS3_HROWS = 10 + 192 + 1;
-}
-#endif
+// (k_rb_stream2 / 2x / 3 -- two blocks per CU, anti-phased groups, half-step slots -- were parity-green and measured SLOWER than
+//  k_rb_stream in round 3; removed in round 5, `git log -- csrc/rb_stream2_kernels.hpp` has them.)
 
 namespace rvcmi {
 int num_cus();
@@ -32,34 +23,16 @@ namespace {
 #ifndef RS_KL_DEFAULT
 #define RS_KL_DEFAULT 2  // measured (r3k): 0.641 -> 0.623 ms per clip at B = 1 with the planning constant below, 0.614 -> 0.605 at B = 16
 #endif
-#ifndef RS_V2X_DEFAULT
-#define RS_V2X_DEFAULT 0
-#endif
-#ifndef RS_V3_DEFAULT
-#define RS_V3_DEFAULT 0  // until the GPU A/B says otherwise
-#endif
 
 struct Geo {
     int MI, NJ, NCO, bpc;  // bpc = blocks per CU (k_rb_stream: one wave per SIMD, NCO * bpc = 4)
-    int ver;               // 1 = k_rb_stream, 2 = k_rb_stream2 (two blocks per CU, swizzled 256-byte rows), 3 = k_rb_stream3 (half-step slots)
     double c0;             // planning: a block's time is steps x (k + c0) units
 };
-// k_rb_stream2 (two blocks per CU): every strip pays the same warm-up rows but a step is half as long, so it needs LONG strips
-// to win.  Measured (r3g): B = 1 0.82 vs 0.72 ms, B = 16 0.640 vs 0.623, B = 64 0.606 vs 0.628 ms per clip -- it only
-// pays at B = 64.  Option RS_V2: 0 (default) = never, 1 = whenever supported, 2 = from RS_V2_STEPS (default 150) steps per block on.
-bool geo_for(int C, int nd, Geo& g, const Options& opt, int ver = 1) {
+bool geo_for(int C, int nd, Geo& g, const Options& opt) {
     const bool sm = opt.geti("RS_SMALL", 1) != 0;
-    if (C == 256 && nd == 1) { g = {2, sm ? 3 : 4, 4, 1, 1, 4.4}; return true; }
-    // k_rb_stream2: measured cycles per pair-step 46.2k / 32.9k / 20.0k for k = 11 / 7 / 3 => time ~ steps x (k + 3.1)
-    if (C == 128 && nd == 3 && ver == 2) { g = {1, 3, 4, 2, 2, opt.get("RS_C0", 3.1)}; return true; }
-    // k_rb_stream3 (rb_stream3_kernels.hpp): publish / history work in the MFMA shadow; planning constant from the slot model
-    // (per pair-step ~ 4 x (24 k MFMAs x 33 cycles + 72 gaps x 9) + barriers + IO  =>  time ~ steps x (k + 2.0))
-    // k_rb_stream2x: k_rb_stream2's two strips per CU as two groups of one 8-wave block in anti-phase (one K loop and one phase
-    // per inter-barrier interval): planning unit = the pair, time ~ steps x (k + c0) with the phases in the K loops' shadow
-    if (C == 128 && nd == 3 && ver == 4) { g = {1, 3, 4, 2, 4, opt.get("RS_C0", 1.0)}; return true; }
-    if (C == 128 && nd == 3 && ver == 3) { g = {1, 6, 4, 1, 3, opt.get("RS_C0", 2.0)}; return true; }
+    if (C == 256 && nd == 1) { g = {2, sm ? 3 : 4, 4, 1, 4.4}; return true; }
     // (the lean K loop shortens the k = 11 / 7 pair-steps more than the k = 3 ones: per pair-step 45.6k / 33.0k / 20.2k cycles => k + 3.8)
-    if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1, 1, opt.get("RS_C0", (sm && opt.geti("RS_KL", RS_KL_DEFAULT) == 2) ? 3.8 : 4.4)}; return true; }
+    if (C == 128 && nd == 3) { g = {1, sm ? 6 : 8, 4, 1, opt.get("RS_C0", (sm && opt.geti("RS_KL", RS_KL_DEFAULT) == 2) ? 3.8 : 4.4)}; return true; }
     // (C = 128 pair by pair with TWO blocks per CU -- NJ = 4, 225 registers, 0 spills -- was measured: both waves of a SIMD sit in
     //  their K loops at the same time (72 cycles per MFMA per wave), the phases overlap no better than in the one-wave design
     //  (MFMA pipe 66 % busy in both) and three launches move 3x the bytes: 0.82 vs 0.71 ms on the same box.  Not kept.)
@@ -86,54 +59,6 @@ void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStre
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(64 * NCO), smem, st, a);
 }
 
-#ifdef RVCMI_DEV_VARIANTS
-template <typename OpT>
-void launch_inst3(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0};
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    const unsigned long long bit = 1ull << (dev & 63);
-    auto kern = &k_rb_stream3<OpT>;
-    if (!(attr_done.load() & bit)) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done.fetch_or(bit);
-    }
-    if (nblocks < 0) return;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(256), smem, st, a);
-}
-
-template <typename OpT, int KL>
-void launch_inst2x(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0};
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    const unsigned long long bit = 1ull << (dev & 63);
-    auto kern = &k_rb_stream2x<OpT, 3, 3, KL>;
-    if (!(attr_done.load() & bit)) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done.fetch_or(bit);
-    }
-    if (nblocks < 0) return;
-    // (strip counts are even per resblock: launch_geo) one block = two consecutive strips
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B / 2), dim3(512), 2 * smem, st, a);
-}
-
-template <typename OpT, int NJ, int ND>
-void launch_inst2(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0};
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    const unsigned long long bit = 1ull << (dev & 63);
-    auto kern = &k_rb_stream2<OpT, NJ, ND>;
-    if (!(attr_done.load() & bit)) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_done.fetch_or(bit);
-    }
-    if (nblocks < 0) return;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks * (unsigned)B), dim3(256), smem, st, a);
-}
-
-#endif  // RVCMI_DEV_VARIANTS
 
 // weight ring of the C = 128 kernel: NB groups of KG k-steps; a group is requested (NB-1)*KG k-steps ahead of its use.
 // (4 groups of 2 k-steps -- the same 32 registers, 6 instead of 4 k-steps of L2 latency covered -- was measured: 47 instead
@@ -145,13 +70,7 @@ void launch_inst2(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStr
 #define RS_NB128 2
 #endif
 template <typename OpT>
-void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st, int ver = 1) {
-#ifdef RVCMI_DEV_VARIANTS
-    if (ver == 4 && C == 128 && nd == 3) return (a.flags & 2) ? launch_inst2x<OpT, 2>(a, nblocks, B, smem, st) : launch_inst2x<OpT, 1>(a, nblocks, B, smem, st);
-    if (ver == 3 && C == 128 && nd == 3) return launch_inst3<OpT>(a, nblocks, B, smem, st);
-    if (ver == 2 && C == 128 && nd == 3 && NJ == 3) return launch_inst2<OpT, 3, 3>(a, nblocks, B, smem, st);
-#endif
-    if (ver != 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: variant %d is a dev variant (build with RVCMI_DEFINES=RVCMI_DEV_VARIANTS)", ver);
+void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
     if (C == 256 && nd == 1 && NJ == 4) return launch_inst<OpT, 256, 2, 4, 4, 1>(a, nblocks, B, smem, st);
     if (C == 256 && nd == 1 && NJ == 3) return launch_inst<OpT, 256, 2, 3, 4, 1>(a, nblocks, B, smem, st);
     if (C == 128 && nd == 3 && NJ == 8) return launch_inst<OpT, 128, 1, 8, 4, 3>(a, nblocks, B, smem, st);
@@ -192,18 +111,6 @@ void rb_stream_prepare() {
     launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr);
     launch_t<_Float16>(128, 3, 6, a, -1, 1, 0, nullptr);
     a.flags = 0;
-#ifdef RVCMI_DEV_VARIANTS
-    launch_t<__bf16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
-    launch_t<_Float16>(128, 3, 3, a, -1, 1, 0, nullptr, 2);
-    launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr, 3);
-    launch_t<_Float16>(128, 3, 6, a, -1, 1, 0, nullptr, 3);
-    for (int fl : {0, 2}) {  // both K-loop variants of k_rb_stream2x
-        a.flags = fl;
-        launch_t<__bf16>(128, 3, 3, a, -1, 1, 0, nullptr, 4);
-        launch_t<_Float16>(128, 3, 3, a, -1, 1, 0, nullptr, 4);
-    }
-    a.flags = 0;
-#endif
 }
 
 bool rb_stream_supported(int operand, int C, int nd) {
@@ -218,20 +125,6 @@ bool rb_stream_launch(int operand, int C, int nd, const RbStreamDesc* jobs, int 
                       hipStream_t st, const Options& opt, bool dry_run) {
     Geo g;
     if (operand == RVCMI_OPERAND_F32 || njobs < 1 || njobs > 3) return false;
-#ifdef RVCMI_DEV_VARIANTS
-    // RS_V2X: 1 = k_rb_stream2x (two anti-phased strips per 8-wave block) wherever it is instantiated, 0 = never
-    if (opt.geti("RS_V2X", RS_V2X_DEFAULT) && geo_for(C, nd, g, opt, 4) && g.ver == 4 &&
-        launch_geo(g, force ? 0 : 4, operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
-        return true;
-    // RS_V3: 1 = k_rb_stream3 wherever it is instantiated (C = 128 whole resblocks), 0 = never (A/B runs; default set below)
-    if (opt.geti("RS_V3", RS_V3_DEFAULT) && geo_for(C, nd, g, opt, 3) && g.ver == 3 &&
-        launch_geo(g, force ? 0 : 4, operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
-        return true;
-    const int v2 = opt.geti("RS_V2", 0);
-    if (v2 && geo_for(C, nd, g, opt, 2) && g.ver == 2 &&
-        launch_geo(g, v2 == 1 ? (force ? 0 : 4) : opt.geti("RS_V2_STEPS", 150), operand, C, nd, jobs, njobs, L, B, bstride, st, opt, dry_run))
-        return true;
-#endif
     if (!geo_for(C, nd, g, opt)) return false;
     // auto mode: only where the persistent walk measured faster than the tile kernels -- C = 128 (whole resblocks) from 4 steps
     // per block; C = 256 (pair level) only with long strips (large batches).
@@ -270,8 +163,7 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
             J.b2[m] = d.b2[m];
             J.dil[m] = d.dil[m];
             const int p1 = d.dil[m] * (d.k - 1) / 2;
-            if (p1 + p2 > 32 || 2 * p2 > RS_HROW || p1 + p2 + d.dil[m] - 32 > (g.ver >= 2 ? RS2_SLACK : RS_SLACK) ||
-                32 + p1 - p2 > (g.ver >= 2 ? RS2_HEAD : RS_HEAD - RS_HROW) || (g.ver == 3 && d.k < 3))
+            if (p1 + p2 > 32 || 2 * p2 > RS_HROW || p1 + p2 + d.dil[m] - 32 > RS_SLACK || 32 + p1 - p2 > RS_HEAD - RS_HROW)
                 return false;  // halo larger than the 32-row lag / the head room of the tile: not this kernel
             warm[j] += p1;
             J.sx_off[m] = sx;
@@ -348,14 +240,6 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
         const int len = std::max(rows, steps * R - warm[j]);
         J.strip_len = len;
         J.nstrips = (L + len - 1) / len;
-        if (g.ver == 4 && (J.nstrips & 1)) {  // pairs of strips share a block: an odd count gets a shorter split or one empty strip
-            const int n2 = J.nstrips + 1, rows2 = (L + n2 - 1) / n2, steps2 = (rows2 + warm[j] + R - 1) / R;
-            if (steps2 * R - warm[j] >= rows2 && steps2 <= steps) {  // same or fewer steps with one more strip
-                J.strip_len = std::max(rows2, steps2 * R - warm[j]);
-            }
-            J.nstrips = (L + J.strip_len - 1) / J.strip_len;
-            if (J.nstrips & 1) ++J.nstrips;  // the extra strip starts at or beyond L: it loads clamped rows and stores nothing
-        }
         J.blk0 = nblocks;
         nblocks += J.nstrips;
         min_steps = std::min(min_steps, steps);
@@ -363,31 +247,19 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
     a.side_rows = side_rows;
     // k_rb_stream with the lean K loop (kconv) and the coalesced step IO; its buffer descriptors address an utterance's rows with
     // 32-bit byte offsets, so utterances of 2 GiB or more per stream (349 s of audio at C = 128) keep the D-layout form
-    if (g.ver == 1 && opt.geti("RS_KL", RS_KL_DEFAULT) == 2 && (double)L * C * 4.0 < 2147483648.0) a.flags = 4;
+    if (opt.geti("RS_KL", RS_KL_DEFAULT) == 2 && (double)L * C * 4.0 < 2147483648.0) a.flags = 4;
     a.lens = jobs[0].lens;
     a.lmul = jobs[0].lmul;
-    if (a.lens && g.ver != 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: ragged batches are implemented by k_rb_stream only");
-    if (jobs[0].y_half) {
-        if (g.ver != 1) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: fp16 output streams are implemented by k_rb_stream only");
-        a.flags |= 8;
-    }
-    if (g.ver == 4) a.flags = opt.geti("RS_V2X", RS_V2X_DEFAULT) == 2 ? 2 : 0;  // RS_V2X = 2: the K loop with B two k-steps ahead
-    if (g.ver == 2) {  // RS_SKEW = units of 1024 cycles per (k + 3), RS_PRIO = 1: s_setprio inside the K loops
-        a.skew = opt.geti("RS_SKEW", 2);
-        a.flags = opt.geti("RS_PRIO", 0) & 1;
-    }
+    if (jobs[0].y_half) a.flags |= 8;
     if (min_steps < min_steps_required) return false;
-    const size_t smem = g.ver == 4   ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
-                        : g.ver == 3 ? (size_t)(RS3_XROWS + RS3_HROWS + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
-                        : g.ver == 2 ? (size_t)(RS2_HEAD + R + RS2_SLACK + side_rows + 1) * RS2_STRIDE + (size_t)nd * 2 * C * sizeof(float)
-                                     : (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
+    const size_t smem = (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
     // k_rb_stream with KL = 2 (lean K loop + coalesced step IO): [side | dump | biases | M ...] with the fp32 transposition tile
     // T (R rows x (4 C + 16) bytes) starting at M and running over its end (rb_stream_kernels.hpp)
-    const bool kl2 = g.ver == 1 && C == 128 && nd == 3 && g.NJ == 6 && (a.flags & 4);
+    const bool kl2 = C == 128 && nd == 3 && g.NJ == 6 && (a.flags & 4);
     const size_t smem_kl2 = (size_t)(side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float) +
                             std::max((size_t)(RS_HEAD + R + RS_SLACK) * (2 * C + 16), (size_t)R * (4 * C + 16));
     if (kl2 && smem_kl2 > (size_t)160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large (C=%d)", smem_kl2, C);
-    if (smem > (size_t)160 * 1024 / (g.ver == 4 ? 2 : g.bpc))
+    if (smem > (size_t)160 * 1024 / g.bpc)
         RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: LDS image %zu B too large for %d block(s) per CU (C=%d)", smem, g.bpc, C);
     if (dry_run) return true;
     // dev only: option RS_STAMPS prints the per-phase cycle breakdown of every launch (synchronises; never set it in a timed run)
@@ -399,16 +271,14 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
         HIP_CHECK(hipMemsetAsync(ts, 0, nts * 8, st));
         a.ts = ts;
     }
-    if (operand == RVCMI_OPERAND_BF16) launch_t<__bf16>(C, nd, g.NJ, a, nblocks, B, kl2 ? smem_kl2 : smem, st, g.ver);
-    else launch_t<_Float16>(C, nd, g.NJ, a, nblocks, B, kl2 ? smem_kl2 : smem, st, g.ver);
+    if (operand == RVCMI_OPERAND_BF16) launch_t<__bf16>(C, nd, g.NJ, a, nblocks, B, kl2 ? smem_kl2 : smem, st);
+    else launch_t<_Float16>(C, nd, g.NJ, a, nblocks, B, kl2 ? smem_kl2 : smem, st);
     if (want_stamps) {
         HIP_CHECK(hipStreamSynchronize(st));
         std::vector<unsigned long long> h(nts);
         HIP_CHECK(hipMemcpy(h.data(), ts, nts * 8, hipMemcpyDeviceToHost));
         (void)hipFree(ts);
-        static const char* names1[10] = {"phaseA", "barA", "conv1", "bar1", "phaseB", "barB", "conv2", "bar2", "xload", "store"};
-        static const char* names3[10] = {"slot1", "bar", "slot2", "bar", "slot3", "bar", "slot4", "bar", "xload", "store"};
-        const char* const* names = g.ver == 3 ? names3 : names1;
+        static const char* names[10] = {"phaseA", "barA", "conv1", "bar1", "phaseB", "barB", "conv2", "bar2", "xload", "store"};
         for (int j = 0; j < njobs; ++j) {
             double sum[10] = {0}, steps = 0, tot_max = 0;
             long cnt = 0;
@@ -422,7 +292,7 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
                 ++cnt;
             }
             if (!cnt) continue;
-            fprintf(stderr, "[rs stamps] v%d C=%d nd=%d NJ=%d k=%d strips=%d len=%d steps/blk=%.1f  cycles per PAIR-step:", g.ver, C, nd, g.NJ, a.job[j].k,
+            fprintf(stderr, "[rs stamps] C=%d nd=%d NJ=%d k=%d strips=%d len=%d steps/blk=%.1f  cycles per PAIR-step:", C, nd, g.NJ, a.job[j].k,
                     a.job[j].nstrips, a.job[j].strip_len, steps / cnt);
             for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f", names[i], sum[i] / (steps * nd));
             fprintf(stderr, " | per step: xload %.0f store %.0f | slowest wave total %.0f cycles\n", sum[8] / steps, sum[9] / steps, tot_max);

@@ -27,14 +27,9 @@ int num_cus();
 void rb_stream_prepare();
 // Channel counts / fusion depths the kernel is instantiated for.
 bool rb_stream_supported(int operand, int C, int nd);
-// Option keys read from `opt` (dev / tests): RS_SMALL (0 = the larger time tiles), RS_V2 (0 never / 1 whenever supported /
-// 2 by strip length from RS_V2_STEPS on), RS_V3 (1 = k_rb_stream3 for C = 128, 0 = never), RS_V2X (1 = k_rb_stream2x, 0 = never), RS_KL (2 = k_rb_stream with the lean K loop kconv), RS_C0 (planning constant), RS_SKEW, RS_PRIO, RS_STAMPS (print phase stamps; syncs).
-inline void rb_stream_load_env(Options& opt) {
-    opt.load_env({"RS_SMALL", "RS_KL", "RS_C0", "RS_STAMPS"});
-#ifdef RVCMI_DEV_VARIANTS  // the opt-in streaming variants are keys of a handle only where they are compiled in
-    opt.load_env({"RS_V2", "RS_V2_STEPS", "RS_V3", "RS_V2X", "RS_SKEW", "RS_PRIO"});
-#endif
-}
+// Option keys read from `opt` (dev / tests): RS_SMALL (0 = the larger time tiles), RS_KL (2 = k_rb_stream with the lean K loop
+// kconv), RS_C0 (planning constant), RS_STAMPS (print phase stamps; syncs).
+inline void rb_stream_load_env(Options& opt) { opt.load_env({"RS_SMALL", "RS_KL", "RS_C0", "RS_STAMPS"}); }
 // Plans strips for `B` utterances of `L` rows and launches ONE kernel covering all `njobs` resblocks.  Returns false
 // (nothing launched) when the strips would be too short for the persistent walk to pay and `force` is not set.
 // `dry_run`: plan only (same return value), launch nothing.

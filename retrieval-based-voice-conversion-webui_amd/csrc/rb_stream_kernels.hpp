@@ -52,9 +52,8 @@ struct RbStreamArgs {
     int lmul;
     long bstride;
     int side_rows;  // rows of the side area (max over jobs)
-    int skew;       // k_rb_stream2: the second block of a CU starts `skew * (k + 3)` x 1024 cycles late (0 = together)
-    int flags;      // k_rb_stream2: bit 0 = raise the wave priority inside the K loops; bit 2 (4) = lean K loop instantiation;
-                    // bit 3 (8) = the dst streams are fp16 (pack4_h, nsf_kernels.hpp), same element layout
+    int flags;      // bit 2 (4) = lean K loop instantiation; bit 3 (8) = the dst streams are fp16 (pack4_h, nsf_kernels.hpp), same
+                    // element layout
     unsigned long long* ts;  // dev only (RVCMI_RS_STAMPS=1): per-wave cycle sums per phase, [block][wave][16]
 };
 
@@ -295,7 +294,7 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
 
             // ---- phase A: M <- [H head | X head | lrelu(x) new rows] ---------------------------------------------------
             // KL = 2: the X tail is not copied out after conv1 any more; the publish writes its last Hx rows a second time into the
-            // history buffer ("dual write", as k_rb_stream2) and the X head is restored WAVE-PRIVATELY -- each wave moves its own
+            // history buffer ("dual write") and the X head is restored WAVE-PRIVATELY -- each wave moves its own
             // 32 * MI channels, reads issued before its own dual writes (a wave's LDS operations execute in order) -- so the two
             // do not race without a barrier.  Saves the Hx-row LDS -> LDS copy of phase B.
             constexpr int WB = 64 * MI;            // bytes of a row owned by one wave

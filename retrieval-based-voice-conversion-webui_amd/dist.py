@@ -77,7 +77,7 @@ def broadcast_index(index, src: int = 0, device=None, group=None):
     return IVFFlatHIP.from_blob(buf)
 
 
-def convert_batch(paths, convert_one, index=None, src: int = 0, group=None, gather: bool = True, device=None):
+def convert_batch(paths, convert_one=None, index=None, src: int = 0, group=None, gather: bool = True, device=None, convert_many=None):
     """``VC.vc_multi`` (infer/modules/vc/modules.py:201-266: one ``vc_single`` per file of a folder, sequentially) across the
     ranks of one node.  Rank r converts the contiguous shard ``shard_range(len(paths), r, world)`` of ``paths`` -- the same list
     on every rank -- by calling ``convert_one(path, index)`` (e.g. ``lambda p, ix: vc.vc_single(sid, p, ..., file_index=ix, ...)``
@@ -90,7 +90,15 @@ def convert_batch(paths, convert_one, index=None, src: int = 0, group=None, gath
     files in the order of ``paths`` (one ``gather_object`` of the per-rank host results at the very end -- the reference's
     ``infos`` list) and the other ranks their own shard.  An exception inside ``convert_one`` becomes that file's result (the
     reference appends the traceback text to ``infos`` and goes on), so one bad file never stalls the other ranks.
-    Without an initialised process group it is the plain sequential loop."""
+    Without an initialised process group it is the plain sequential loop.
+
+    ``convert_many(paths_of_this_rank, index) -> list of results`` (instead of ``convert_one``): the rank's whole shard in ONE call, so
+    that the files are batched on its GPU -- a closure over ``rvc_amd.pipeline.convert_files`` (``Pipeline.convert_files`` after
+    ``install()``), which sends the segments of all files through the generator as ragged batches and through ONE retrieval call.  If it
+    raises, the shard is converted again file by file (``convert_many([p], index)``) so that the failure stays with its file.
+
+    Results travel as Python objects (``gather_object``): return what ``vc_multi`` keeps -- an info string, or the path of the file the
+    rank wrote -- not the waveforms of a 512-clip folder."""
     import traceback
 
     paths = list(paths)
@@ -108,12 +116,24 @@ def convert_batch(paths, convert_one, index=None, src: int = 0, group=None, gath
         if int(flag.item()):
             index = broadcast_index(index, src=src, device=device, group=group)
     lo, hi = shard_range(len(paths), rank, world)
+    if (convert_one is None) == (convert_many is None):
+        raise ValueError("give exactly one of convert_one / convert_many")
     mine = []
-    for p in paths[lo:hi]:
+    shard = paths[lo:hi]
+    if convert_many is not None and shard:
         try:
-            mine.append((p, convert_one(p, index)))
-        except Exception:  # noqa  (modules.py:196-199: vc_single returns the traceback text instead of raising)
-            mine.append((p, traceback.format_exc()))
+            res = list(convert_many(shard, index))
+            if len(res) != len(shard):
+                raise ValueError("convert_many returned %d results for %d files" % (len(res), len(shard)))
+            mine = list(zip(shard, res))
+        except Exception:  # noqa  (find the file that failed: one call per file, failures become that file's result)
+            convert_one = lambda p, ix: convert_many([p], ix)[0]  # noqa: E731
+    if not mine:
+        for p in shard:
+            try:
+                mine.append((p, convert_one(p, index)))
+            except Exception:  # noqa  (modules.py:196-199: vc_single returns the traceback text instead of raising)
+                mine.append((p, traceback.format_exc()))
     if not (on and world > 1 and gather):
         return mine
     parts = [None] * world if rank == src else None

@@ -217,6 +217,9 @@ def infer_hip(net_g, front: FrontHIP, phone, phone_lengths, sid, pitch=None, pit
     if isinstance(net_g.dec, GeneratorHIP):
         return net_g.dec(z, g=g, n_res=return_length2, **rag)
     if not isinstance(net_g.dec, (NSFGeneratorHIP, GeneratorHIP)) and callable(net_g.dec):  # a foreign dec (tests' stand-ins)
+        if ragged:  # it cannot be told the lengths: the padded-batch result would come back labelled per-item exact
+            raise TypeError("ragged=True needs the HIP generator as net_g.dec (got %s): a foreign dec computes the padded batch, "
+                            "whose short items are contaminated by the rows behind them" % type(net_g.dec).__name__)
         if pitchf is not None:
             return net_g.dec(z, pitchf, g=g, n_res=return_length2, **({"noise": noise_dec} if noise_dec is not None else {}))
         return net_g.dec(z, g=g, n_res=return_length2)

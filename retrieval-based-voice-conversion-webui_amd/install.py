@@ -75,6 +75,9 @@ class _FaissShim(types.ModuleType):
         return getattr(real, name)
 
 
+_ABSENT = object()  # `old` of an attribute install() ADDED: uninstall() deletes it
+
+
 def _rebind_methods(rebound) -> None:
     """``Pipeline.vc`` / ``Pipeline.pipeline`` / ``RVC.infer`` -> the device-resident versions.  The modules are imported here
     (after the faiss name has been taken care of) when the checkout provides them; a checkout without them is left alone."""
@@ -99,6 +102,9 @@ def _rebind_methods(rebound) -> None:
                 new._rvcmi_original = old
                 setattr(cls, name, new)
                 rebound.append((cls, name, old))
+        if "convert_files" not in cls.__dict__:  # a NEW method: Pipeline.pipeline for several inputs at once (vc_multi's loop, batched)
+            cls.convert_files = _pl.convert_files
+            rebound.append((cls, "convert_files", _ABSENT))
     mod = grab(_RTRVC_MODULE)
     cls = getattr(mod, "RVC", None) if mod is not None else None
     if cls is not None:
@@ -172,7 +178,10 @@ def uninstall() -> None:
     if not _state.get("installed"):
         return
     for mod, name, old in reversed(_state.get("rebound", [])):
-        setattr(mod, name, old)
+        if old is _ABSENT:
+            delattr(mod, name)
+        else:
+            setattr(mod, name, old)
     if "faiss_prev" in _state:
         if _state["faiss_prev"] is None:
             sys.modules.pop("faiss", None)

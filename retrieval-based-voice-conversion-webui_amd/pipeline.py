@@ -52,13 +52,9 @@ def _is_hip_index(index) -> bool:
     return isinstance(index, IVFFlatHIP)
 
 
-def features_device(self, model, audio0, pitch, pitchf, times, index, index_rate, version, protect):
-    """``Pipeline.vc`` from HuBERT to the tensor handed to ``net_g.infer`` (pipeline.py:90-159): features on the GPU, retrieval
-    blend + x2 + protect mix in one launch.  Returns (feats [1, p_len, d], pitch [1, p_len] or None, pitchf or None, p_len)."""
-    from time import time
-
-    from . import glue
-
+def hubert_device(self, model, audio0, pitch, pitchf, version):
+    """The HuBERT half of ``Pipeline.vc`` (pipeline.py:90-112, 146-151): -> (feats [1, nq, d] on the GPU, BEFORE retrieval,
+    pitch [1, p_len] or None, pitchf or None, p_len)."""
     dev = torch.device(self.device)
     feats = torch.as_tensor(audio0)
     feats = feats.half() if self.is_half else feats.float()
@@ -67,7 +63,6 @@ def features_device(self, model, audio0, pitch, pitchf, times, index, index_rate
     assert feats.dim() == 1, feats.dim()
     feats = feats.view(1, -1)
     padding_mask = torch.zeros(feats.shape, dtype=torch.bool, device=dev)
-    t0 = time()
     with torch.no_grad():
         logits = model.extract_features(source=feats.to(dev), padding_mask=padding_mask, output_layer=9 if version == "v1" else 12)
         feats = model.final_proj(logits[0]) if version == "v1" else logits[0]
@@ -76,11 +71,64 @@ def features_device(self, model, audio0, pitch, pitchf, times, index, index_rate
     p_len = min(int(audio0.shape[0]) // self.window, 2 * nq)  # pipeline.py:146-151
     if use_f0:
         pitch, pitchf = pitch[:, :p_len], pitchf[:, :p_len]
+    return feats, (pitch if use_f0 else None), (pitchf if use_f0 else None), p_len
+
+
+def features_device(self, model, audio0, pitch, pitchf, times, index, index_rate, version, protect):
+    """``Pipeline.vc`` from HuBERT to the tensor handed to ``net_g.infer`` (pipeline.py:90-159): features on the GPU, retrieval
+    blend + x2 + protect mix in one launch.  Returns (feats [1, p_len, d], pitch [1, p_len] or None, pitchf or None, p_len)."""
+    from time import time
+
+    from . import glue
+
+    t0 = time()
+    feats, pitch, pitchf, p_len = hubert_device(self, model, audio0, pitch, pitchf, version)
+    use_f0 = pitch is not None
     use_index = index is not None and index_rate != 0
     feats = glue.retrieve_blend_expand(feats, index if use_index else None, float(index_rate), pitchf if use_f0 else None,
                                        float(protect) if use_f0 else 0.5, p_len)
     times[0] += time() - t0
-    return feats, (pitch if use_f0 else None), (pitchf if use_f0 else None), p_len
+    return feats, pitch, pitchf, p_len
+
+
+MAX_BATCH_QUERIES = 65536  # HuBERT frames per retrieval call of blend_segments (22 minutes of audio; the score scratch stays < 1 GiB)
+
+
+def blend_segments(raw, index, index_rate, protect):
+    """The retrieval half of ``Pipeline.vc`` (pipeline.py:113-159) for MANY segments at once.  ``raw``: ``hubert_device`` results
+    (of one file or of several).  All their HuBERT frames go through ONE ``rvcmi_ivf_search_blend_expand`` call per
+    ``MAX_BATCH_QUERIES`` frames -- one coarse pass, one list-major scan: the rows of a probed list are read once for every segment
+    that probes it -- and every segment gets back exactly the rows its own call would have produced (a row's search, blend, x2 and
+    protect mix depend on nothing but that row).  -> items for ``infer_segments``."""
+    from . import glue
+
+    use_index = index is not None and index_rate != 0
+    items = [None] * len(raw)
+    start = 0
+    while start < len(raw):
+        end, n = start, 0
+        while end < len(raw) and (end == start or n + int(raw[end][0].shape[1]) <= MAX_BATCH_QUERIES):
+            n += int(raw[end][0].shape[1])
+            end += 1
+        grp = raw[start:end]
+        dev, dtype = grp[0][0].device, grp[0][0].dtype
+        use_f0 = grp[0][1] is not None
+        F = torch.cat([g[0][0] for g in grp]).to(torch.float32).contiguous()  # [n, d]
+        pf = None
+        if use_f0 and float(protect) < 0.5:  # the frame-rate pitchf of every segment at ITS output rows (2 x its first query row)
+            pf = torch.ones(2 * n, device=dev, dtype=torch.float32)
+            o = 0
+            for f, _, pff, p_len in grp:
+                pf[2 * o: 2 * o + p_len] = pff.reshape(-1)[:p_len].to(dev, torch.float32)
+                o += int(f.shape[1])
+        out = torch.empty(2 * n, F.shape[1], device=dev, dtype=torch.float32)
+        glue._blend_expand_into(out, F, index if use_index else None, float(index_rate), pf, float(protect) if use_f0 else 0.5, False)
+        o = 0
+        for i, (f, pt, pff, p_len) in enumerate(grp):
+            items[start + i] = (out[2 * o: 2 * o + p_len].unsqueeze(0).to(dtype), pt, pff, p_len)
+            o += int(f.shape[1])
+        start = end
+    return items
 
 
 def vc_device(self, model, net_g, sid, audio0, pitch, pitchf, times, index, index_rate, version, protect) -> torch.Tensor:
@@ -111,8 +159,13 @@ MAX_BATCH_FRAMES = 32768
 def _ragged_capable(net_g) -> bool:
     from .front import infer_hip
 
+    from .nsf import GeneratorHIP, NSFGeneratorHIP
+
     inf = getattr(net_g, "infer", None)
-    return bool(getattr(inf, "_rvcmi_ragged", False)) or getattr(inf, "func", None) is infer_hip
+    routed = bool(getattr(inf, "_rvcmi_ragged", False)) or getattr(inf, "func", None) is infer_hip
+    # ... and the generator behind it must be the HIP one: infer_hip cannot tell a foreign dec the lengths (it raises), and
+    # infer_segments reads dec.upp / dec.cfg
+    return routed and isinstance(getattr(net_g, "dec", None), (NSFGeneratorHIP, GeneratorHIP))
 
 
 def infer_segments(net_g, sid, items, times=None):
@@ -224,34 +277,40 @@ def _rmvpe_on_device(self, audio_pad, p_len, f0_up_key):
     return glue.rmvpe_f0(hidden.squeeze(0).float(), p_len, int(f0_up_key), RMVPE_THRED)
 
 
-def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr,
-                 resample_sr, rms_mix_rate, version, protect, f0_file=None):
-    """Drop-in ``Pipeline.pipeline``: same arguments, same numpy return (float array scaled to the int16 range)."""
+def _open_index(self, file_index, index_rate):
+    """pipeline.py:205-218.  -> (IVFFlatHIP or None, needs_reference): ``needs_reference`` = an index kind only real faiss reads
+    (not IVF-Flat / L2 ...) while the reference's own pipeline and the real faiss module are bound: the caller hands the whole
+    file to that pipeline (retrieval included; its vc calls come back through vc_hip, which passes a non-HIP index on)."""
     import os
+    import traceback
+
+    from . import _lib, ivf
+
+    if not (file_index != "" and os.path.exists(file_index) and index_rate != 0):
+        return None, False
+    try:
+        # on THIS pipeline's device (config.device), not the process's current GPU; big_npy is never materialised
+        return ivf.read_index(file_index, device=torch.device(self.device)), False
+    except _lib.RvcmiError as e:
+        orig = getattr(pipeline_hip, "_rvcmi_original", None)
+        real = getattr(getattr(_ref_module(self), "faiss", None), "_rvcmi_real", None)
+        if e.code == _lib.ERR_IO and orig is not None and real is not None:
+            return None, True
+        traceback.print_exc()  # the reference prints and converts without an index (pipeline.py:216-218)
+        return None, False
+
+
+def _prepare_file(self, model, sid, audio, times, f0_up_key, f0_method, if_f0, filter_radius, version, f0_file, collect):
+    """``Pipeline.pipeline`` from its input to the point where a segment would enter ``vc`` (pipeline.py:219-300): high-pass,
+    cut points, reflection pad, f0 (RMVPE decoded on the device), then ``collect(audio_segment, pitch_slice, pitchf_slice)`` for
+    every segment in order.  -> the filtered 16 kHz input (``change_rms`` needs it)."""
     import traceback
     from time import time
 
     import numpy as np
 
-    from . import _lib, glue, ivf
-
     ref = _ref_module(self)
     dev = torch.device(self.device)
-    index = None
-    if file_index != "" and os.path.exists(file_index) and index_rate != 0:
-        try:
-            # on THIS pipeline's device (config.device), not the process's current GPU; big_npy is never materialised
-            index = ivf.read_index(file_index, device=dev)
-        except _lib.RvcmiError as e:
-            orig = getattr(pipeline_hip, "_rvcmi_original", None)
-            real = getattr(getattr(ref, "faiss", None), "_rvcmi_real", None)
-            if e.code == _lib.ERR_IO and orig is not None and real is not None:
-                # an index kind only real faiss reads (not IVF-Flat / L2 ...): the reference's own pipeline serves it, retrieval
-                # included (its vc calls come back here through vc_hip, which hands a non-HIP index to the reference's vc)
-                return orig(self, model, net_g, sid, audio, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius,
-                            tgt_sr, resample_sr, rms_mix_rate, version, protect, f0_file)
-            traceback.print_exc()  # the reference prints and converts without an index (pipeline.py:216-218)
-            index = None
     audio = ref.signal.filtfilt(ref.bh, ref.ah, audio)
     opt_ts = _cut_points(self, audio, np.pad(audio, (self.window // 2, self.window // 2), mode="reflect"))
     t1 = time()
@@ -266,7 +325,6 @@ def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, fi
                 inp_f0 = np.array([[float(v) for v in ln.split(",")] for ln in lines], dtype="float32")
         except Exception:  # noqa
             traceback.print_exc()
-    sid = torch.tensor(sid, device=dev).unsqueeze(0).long()
     pitch = pitchf = None
     if if_f0:
         got = None
@@ -283,36 +341,115 @@ def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, fi
             pitchf = torch.as_tensor(np.asarray(pitchf)[:p_len].astype(np.float32), device=dev).unsqueeze(0).float()
     times[1] += time() - t1
     w = self.window
-    segs, s, t = [], 0, None
-    # segments of a long input: one net_g.infer call for all of them when the synthesizer is the HIP one (infer_segments above);
-    # RVCMI_PIPELINE_BATCH=0 (or a foreign net_g) keeps the reference's call-per-segment order
-    batch = _ragged_capable(net_g) and os.environ.get("RVCMI_PIPELINE_BATCH", "1") != "0" and len(opt_ts) > 0
-    items = []
-
-    def convert(a0, lo, hi):
-        pt = pitch[:, lo:hi] if if_f0 else None
-        pf = pitchf[:, lo:hi] if if_f0 else None
-        if batch:
-            items.append(features_device(self, model, a0, pt, pf, times, index, index_rate, version, protect))
-            return
-        o = vc_device(self, model, net_g, sid, a0, pt, pf, times, index, index_rate, version, protect)
-        segs.append(o[self.t_pad_tgt: o.shape[0] - self.t_pad_tgt].float())
-
+    s, t = 0, None
     for t in opt_ts:
         t = t // w * w
-        convert(audio_pad[s: t + self.t_pad2 + w], s // w, (t + self.t_pad2) // w)
+        collect(audio_pad[s: t + self.t_pad2 + w], pitch[:, s // w: (t + self.t_pad2) // w] if if_f0 else None,
+                pitchf[:, s // w: (t + self.t_pad2) // w] if if_f0 else None)
         s = t
-    convert(audio_pad[t:], (t // w) if t is not None else 0, None)
-    if batch:
-        segs = [o[self.t_pad_tgt: o.shape[0] - self.t_pad_tgt].float() for o in infer_segments(net_g, sid, items, times)]
-    audio_opt = torch.cat(segs).contiguous()
+    lo = (t // w) if t is not None else 0
+    collect(audio_pad[t:], pitch[:, lo:] if if_f0 else None, pitchf[:, lo:] if if_f0 else None)
+    return audio, len(opt_ts)
+
+
+def _finish_file(self, segs, audio, tgt_sr, resample_sr, rms_mix_rate):
+    """pipeline.py:344-360 on the device: concatenate the trimmed segments, ``change_rms``, (``resample_sr``: host, like the
+    reference), int16-range scaling, ONE copy to the host."""
+    import numpy as np
+
+    from . import glue
+
+    dev = torch.device(self.device)
+    audio_opt = torch.cat([o[self.t_pad_tgt: o.shape[0] - self.t_pad_tgt].float() for o in segs]).contiguous()
     if rms_mix_rate != 1:
         a16 = torch.as_tensor(np.ascontiguousarray(audio, dtype=np.float32), device=dev)
         audio_opt = glue.change_rms(a16, 16000, audio_opt, int(tgt_sr), float(rms_mix_rate))
     if tgt_sr != resample_sr >= 16000:
         # librosa's soxr resampler has no device twin (and no offline oracle): this one option goes through the host like the
         # reference (pipeline.py:351-354) and comes back for the scaling
-        host = ref.librosa.resample(audio_opt.cpu().numpy(), orig_sr=tgt_sr, target_sr=resample_sr)
+        host = _ref_module(self).librosa.resample(audio_opt.cpu().numpy(), orig_sr=tgt_sr, target_sr=resample_sr)
         audio_opt = torch.as_tensor(host, device=dev).float().contiguous()
     glue.scale_int16_range(audio_opt)
     return audio_opt.cpu().numpy()
+
+
+def pipeline_hip(self, model, net_g, sid, audio, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr,
+                 resample_sr, rms_mix_rate, version, protect, f0_file=None):
+    """Drop-in ``Pipeline.pipeline``: same arguments, same numpy return (float array scaled to the int16 range)."""
+    import os
+
+    index, needs_ref = _open_index(self, file_index, index_rate)
+    if needs_ref:
+        return pipeline_hip._rvcmi_original(self, model, net_g, sid, audio, times, f0_up_key, f0_method, file_index, index_rate, if_f0,
+                                            filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, f0_file)
+    dev = torch.device(self.device)
+    sid = torch.tensor(sid, device=dev).unsqueeze(0).long()
+    # segments of a long input: one net_g.infer call for all of them when the synthesizer is the HIP one (infer_segments above);
+    # RVCMI_PIPELINE_BATCH=0 (or a foreign net_g) keeps the reference's call-per-segment order
+    can_batch = _ragged_capable(net_g) and os.environ.get("RVCMI_PIPELINE_BATCH", "1") != "0"
+    pending, segs = [], []
+
+    def collect(a0, pt, pf):
+        pending.append((a0, pt, pf))
+
+    audio, ncuts = _prepare_file(self, model, sid, audio, times, f0_up_key, f0_method, if_f0, filter_radius, version, f0_file, collect)
+    if can_batch and ncuts > 0:
+        from time import time
+
+        t0 = time()
+        items = blend_segments([hubert_device(self, model, a0, pt, pf, version) for a0, pt, pf in pending], index, index_rate, protect)
+        times[0] += time() - t0
+        segs = infer_segments(net_g, sid, items, times)
+    else:
+        segs = [vc_device(self, model, net_g, sid, a0, pt, pf, times, index, index_rate, version, protect) for a0, pt, pf in pending]
+    return _finish_file(self, segs, audio, tgt_sr, resample_sr, rms_mix_rate)
+
+
+def convert_files(self, model, net_g, sid, audios, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr,
+                  resample_sr, rms_mix_rate, version, protect, f0_files=None):
+    """``Pipeline.pipeline`` for SEVERAL inputs in one go -- the body of ``VC.vc_multi``'s loop (infer/modules/vc/modules.py:201-266:
+    ``load_audio`` + ``vc_single`` -> ``pipeline`` per file of a folder) with the files batched on the GPU:
+
+      1. per file, as ``pipeline`` does it: high-pass, cut points, f0 (RMVPE on the device), HuBERT per segment;
+      2. ONE retrieval call for the HuBERT frames of every segment of every file (``blend_segments``: one coarse pass and one
+         list-major scan per ``MAX_BATCH_QUERIES`` frames instead of one per segment);
+      3. the segments of all files through ``net_g.infer`` as ragged batches (``infer_segments``, at most ``MAX_BATCH_FRAMES`` padded
+         frames per call): a 10 s clip alone fills the chip only in part of the generator (stage 0: 355 tiles on 256 CUs), a batch of
+         them does throughout (BASELINE configs[2]);
+      4. per file: trim + concatenate, ``change_rms``, scaling, one copy to the host.
+
+    ``audios``: list of 16 kHz float waveforms (``load_audio`` output); the other arguments are ``Pipeline.pipeline``'s, shared by all
+    files (``vc_multi`` passes the same sid / f0 method / index / rates for the whole folder); ``f0_files``: None or one entry per
+    input.  -> list of numpy arrays in input order.  Every item is computed exactly as its own call would compute it (same noise
+    draws in the same order, ragged batch items = separate calls; bit-equal with the ResBlock kernel family pinned, to operand
+    rounding otherwise), so the result does not depend on how the files are grouped.  A synthesizer that is not the HIP one, or an
+    index only real faiss reads, takes the plain per-file loop over ``self.pipeline``."""
+    audios = list(audios)
+    f0_files = list(f0_files) if f0_files is not None else [None] * len(audios)
+    if len(f0_files) != len(audios):
+        raise ValueError("f0_files must hold one entry per input")
+    index, needs_ref = _open_index(self, file_index, index_rate)
+    if needs_ref or not _ragged_capable(net_g):
+        return [self.pipeline(model, net_g, sid, a, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr,
+                              resample_sr, rms_mix_rate, version, protect, f) for a, f in zip(audios, f0_files)]
+    from time import time
+
+    dev = torch.device(self.device)
+    sid = torch.tensor(sid, device=dev).unsqueeze(0).long()
+    raw, owner, filtered = [], [], []
+    for i, (a, f0f) in enumerate(zip(audios, f0_files)):
+        def collect(a0, pt, pf, i=i):
+            t0 = time()
+            raw.append(hubert_device(self, model, a0, pt, pf, version))
+            owner.append(i)
+            times[0] += time() - t0
+
+        filtered.append(_prepare_file(self, model, sid, a, times, f0_up_key, f0_method, if_f0, filter_radius, version, f0f, collect)[0])
+    t0 = time()
+    items = blend_segments(raw, index, index_rate, protect)
+    times[0] += time() - t0
+    outs = infer_segments(net_g, sid, items, times)
+    res = []
+    for i in range(len(audios)):
+        res.append(_finish_file(self, [o for o, w in zip(outs, owner) if w == i], filtered[i], tgt_sr, resample_sr, rms_mix_rate))
+    return res

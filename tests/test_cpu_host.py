@@ -29,7 +29,7 @@ def test_library_exports_every_symbol_of_the_header():
         assert hasattr(lib, n), "librvcmi.so does not export %s" % n
     bound = {s[0] for s in _lib.SYMBOLS}
     assert bound == set(names), "python binding and header drifted: %s" % (bound ^ set(names))
-    assert _lib.lib().rvcmi_version() == 1
+    assert _lib.lib().rvcmi_version() == _lib.RVCMI_VERSION == 2
 
 
 def test_struct_layout_matches_the_header():
@@ -151,6 +151,27 @@ def _convert_batch_worker(rank, world, port, n_files):
         assert [p for p, _ in res] == paths[lo:hi]
     own = convert_batch(paths, lambda p, ix: p.upper(), gather=False, device=torch.device("cpu"))
     assert own == [(p, p.upper()) for p in paths[lo:hi]]
+    # convert_many: the rank's shard in ONE call (rvc_amd.pipeline.convert_files batches the files on the GPU); a failing batch is
+    # retried file by file so that the failure stays with its file
+    batches = []
+
+    def many(ps, index):
+        batches.append(list(ps))
+        if "clip_03.wav" in ps:
+            raise ValueError("cannot decode clip_03.wav")
+        return [p.upper() for p in ps]
+
+    own = convert_batch(paths, index="added.index", gather=False, device=torch.device("cpu"), convert_many=many)
+    assert batches[0] == paths[lo:hi]
+    exp = [(p, p.upper()) for p in paths[lo:hi]]
+    if "clip_03.wav" in paths[lo:hi]:
+        assert batches[1:] == [[p] for p in paths[lo:hi]]
+        assert [r for p, r in own if p != "clip_03.wav"] == [p.upper() for p in paths[lo:hi] if p != "clip_03.wav"]
+        assert "cannot decode" in dict(own)["clip_03.wav"]
+    else:
+        assert own == exp and len(batches) == 1
+    with pytest.raises(ValueError):
+        convert_batch(paths, gather=False, device=torch.device("cpu"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -417,7 +438,9 @@ def test_infer_segments_batches_pads_and_draws_noise_like_sequential_calls():
 
     infer._rvcmi_ragged = True
     net_g = types.SimpleNamespace(infer=infer, dec=types.SimpleNamespace(upp=upp, cfg={"inter_channels": IC}))
-    assert pl._ragged_capable(net_g) and not pl._ragged_capable(types.SimpleNamespace(infer=lambda *a, **k: None))
+    # a ragged-capable `infer` is not enough: the generator behind it must be the HIP one, which alone can be told the lengths
+    # (the positive case runs on the GPU: tests/test_gpu_dropin.py drives the batch path through it)
+    assert not pl._ragged_capable(net_g) and not pl._ragged_capable(types.SimpleNamespace(infer=lambda *a, **k: None))
     lens = [5, 9, 3, 7]
     items = []
     for i, T in enumerate(lens):

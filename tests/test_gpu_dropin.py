@@ -477,6 +477,111 @@ def test_segments_of_a_file_in_one_batched_call_equal_the_sequential_pipeline(rv
     assert not np.array_equal(res[0][0], out_b)  # (different noise than the reference's CPU draws)
 
 
+def test_convert_files_batches_several_files_and_equals_the_per_file_pipeline(rvc_tree, gpu, tmp_path, monkeypatch):
+    """``Pipeline.convert_files`` (bound by ``install()``; ``rvc_amd.pipeline.convert_files``) = the loop body of ``VC.vc_multi``
+    (infer/modules/vc/modules.py:201-266) for several inputs at once: five 16 kHz inputs of different lengths (one, two and three
+    segments; the WebUI-default configuration with an index FILE, rmvpe, rms_mix_rate 0.25, protect 0.33).
+
+      * every waveform is BIT-equal to what ``Pipeline.pipeline`` returns for that file alone (same seed: the noise of every segment
+        is drawn in the order of the sequential loop; ResBlock kernel family pinned, since a batch and a single clip may otherwise
+        pick different families per stage);
+      * the HuBERT frames of ALL segments of ALL files go through ONE retrieval call, the segments through ragged ``net_g.infer``
+        batches, and exactly one tensor per file crosses to the host;
+      * the fixture file (first in the list, reference noise injected for its three segments) is within 1e-3 of the waveform the REAL
+        reference ``Pipeline.pipeline`` returned (golden pipeline_v2_48k_webui)."""
+    import functools
+    import types
+
+    import rvc_amd
+    from oracle import ivf_oracle as io
+    from rvc_amd.front import infer_hip
+
+    d = load_golden("pipeline_v2_48k_webui")
+    seed = int(d["seed"])
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    rvc_amd.install(device=gpu, operand="fp16")
+    import infer.modules.vc.pipeline as pl
+    import rvc.synthesizer as rs
+
+    assert pl.Pipeline.convert_files is rvc_amd.pipeline.convert_files
+    net_g, _ = rs.get_synthesizer(make_cpt(seed), gpu)
+    for key, val in (("RB_STREAM", 0), ("NO_RB_SPLIT", 1)):  # same kernel family for every batch size
+        net_g.dec.set_option(key, val)
+    config = types.SimpleNamespace(device=gpu, **{k[4:]: (bool(d[k]) if k == "cfg_is_half" else int(d[k])) for k in d if k.startswith("cfg_")})
+    pipe = pl.Pipeline(cfg.sr, config)
+    fake = synth.FakeRMVPE(gpu, seed)
+    pipe.f0_gen = types.SimpleNamespace(rmvpe=fake, is_half=False, device=gpu)  # no ``calculate``: a host fallback would raise
+    path = str(tmp_path / "added.index")
+    io.write_index(synth.make_ivf(int(d["index_n"]), int(d["index_d"]), seed=int(d["index_seed"])), path)
+    n0 = int(d["n_audio"])
+    audios = [synth.make_audio16k(n0, seed), synth.make_audio16k(16000 * 2 + 77, seed + 1), synth.make_audio16k(n0 // 2 + 4321, seed + 2),
+              synth.make_audio16k(16000, seed + 3), synth.make_audio16k(n0 - 16000 * 3, seed + 4)]
+    hub = synth.FakeHubert(768, seed)
+    tail = (int(d["f0_up_key"]), "rmvpe", path, float(d["index_rate"]), 1, int(d["filter_radius"]), cfg.sr, 0, float(d["rms_mix_rate"]),
+            "v2", float(d["protect"]))
+    # --- per file, the rebound Pipeline.pipeline
+    torch.manual_seed(5)
+    seq = [pipe.pipeline(hub, net_g, int(d["sid"]), a.copy(), [0, 0, 0], *tail) for a in audios]
+    state_seq = torch.cuda.get_rng_state(gpu).clone()
+    nseg = hub.calls
+    assert nseg > len(audios) and fake.model.calls == len(audios)  # (some files have several segments)
+    # --- all files at once
+    searches, infers = [], []
+    real_blend = rvc_amd.glue._blend_expand_into
+    monkeypatch.setattr(rvc_amd.glue, "_blend_expand_into", lambda out, f, index, *a: (searches.append((int(f.shape[0]), index is not None)), real_blend(out, f, index, *a))[1])
+    base = net_g.infer
+
+    def counting_infer(phone, lengths, *a, **k):
+        infers.append([int(x) for x in lengths.tolist()])
+        return base(phone, lengths, *a, **k)
+
+    counting_infer._rvcmi_ragged = True
+    net_g.infer = counting_infer
+    spy = _CpuSpy(monkeypatch)
+    hub.calls = 0
+    times = [0, 0, 0]
+    torch.manual_seed(5)
+    bat = pipe.convert_files(hub, net_g, int(d["sid"]), [a.copy() for a in audios], times, *tail)
+    assert torch.equal(torch.cuda.get_rng_state(gpu), state_seq)  # the same draws from the seeded generator
+    assert hub.calls == nseg and len(bat) == len(audios)
+    assert len(searches) == 1 and searches[0][1], searches          # ONE retrieval call for every segment of every file
+    assert sum(len(c) for c in infers) == nseg and len(infers) == 1, infers  # one ragged batch (well under MAX_BATCH_FRAMES)
+    assert spy.calls == [tuple(o.shape) for o in bat], "host hops: %s" % spy.calls  # one per file: the finished audio
+    for i, (o, r) in enumerate(zip(bat, seq)):
+        assert o.shape == r.shape and np.array_equal(o, r), "file %d: batched vs per-file max diff %g" % (i, float(np.abs(o - r).max()))
+    assert times[0] > 0 and times[1] > 0 and times[2] > 0
+    # --- bounded batches: the same result in several ragged calls / several retrieval calls
+    monkeypatch.setattr(rvc_amd.pipeline, "MAX_BATCH_FRAMES", 2 * max(max(c) for c in infers))
+    monkeypatch.setattr(rvc_amd.pipeline, "MAX_BATCH_QUERIES", 400)
+    del searches[:], infers[:]
+    torch.manual_seed(5)
+    bat2 = pipe.convert_files(hub, net_g, int(d["sid"]), [a.copy() for a in audios], [0, 0, 0], *tail)
+    assert len(infers) > 1 and len(searches) > 1
+    for o, r in zip(bat2, seq):
+        assert np.array_equal(o, r)
+    # --- the fixture file against the REAL reference's output: its three segments get the reference's noise draws
+    noise = synth.infer_noise([int(x) for x in d["seg_frames"]], cfg.upp)
+    raw_infer = functools.partial(infer_hip, net_g, net_g._rvcmi_front)
+
+    def infer_with_reference_noise(phone, lengths, sid, *a, **k):
+        nz, nd = k["noise_zp"].clone(), k["noise_dec"].clone()  # (infer_segments drew them; items 0..2 are the fixture file's segments)
+        for b, (z_b, d_b) in enumerate(noise):
+            n = z_b.shape[2]
+            assert int(lengths[b]) == n
+            nz[b, :, :n], nd[b, :n * cfg.upp] = z_b[0].to(gpu), d_b[0].to(gpu)
+        k["noise_zp"], k["noise_dec"] = nz, nd
+        return raw_infer(phone, lengths, sid, *a, **k)
+
+    infer_with_reference_noise._rvcmi_ragged = True
+    net_g.infer = infer_with_reference_noise
+    monkeypatch.setattr(rvc_amd.pipeline, "MAX_BATCH_FRAMES", 32768)
+    out = pipe.convert_files(hub, net_g, int(d["sid"]), [a.copy() for a in audios], [0, 0, 0], *tail)[0]
+    e = rms(out / 32768.0, d["out"] / 32768.0)
+    assert out.shape == d["out"].shape and e <= 1e-3, "fixture file inside a five-file batch: RMS %.3e vs the reference" % e
+    rvc_amd.uninstall()
+    assert not hasattr(pl.Pipeline, "convert_files")
+
+
 def test_front_at_benchmark_size_matches_the_reference_modules(gpu):
     """enc_p + z_p + flow^-1 at T = 1198 (global attention over the whole 10 s clip) against the REFERENCE modules' own output
     (fixture bigfront_v2_B1_T1198_z), not only against the oracle restatement."""

@@ -29,26 +29,10 @@ def hip_gen(cfg, w, operand, gpu):
     return _gens[key]
 
 
-DEV_KEYS = ("RS_V2", "RS_V3", "RS_V2X")  # the opt-in streaming variants: only in a library built with RVCMI_DEV_VARIANTS
-
-
 def pin(gen, **opts):
     """Test options of ONE handle (rvcmi_nsf_set_option): e.g. RB_STREAM=1 forces the streaming ResBlock kernels, RS_SMALL picks
-    their tile height; None restores the launcher's own choice.  A dev-variant key (k_rb_stream2 / 2x / 3) that is switched ON
-    skips the test when the loaded library was built without those kernels (the default build: an unknown option key is an
-    error, never silently ignored); switched off / restored it is simply not sent."""
-    import rvc_amd
-
+    their tile height; None restores the launcher's own choice (an unknown option key is an error, never silently ignored)."""
     for k, v in opts.items():
-        if k in DEV_KEYS:
-            try:
-                gen.set_option(k, v)
-            except rvc_amd.RvcmiError as e:
-                if "unknown option" not in str(e):
-                    raise
-                if v:
-                    pytest.skip("dev variant %s is not compiled into this librvcmi.so (RVCMI_DEFINES=RVCMI_DEV_VARIANTS)" % k)
-            continue
         gen.set_option(k, v)
     return gen
 
@@ -274,13 +258,9 @@ def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
     har = gen.debug_tap("har", zd, fd, gd, noise=nd)
     rel = rms(har, taps["har"]) / float(taps["har"].pow(2).mean().sqrt())
     assert rel <= 1e-6, "har (sine source over 1198 voiced frames): relative RMS %.2e" % rel
-    # every streaming ResBlock kernel of the C = 128 stage on the whole clip: k_rb_stream, k_rb_stream3 (half-step slots),
-    # k_rb_stream2x (two anti-phased strips per block, both K loops)
-    for small in ("1", "kl2", "v3", "v2x", "v2x2"):
-        try:
-            pin(gen, **_rs_opts(small))
-        except pytest.skip.Exception:  # a dev variant that is not compiled into this library
-            continue
+    # both K loops of the streaming ResBlock kernel of the C = 128 stage on the whole clip
+    for small in ("1", "kl2"):
+        pin(gen, **_rs_opts(small))
         o = gen(zd, fd, gd, noise=nd).cpu()
         assert torch.isfinite(o).all() and rms(o, d["out"]) <= 1e-3, "%s: RMS %.3e vs the reference waveform" % (small, rms(o, d["out"]))
         assert rms(o, out) <= 5e-4
@@ -302,7 +282,7 @@ def test_full_clip_voiced_whole_waveform_vs_reference_golden_and_oracle(gpu):
     assert rms(gen32(zd, fd, gd, noise=nd).cpu(), d["out"]) <= 2e-5
 
 
-@pytest.mark.parametrize("rb_stream", ["0", "1", "v3", "v2x", "kl2"])
+@pytest.mark.parametrize("rb_stream", ["0", "1", "kl2"])
 def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu):
     """BASELINE configs[2] geometry (grid.z = batch, multi-GB streams, the large-batch launch shapes): 16 different full-size
     voiced clips in one call; every item must be BIT-equal to the same clip run alone -- with the ResBlock kernel family
@@ -321,8 +301,7 @@ def test_batch_16_full_clips_equal_their_single_clip_results(rb_stream, gpu):
         ns.append(nsf_oracle.reference_noise(1, T, cfg.upp, 114514 + b))
     Z, F, G, N = torch.cat(zs).to(gpu), torch.cat(fs).to(gpu), torch.cat(gs).to(gpu), torch.cat(ns).to(gpu)
     gen = pin(rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=B, max_T=T),
-              RB_STREAM=int(rb_stream) if rb_stream in "01" else 1, RS_V3=int(rb_stream == "v3"), RS_V2X=int(rb_stream == "v2x"),
-              RS_KL=2 if rb_stream == "kl2" else 1)
+              RB_STREAM=int(rb_stream) if rb_stream in "01" else 1, RS_KL=2 if rb_stream == "kl2" else 1)
     out = gen(Z, F, G, noise=N)
     assert out.shape == (B, 1, T * cfg.upp) and torch.isfinite(out).all()
     d = load_golden("full_v2_48k_T1198_voiced")
@@ -370,28 +349,19 @@ def test_batch_64_bench_config_3_geometry(gpu):
 # ---- streaming fused ResBlock kernel (csrc/rb_stream_kernels.hpp) -------------------------------------------------------
 # At full clip size the launcher picks it by itself (the full-size tests above run it); option RB_STREAM=1 forces it for
 # the small golden cases too (single short strips, sequence ends inside the first step), RS_SMALL selects the time-tile
-# height, RS_V2=1 the two-blocks-per-CU variant k_rb_stream2 (csrc/rb_stream2_kernels.hpp), RS_V3=1 / 0 the variant with the
-# publish work in the MFMA shadow, k_rb_stream3 (csrc/rb_stream3_kernels.hpp), and its absence.
+# height, RS_KL the K loop (1 = conv_run, 2 = the lean kconv with the coalesced step IO: the shipped default).
 
 def _rs_opts(small):
-    """test parameter -> options of the streaming ResBlock launcher (every variant pinned on or off explicitly)"""
-    o = {"RS_SMALL": None, "RS_V2": 0, "RS_V3": 0, "RS_V2X": 0, "RS_KL": 1}
-    if small == "v2":
-        o["RS_V2"] = 1
-    elif small == "v3":
-        o["RS_V3"] = 1
-    elif small == "v2x":     # two anti-phased strips per 8-wave block, K loop with B fragments one k-step ahead
-        o["RS_V2X"] = 1
-    elif small == "v2x2":    # ... two k-steps ahead, one s_waitcnt per k-step
-        o["RS_V2X"] = 2
-    elif small == "kl2":     # k_rb_stream with the lean K loop (kconv), dual-written X tail, LDS-only barriers
+    """test parameter -> options of the streaming ResBlock launcher (tile height and K loop pinned explicitly)"""
+    o = {"RS_SMALL": None, "RS_KL": 1}
+    if small == "kl2":     # k_rb_stream with the lean K loop (kconv), dual-written X tail, LDS-only barriers
         o["RS_SMALL"], o["RS_KL"] = 1, 2
     else:
         o["RS_SMALL"] = int(small)
     return o
 
 
-@pytest.mark.parametrize("small", ["0", "1", "v2", "v3", "v2x", "v2x2", "kl2"])
+@pytest.mark.parametrize("small", ["0", "1", "kl2"])
 @pytest.mark.parametrize("name", ["dec_v2_48k_B1_T70", "dec_v2_48k_B2_T24", "dec_v1_40k_B1_T20", "dec_v1_32k_B1_T16",
                                   "dec_nof0_v2_48k_B1_T16", "dec_v1_40k_nres_T31"])
 def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu):
@@ -408,7 +378,7 @@ def test_streaming_resblock_kernel_on_reference_goldens(name, small, gpu):
         assert e <= BAR[operand], "%s/%s (streaming resblocks): RMS error %.3e" % (name, operand, e)
 
 
-@pytest.mark.parametrize("small", ["0", "1", "v2", "v3", "v2x", "v2x2", "kl2"])
+@pytest.mark.parametrize("small", ["0", "1", "kl2"])
 def test_streaming_resblock_kernel_stage_taps_and_many_strips(small, gpu):
     """Forced onto a clip of 300 frames: hundreds of strips of one to three steps each (every strip boundary, warm-up
     and tail case), batch of 2 with different inputs; per-stage taps and the waveform against the oracle."""

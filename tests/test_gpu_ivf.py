@@ -276,6 +276,151 @@ def test_stress_size_ranking_properties(gpu):
         assert np.array_equal(D[i], dd[order].astype(np.float32))
 
 
+def _path_names(h, fn):
+    """Runs fn() with the handle's profiler on -> (result, set of launch names): 'ivf_plan' / 'ivf_select' = the list-major kernels."""
+    h.profile(True)
+    r = fn()
+    names = {st["name"] for st in h.profile_read()}
+    h.profile(False)
+    return r, names
+
+
+def _assert_equal_to_c_oracle(idx, h, q, gpu, what, blend_rate=0.75):
+    """ids bit-equal on every query; distances bit-equal after the fp64 -> fp32 rounding except where the two fp64 summation orders
+    (the C loop adds in element order, the wave adds 64 lane partials) straddle an fp32 rounding boundary: at most a handful of
+    1-ulp cases in 300 000 distances; fused search + blend <= 1e-5 RMS against the C blend of the oracle's own (D, P)."""
+    Dr, Ir, Pr = ivf_oracle.search_c(idx, q, 8)
+    (D, I), names = _path_names(h, lambda: h.search(q, 8))
+    assert {"ivf_plan", "ivf_select"} <= names, "%s: the list-major kernels did not run (%s)" % (what, names)
+    bad = int((I != Ir).sum())
+    assert bad == 0, "%s: %d of %d ids differ from the fp64 oracle (first query %d)" % (what, bad, I.size, int(np.argwhere(I != Ir)[0][0]))
+    neq = D != Dr
+    if neq.any():
+        ulp = np.abs(D.view(np.int32).astype(np.int64) - Dr.view(np.int32).astype(np.int64))
+        assert int(neq.sum()) <= 8 and int(ulp.max()) <= 1, "%s: %d distances differ, up to %d ulp" % (what, int(neq.sum()), int(ulp.max()))
+    feats = torch.from_numpy(q).to(gpu).contiguous()
+    _, names = _path_names(h, lambda: h.search_blend(feats, blend_rate, 8))
+    assert {"ivf_plan", "ivf_select"} <= names, names
+    exp = ivf_oracle.blend_c(idx, q, Dr, Pr, blend_rate)
+    got = feats.cpu().numpy()
+    fin = np.isfinite(exp).all(1)  # (an exact hit -> distance 0 -> weight inf -> NaN row, in numpy as on the device)
+    assert np.array_equal(np.isfinite(got).all(1), fin)
+    e = float(np.sqrt(np.mean((got[fin].astype(np.float64) - exp[fin]) ** 2)))
+    assert e <= 1e-5, "%s: blend RMS %.2e" % (what, e)
+    return int(neq.sum())
+
+
+def test_batch_scale_on_the_bench_index_equals_the_oracle(gpu):
+    """BASELINE configs[2]: 64 clips x 599 queries = 38 336 queries in ONE call against the 10000 x 768 index of bench.py -- the
+    list-major path with many 32-query tiles per list (fp32 near-ties become expected at this scale; the fp64
+    verification margin of k_lm_select is what keeps the answer exact).  Checked on EVERY query against the OpenMP C oracle."""
+    idx = synth.make_ivf(10000, 768, seed=4321, kmeans_iters=1)  # bench.py's index
+    q = synth.make_phone(64, 599, 768, seed=1234).reshape(-1, 768).numpy()  # bench.py's queries (rank 0)
+    q[7] = idx["xb"][123]  # one exact hit
+    h = make(idx, gpu)
+    _assert_equal_to_c_oracle(idx, h, q, gpu, "10000 x 768, 38336 queries")
+    # the same queries in the query-major kernel (IVF_LM=0): the same bits
+    D1, I1 = h.search(q[:4096], 8)
+    h.set_option("IVF_LM", 0)
+    (D0, I0), names = _path_names(h, lambda: h.search(q[:4096], 8))
+    assert "ivf_plan" not in names and np.array_equal(I0, I1) and np.array_equal(D0, D1)
+
+
+def test_batch_scale_on_the_config3_index_equals_the_oracle(gpu, tmp_path):
+    """BASELINE configs[3] exactly as ``bench.py --config 3`` builds it: 1 000 000 x 256 clustered rows, nlist 16000 (of the
+    planner's 16 384), trained on the GPU (``rvcmi_ivf_build``, 2 iterations, seed 4321), one rank's 64 x 599 = 38 336 queries."""
+    import rvc_amd
+
+    n, d = 1_000_000, 256
+    nlist = synth.ivf_nlist(n)
+    assert nlist == 16000
+    rows = synth.make_clustered_rows(n, d, nlist, seed=4321)
+    h = rvc_amd.IVFFlatHIP.train(rows, nlist=nlist, niter=2, seed=4321, device=gpu)
+    del rows
+    path = str(tmp_path / "config3.index")
+    rvc_amd.write_index(h, path)
+    idx = ivf_oracle.read_index(path)  # the host copy of what the GPU built: the oracle searches THAT index
+    assert idx["ntotal"] == n and idx["nlist"] == nlist and int(np.diff(idx["list_offsets"]).max()) <= 2048
+    q = synth.make_phone(64, 599, d, seed=1234).reshape(-1, d).numpy()
+    _assert_equal_to_c_oracle(idx, h, q, gpu, "1M x 256 (GPU-trained), 38336 queries")
+
+
+def _tiny_index(sizes, d, seed=0, spread=0.05):
+    """An IVF layout with GIVEN list sizes: centroid c far from the others, its rows a tight cloud around it."""
+    rng = np.random.default_rng(seed)
+    nlist = len(sizes)
+    cent = (rng.standard_normal((nlist, d)) * 4.0).astype(np.float32)
+    off = np.zeros(nlist + 1, np.int64)
+    np.cumsum(np.asarray(sizes, np.int64), out=off[1:])
+    n = int(off[-1])
+    lab = np.repeat(np.arange(nlist), sizes)
+    vecs = (cent[lab] + spread * rng.standard_normal((n, d))).astype(np.float32)
+    ids = rng.permutation(n).astype(np.int64)
+    return dict(d=d, ntotal=n, nlist=nlist, nprobe=1, centroids=cent, list_offsets=off, ids=ids, vecs=vecs)
+
+
+@pytest.mark.parametrize("case", ["nlist_16384", "nlist_16385", "list_2048", "list_2049", "d_64", "d_48", "nq_64", "nq_63"])
+def test_list_major_boundaries_pin_the_path_and_both_paths_agree(case, gpu, capfd):
+    """The limits of the list-major kernels (ivf.hip ``lm_unusable_reason``): the planner counts at most 16 384 lists in LDS, the selector
+    stages a score row of at most 2048 entries, the MFMA K chunk wants d % 32 == 0, and below 64 queries the one-launch query-major
+    kernel is kept.  On each side of each limit: WHICH path ran (profiler names), that its answer equals the fp64 oracle, and -- a
+    call of 64 queries or more that has to fall back says so ONCE on stderr instead of silently re-reading every list per query."""
+    rng = np.random.default_rng(7)
+    nq, d = 128, 32
+    if case.startswith("nlist"):
+        nlist = int(case.split("_")[1])
+        idx = _tiny_index([2] * nlist, d, seed=1)
+    elif case.startswith("list"):
+        idx = _tiny_index([int(case.split("_")[1]), 5, 0, 40, 9], d, seed=2)
+    elif case.startswith("d_"):
+        d = int(case.split("_")[1])
+        idx = _tiny_index([40, 3, 70, 0, 12, 33], d, seed=3)
+    else:
+        nq = int(case.split("_")[1])
+        idx = _tiny_index([40, 3, 70, 0, 12, 33], d, seed=4)
+    lm = case in ("nlist_16384", "list_2048", "d_64", "nq_64")
+    # queries near the centroids of a few lists (the long list first), one of them an exact stored row
+    pick = rng.integers(0, min(idx["nlist"], 64), size=nq)
+    pick[: nq // 2] = 0
+    q = (idx["centroids"][pick] + 0.05 * rng.standard_normal((nq, d))).astype(np.float32)
+    q[1] = idx["vecs"][0]
+    h = make(idx, gpu)
+    capfd.readouterr()
+    (D, I), names = _path_names(h, lambda: h.search(q, 8))
+    err = capfd.readouterr().err
+    assert ("ivf_plan" in names) == lm and ("ivf_select" in names) == lm, (case, names)
+    if lm or nq < 64:
+        assert "query-major scan" not in err, err
+    else:
+        assert err.count("query-major scan") == 1 and {"nlist_16385": "16384 lists", "list_2049": "2048 rows", "d_48": "multiple of 32"}[case] in err, err
+        h.search(q, 8)
+        assert "query-major scan" not in capfd.readouterr().err  # once per index
+    Dr, Ir, _ = ivf_oracle.search_c(idx, q, 8)
+    assert np.array_equal(I, Ir), "%s: %d ids differ" % (case, int((I != Ir).sum()))
+    assert np.array_equal(D, Dr)
+    # the other path on the same call (forced): identical bits
+    if lm:
+        h.set_option("IVF_LM", 0)
+        (D2, I2), names2 = _path_names(h, lambda: h.search(q, 8))
+        assert "ivf_plan" not in names2 and np.array_equal(I2, I) and np.array_equal(D2, D)
+
+
+def test_reserve_beyond_the_scratch_bound_retires_the_list_major_buffers(gpu):
+    """``reserve`` above the 1 GiB score-scratch bound used to leave the list-major buffers at their earlier, smaller
+    size while raising the handle's query capacity -- a later search under the bound then ran the list-major kernels past those
+    buffers.  Now the big reserve retires them and the next call that fits re-reserves them at ITS size: exact results, no overrun."""
+    idx = _tiny_index([1500, 40, 7, 0, 300], 32, seed=5)
+    h = make(idx, gpu)
+    q = (idx["centroids"][np.zeros(4096, np.int64)] + 0.05 * np.random.default_rng(1).standard_normal((4096, 32))).astype(np.float32)
+    (_, I0), names = _path_names(h, lambda: h.search(q[:128], 8))  # list-major scratch sized for 128 queries
+    assert "ivf_plan" in names
+    h.reserve(200_000)  # 200000 x 1504 x 4 B = 1.2 GB > 1 GiB: no list-major scratch for THIS capacity
+    (D, I), names = _path_names(h, lambda: h.search(q, 8))  # 4096 queries <= the handle's capacity, 32x the old scratch
+    assert "ivf_plan" in names
+    Dr, Ir, _ = ivf_oracle.search_c(idx, q, 8)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr) and np.array_equal(I[:128], I0)
+
+
 def test_index_build_kmeans_lists_and_roundtrip(gpu, tmp_path):
     """web.py:544-571 on the GPU: k-means objective never increases, every vector sits in the list of its exact (fp64) nearest
     centroid with ids ascending inside a list, every centroid is the mean of its list after convergence steps, a vector
