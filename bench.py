@@ -345,9 +345,25 @@ def stream_mode(a):
 
     st, cap = _time_chunks(hot, graph=bool(a.graph))
     assert torch.isfinite(hold["o"]).all()
+
+    def kernel_breakdown(fn, handles, n=50):
+        """us per chunk of every launch (HIP events around each launch, eager, AFTER the timed chunks): where a chunk's time goes"""
+        for h_ in handles:
+            h_.profile(True)
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        out = {}
+        for h_ in handles:
+            for s_ in h_.profile_read():
+                out[s_["name"]] = round(1e3 * s_["ms"] / n, 2)
+            h_.profile(False)
+        return out
+
+    hot_kernels = kernel_breakdown(hot, [index, gen])
     line = {"metric": "realtime chunk latency p50 (retrieval + NSF decode), v1/40k, 256 ms block", "value": st["p50_ms"],
             "unit": "ms", "p90": st["p90_ms"], "p99": st["p99_ms"], "higher_is_better": False, "n_gpus": 1, "dtype": a.operand,
-            "data": "synthetic", "hot_path": st,
+            "data": "synthetic", "hot_path": dict(st, kernels_us_per_chunk=hot_kernels),
             "config": {"workload": "BASELINE configs[4] (hot path only): T=31 frames -> 12400 samples, 16 queries", "hipgraph": cap}}
     if a.operand != "fp32" and a.index_d == 768:
         # the whole RVC.infer of the realtime loop after HuBERT / f0 (infer/lib/rtrvc.py:163-251, gui.py:1057-1090):
@@ -382,6 +398,7 @@ def stream_mode(a):
 
         st2, cap2 = _time_chunks(whole, graph=bool(a.graph))
         assert torch.isfinite(hold["w"]).all()
+        st2 = dict(st2, kernels_us_per_chunk=kernel_breakdown(whole, [index, front, gen]))
         line["whole_chunk"] = dict(st2, what="retrieval (16 rows, guarded) + x2 + protect + enc_p(282) + flow(56) + decode(31) + SOLA", hipgraph=cap2)
     emit(line)
 

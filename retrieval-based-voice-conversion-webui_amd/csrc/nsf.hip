@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -438,6 +438,13 @@ static void launch_ups_inst(UpsArgs a, int nj, int B, hipStream_t st) {
         } else {
             a.out_tr = 0;
         }
+    }
+    if (a.bias_off && a.cout % 4 == 0) {  // option UPS_BL: [2][cout] fp32 LDS copy of bias / bn behind everything else
+        smem = (smem + 15) / 16 * 16;
+        a.bias_off = (int)smem;
+        smem += (size_t)2 * a.cout * 4;
+    } else {
+        a.bias_off = 0;
     }
     if (nj == 4) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 4>), grid, dim3(256), smem, st, a);
     else if (nj == 2) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 2>), grid, dim3(256), smem, st, a);
@@ -874,6 +881,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             UpsArgs ua;
             memset(&ua, 0, sizeof(ua));
             ua.dbg = dbg_flags(h);
+            ua.bias_off = h->opt.geti("UPS_BL", 1) != 0 ? 1 : 0;  // (the launcher turns it into the LDS offset)
             ua.in_a = y[0];
             ua.in_b = y[1];
             ua.in_c = y[2];

@@ -1118,6 +1118,9 @@ constexpr int RB_ROWS = 128;  // default conv1 output rows per tile = 4 MFMA col
 
 // Waves are laid out NW (output-channel slices of 32*MI) x NWT (time slabs of 32*NJ_ rows); OCC = waves per SIMD the
 // register budget is capped for.
+// (Round 5, measured and removed: the lean K loop kconv + LDS-only barriers of k_rb_stream for the C = 256 instantiation -- 253 registers, no
+//  spills, parity-green -- ran 0.295 -> 0.320 ms per clip, ABAB x 3 on one lease: with two co-resident blocks at pair level 0 the group
+//  structure of conv_run was never the limit, and kconv's 8-deep ring holds twice the weight registers.  DESIGN.md 4f.)
 template <typename OpT, int C, int MI, int NW, int KG, int NJ_ = RB_ROWS / 32, int NWT = 1, int OCC = 2>
 static __global__ void __launch_bounds__(64 * NW * NWT, OCC) k_rb_pair(RbPairArgs a) {
     constexpr int ROWS = 32 * NJ_ * NWT;  // conv1 output rows per tile
@@ -1346,6 +1349,8 @@ struct UpsArgs {
     int nz_k1;         // 1: the <=16-tap noise conv runs as one extra k-step fed from an fp16 copy of the har span in LDS
     int nvt, cog, vpw;
     int dbg;  // timing ablations only: 1 skip staging loads, 2 skip MFMA, 4 skip noise conv, 16 skip store
+    int bias_off;      // > 0: byte offset of a [2][cout] fp32 LDS copy of bias / bn, staged with the tile (round 5: the epilogue's bias
+                       // vectors were a dependent global round trip behind the K loop of every virtual tile)
 };
 
 template <typename OpT, int CIN, int MI, int WV, int NJ = 4>
@@ -1389,6 +1394,10 @@ static __global__ void __launch_bounds__(256, UPS_OCC) k_ups(UpsArgs a) {  // 2 
             const float v = hp[idc];
             hpre[j] = (idx >= 0 && idx < Lhb && (int)threadIdx.x + 256 * j < hspan) ? v : 0.f;
         }
+    }
+    float* bias_l = (float*)(smem + a.bias_off);
+    if (a.bias_off) {
+        for (int i = threadIdx.x; i < 2 * a.cout; i += 256) bias_l[i] = i < a.cout ? a.bias[i] : (a.bn ? a.bn[i - a.cout] : 0.f);
     }
     const int total = a.tile_rows * C8;
     for (int base = threadIdx.x; base < total; base += SB * 256) {
@@ -1495,6 +1504,8 @@ static __global__ void __launch_bounds__(256, UPS_OCC) k_ups(UpsArgs a) {  // 2 
         // (requesting the epilogue's bias vectors here, before the K loop, costs 78 registers = one resident block per CU:
         //  ups_c128 65 -> 78 us on one lease, ABAB.  Occupancy, not the number of dependent round trips, is what this kernel lives on.)
 // (a 4-group weight ring for the one-tile waves: 148 -> 200 VGPRs, 3 -> 2 blocks per CU; C_in 256 unchanged, 128 slower)
+        // (round 5, measured: requesting the first virtual tile's weights BEFORE the staging -- conv_prefetch hoisted, conv_run here -- costs
+        //  154 -> 214 registers at C_in = 128 / 256, i.e. 3 -> 2 resident blocks, like every other value held across the staging)
         if (!(a.dbg & 2)) conv_core<OpT, CIN, MI, NJ>(acc, lds_lane, wlane, a.ct_stride, a.ntaps_p, a.ph_in_off[r] - a.lo, -1);
         if (a.nz_k1) {  // + noise_convs[i](har): one k-step, B = the row's 16-sample window (nsf.py:173-174)
             frag An[MI], Bn[NJ];
@@ -1553,10 +1564,12 @@ static __global__ void __launch_bounds__(256, UPS_OCC) k_ups(UpsArgs a) {  // 2 
                         const int co = (ct0 + mi) * 32 + 8 * g + 4 * (lane >> 5);
                         if (co >= a.cout) continue;
                         f32x4 v = {acc[mi][jt][4 * g + 0], acc[mi][jt][4 * g + 1], acc[mi][jt][4 * g + 2], acc[mi][jt][4 * g + 3]};
-                        v += *(const f32x4*)(a.bias + co);
-                        if (har) v += nv[mi][g] + *(const f32x4*)(a.bn + co);  // x + (noise_conv + its bias), nsf.py:173-174
+                        const float* bsrc = a.bias_off ? bias_l : a.bias;
+                        const float* bnsrc = a.bias_off ? bias_l + a.cout : a.bn;
+                        v += *(const f32x4*)(bsrc + co);
+                        if (har) v += nv[mi][g] + *(const f32x4*)(bnsrc + co);  // x + (noise_conv + its bias), nsf.py:173-174
                         else if (addend) v += nv[mi][g];                       // the addend already carries the noise bias
-                        else if (a.nz_k1) v += *(const f32x4*)(a.bn + co);
+                        else if (a.nz_k1) v += *(const f32x4*)(bnsrc + co);
                         if (a.out_tr) {  // row (q - q0) * u + r of the block's output tile; row pitch = cout elements + 16 bytes
                             const int orow = (tw0 + jt * 32 + (lane & 31)) * a.u + r;
                             char* ot = smem + a.out_tr_off;

@@ -421,8 +421,8 @@ def convert_files(self, model, net_g, sid, audios, times, f0_up_key, f0_method, 
     ``audios``: list of 16 kHz float waveforms (``load_audio`` output); the other arguments are ``Pipeline.pipeline``'s, shared by all
     files (``vc_multi`` passes the same sid / f0 method / index / rates for the whole folder); ``f0_files``: None or one entry per
     input.  -> list of numpy arrays in input order.  Every item is computed exactly as its own call would compute it (same noise
-    draws in the same order, ragged batch items = separate calls; bit-equal with the ResBlock kernel family pinned, to operand
-    rounding otherwise), so the result does not depend on how the files are grouped.  A synthesizer that is not the HIP one, or an
+    draws in the same order, ragged batch items = separate calls; bit-equal with the shape-dependent kernel choices pinned --
+    generator ``RB_STREAM`` / ``NO_RB_SPLIT``, front ``FR_NJ`` / ``FR_FFN_SPLIT`` -- and equal to operand rounding otherwise), so the result does not depend on how the files are grouped.  A synthesizer that is not the HIP one, or an
     index only real faiss reads, takes the plain per-file loop over ``self.pipeline``."""
     audios = list(audios)
     f0_files = list(f0_files) if f0_files is not None else [None] * len(audios)

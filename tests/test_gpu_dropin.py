@@ -507,6 +507,8 @@ def test_convert_files_batches_several_files_and_equals_the_per_file_pipeline(rv
     net_g, _ = rs.get_synthesizer(make_cpt(seed), gpu)
     for key, val in (("RB_STREAM", 0), ("NO_RB_SPLIT", 1)):  # same kernel family for every batch size
         net_g.dec.set_option(key, val)
+    for key, val in (("FR_NJ", 1), ("FR_FFN_SPLIT", 1)):  # ... in the front too (tile height and the split FFN follow the tile count)
+        net_g._rvcmi_front.set_option(key, val)
     config = types.SimpleNamespace(device=gpu, **{k[4:]: (bool(d[k]) if k == "cfg_is_half" else int(d[k])) for k in d if k.startswith("cfg_")})
     pipe = pl.Pipeline(cfg.sr, config)
     fake = synth.FakeRMVPE(gpu, seed)
@@ -515,7 +517,7 @@ def test_convert_files_batches_several_files_and_equals_the_per_file_pipeline(rv
     io.write_index(synth.make_ivf(int(d["index_n"]), int(d["index_d"]), seed=int(d["index_seed"])), path)
     n0 = int(d["n_audio"])
     audios = [synth.make_audio16k(n0, seed), synth.make_audio16k(16000 * 2 + 77, seed + 1), synth.make_audio16k(n0 // 2 + 4321, seed + 2),
-              synth.make_audio16k(16000, seed + 3), synth.make_audio16k(n0 - 16000 * 3, seed + 4)]
+              synth.make_audio16k(16000, seed + 3), synth.make_audio16k(50000, seed + 4)]  # t_max = 16000 samples: 3, 3, 2, 1, 4 segments
     hub = synth.FakeHubert(768, seed)
     tail = (int(d["f0_up_key"]), "rmvpe", path, float(d["index_rate"]), 1, int(d["filter_radius"]), cfg.sr, 0, float(d["rms_mix_rate"]),
             "v2", float(d["protect"]))
