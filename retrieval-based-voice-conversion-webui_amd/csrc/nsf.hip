@@ -1146,14 +1146,15 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             HIP_CHECK(hipGetLastError());
             if (ra.dbg & 32) {  // dev only: per-phase cycle breakdown, averaged per resblock kernel size
                 HIP_CHECK(hipStreamSynchronize(st));
-                std::vector<unsigned long long> ts(nblk * 4 * 16);
+                const int nwv = C == 64 ? RbFullGeom<64>::NWV : RBF32_NWV;  // waves per block: the stamp rows of a tile
+                std::vector<unsigned long long> ts(nblk * nwv * 16);
                 HIP_CHECK(hipMemcpy(ts.data(), h->dbg.p, ts.size() * 8, hipMemcpyDeviceToHost));
                 for (int oj = 0; oj < nk; ++oj) {
                     double sum[16] = {0};
                     long cnt = 0;
                     for (int t = 0; t < ra.job[oj].ntiles; ++t)
-                        for (int w = 0; w < 4; ++w) {
-                            const unsigned long long* p = &ts[((size_t)(0 * nk + oj) * max_tiles + t) * 64 + w * 16];
+                        for (int w = 0; w < nwv; ++w) {
+                            const unsigned long long* p = &ts[(((size_t)(0 * nk + oj) * max_tiles + t) * nwv + w) * 16];
                             if (!p[0]) continue;
                             for (int i = 1; i < 16; ++i) sum[i] += p[i] ? (double)(p[i] - p[i - 1]) : 0.0;
                             ++cnt;
