@@ -781,11 +781,13 @@ def main():
             "n_gpus": dist.get_world_size() if use_dist else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # what the arithmetic is, not a precision claim: MFMA operands AND (round 4, options Y_F16 / X0_F16, default on) the
-            # inter-stage streams in HBM -- the three ResBlock outputs of stages 1-3 and the ups output X0 of stages 2-3 -- are fp16;
+            # inter-stage streams in HBM -- the three ResBlock outputs of stages 1-3 and the ups output X0 of stages 1-3 (round 5: also
+            # of the streaming stage) -- are fp16;
             # accumulators, biases, the residual stream INSIDE a ResBlock, the excitation and conv_post are fp32
             "dtype": ("%s MFMA operands%s, fp32 accumulate / in-block residual; fp32 MFMA prefilter + fp64 verified IVF distances" % (
                 a.operand, "" if os.environ.get("RVCMI_Y_F16", "1") == "0" else (
-                    " + fp16 inter-stage streams (ResBlock outputs%s)" % ("" if os.environ.get("RVCMI_X0_F16", "1") == "0" else ", ups output at C <= 64")))
+                    " + fp16 inter-stage streams (ResBlock outputs%s)" % ("" if os.environ.get("RVCMI_X0_F16", "1") == "0" else (
+                        ", ups output of stages 2-3" if os.environ.get("RVCMI_X0_F16_NOSTREAM") else ", ups output of stages 1-3"))))
                       ) if a.operand != "fp32" else "fp32 (fp32 MFMA, fp32 streams)",
             "data": "synthetic (seeded weights, features, f0, noise, index; no checkpoints offline)",
             "config": {"workload": "BASELINE configs[%d]: v2/48k, %d x 10 s clip(s) per GPU, T=%d frames, 599 queries/clip, "

@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -560,8 +560,10 @@ static bool x0_f16(const rvcmi_nsf* h, int C, size_t maxnd) {
 }
 
 // Whole resblocks of a stage on the streaming kernel (ND = 3).  Fills src[j] with the output streams on success.
+// `xhalf`: X0 is an fp16 stream (round 5).  `dry`: plan only -- would this stage stream?  (decides BEFORE the upsampler runs whether it
+// may write X0 as fp16: the tile kernels a short clip falls back to read fp32 rows)
 static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int L, int B, int nk, const float** src, hipStream_t st,
-                               const int* lens, int lm) {
+                               const int* lens, int lm, bool xhalf = false, bool dry = false) {
     const bool yh = y_f16(h);
     const int mode = rb_stream_mode(h);
     if (mode == 0 || op == RVCMI_OPERAND_F32 || nk > 3) return false;
@@ -580,6 +582,7 @@ static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int 
         d.src = h->X0.as<float>();
         d.dst = h->Ya[j].as<float>();
         d.y_half = yh ? 1 : 0;
+        d.x_half = xhalf ? 1 : 0;
         d.lens = lens;
         d.lmul = lm;
         d.k = s.rb[j][0].first.ntaps[0];
@@ -597,11 +600,12 @@ static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int 
             flops += (c1.flops_per_pos + c2.flops_per_pos) * (double)L * B;
             bytes += 2.0 * d.k * C * C * 2;
         }
-        bytes += (double)B * L * C * (yh ? 6 : 8);
+        bytes += (double)B * L * C * ((yh ? 2 : 4) + (xhalf ? 2 : 4));
     }
     char nm[48];
     snprintf(nm, sizeof(nm), "rb_stream_c%d", C);
     if (!rb_stream_launch(op, C, 3, sd, nk, L, B, (long)L * C, mode == 1, st, h->opt, true)) return false;
+    if (dry) return true;
     h->prof.launch(nm, flops, bytes, st, [&] { rb_stream_launch(op, C, 3, sd, nk, L, B, (long)L * C, mode == 1, st, h->opt); });
     HIP_CHECK(hipGetLastError());
     for (int j = 0; j < nk; ++j) src[j] = h->Ya[j].as<float>();
@@ -845,7 +849,11 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
         const int nk = (int)s.rb.size();
         size_t maxnd0 = 0;
         for (int j = 0; j < nk; ++j) maxnd0 = std::max(maxnd0, s.rb[j].size());
-        const bool x0h = op != RVCMI_OPERAND_F32 && x0_f16(h, C, maxnd0);  // X0 of this stage is fp16 (consumer: k_rb_full)
+        // X0 of this stage is fp16: where the consumer is k_rb_full (C <= 64), and -- round 5 -- where the whole resblocks WILL run on the
+        // streaming kernel with its coalesced step IO (C = 128 on clips long enough for strips; decided by a dry run of the planner)
+        const bool x0h_stream = op != RVCMI_OPERAND_F32 && C > 64 && y_f16(h) && h->opt.geti("X0_F16", 1) != 0 && !h->opt.on("X0_F16_NOSTREAM") &&
+                                try_rb_stream_full(h, s, op, C, (int)L, B, nk, nullptr, st, lens, lm, true, true);
+        const bool x0h = op != RVCMI_OPERAND_F32 && (x0_f16(h, C, maxnd0) || x0h_stream);
         char nm[48];
         if (op == RVCMI_OPERAND_F32) {
             {  // x = ups[i](leaky_relu(x, 0.1))                                nsf.py:171-172
@@ -1079,7 +1087,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
                 run_conv_jobs(h, L1, a1, nj, B, nm, st);
                 run_conv_jobs(h, L2, a2, nj, B, nm, st);
             }
-        } else if (try_rb_stream_full(h, s, op, C, (int)L, B, nk, src, st, lens, lm)) {
+        } else if (try_rb_stream_full(h, s, op, C, (int)L, B, nk, src, st, lens, lm, x0h_stream)) {
             // streaming fused resblocks (rb_stream_kernels.hpp): persistent blocks walk strips of the time axis
             stage_half = y_f16(h);
         } else if (C <= 64 && maxnd <= 3 && !h->opt.on("NO_RBFULL")) {

@@ -44,13 +44,13 @@ bool geo_for(int C, int nd, Geo& g, const Options& opt) {
 
 // nblocks < 0: only make sure the > 64 KB dynamic-LDS attribute is set on the current device (once per device and instantiation;
 // done at handle creation so that a first forward inside a stream capture does not have to)
-template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG = 4, int NB = 2, int OCC = 1, int KL = 1>
+template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG = 4, int NB = 2, int OCC = 1, int KL = 1, int XH = 0>
 void launch_inst(const RbStreamArgs& a, int nblocks, int B, size_t smem, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
-    auto kern = &k_rb_stream<OpT, C, MI, NJ, NCO, ND, KG, NB, OCC, KL>;
+    auto kern = &k_rb_stream<OpT, C, MI, NJ, NCO, ND, KG, NB, OCC, KL, XH>;
     if (!(attr_done.load() & bit)) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.fetch_or(bit);
@@ -75,6 +75,8 @@ void launch_t(int C, int nd, int NJ, const RbStreamArgs& a, int nblocks, int B, 
     if (C == 256 && nd == 1 && NJ == 3) return launch_inst<OpT, 256, 2, 3, 4, 1>(a, nblocks, B, smem, st);
     if (C == 128 && nd == 3 && NJ == 8) return launch_inst<OpT, 128, 1, 8, 4, 3>(a, nblocks, B, smem, st);
     // (weight ring 3 / 4 groups deep instead of 2: 65 / 129 spilled registers, 0.70 -> 0.77 / 0.89 ms -- measured, not kept)
+    if (C == 128 && nd == 3 && NJ == 6 && (a.flags & 4) && (a.flags & 16))
+        return launch_inst<OpT, 128, 1, 6, 4, 3, RS_KG128, RS_NB128, 1, 2, 1>(a, nblocks, B, smem, st);  // lean K loop, fp16 input rows
     if (C == 128 && nd == 3 && NJ == 6 && (a.flags & 4)) return launch_inst<OpT, 128, 1, 6, 4, 3, RS_KG128, RS_NB128, 1, 2>(a, nblocks, B, smem, st);  // lean K loop
     if (C == 128 && nd == 3 && NJ == 6) return launch_inst<OpT, 128, 1, 6, 4, 3, RS_KG128, RS_NB128>(a, nblocks, B, smem, st);
     RVCMI_FAIL(RVCMI_ERR_INVALID, "rb_stream: no instantiation for C=%d nd=%d", C, nd);
@@ -107,9 +109,11 @@ void rb_stream_prepare() {
         launch_t<__bf16>(128, 3, nj, a, -1, 1, 0, nullptr);
         launch_t<_Float16>(128, 3, nj, a, -1, 1, 0, nullptr);
     }
-    a.flags = 4;  // the lean-K-loop instantiation of NJ = 6
-    launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr);
-    launch_t<_Float16>(128, 3, 6, a, -1, 1, 0, nullptr);
+    for (int fl : {4, 4 | 16}) {  // the lean-K-loop instantiations of NJ = 6: fp32 / fp16 input rows
+        a.flags = fl;
+        launch_t<__bf16>(128, 3, 6, a, -1, 1, 0, nullptr);
+        launch_t<_Float16>(128, 3, 6, a, -1, 1, 0, nullptr);
+    }
     a.flags = 0;
 }
 
@@ -251,6 +255,10 @@ static bool launch_geo(const Geo& g, int min_steps_required, int operand, int C,
     a.lens = jobs[0].lens;
     a.lmul = jobs[0].lmul;
     if (jobs[0].y_half) a.flags |= 8;
+    if (jobs[0].x_half) {
+        if (!(a.flags & 4) || !(C == 128 && nd == 3 && g.NJ == 6)) return false;  // fp16 input rows: only in the coalesced step IO of KL = 2
+        a.flags |= 16;
+    }
     if (min_steps < min_steps_required) return false;
     const size_t smem = (size_t)(RS_HEAD + R + RS_SLACK + side_rows + 1) * (2 * C + 16) + (size_t)nd * 2 * C * sizeof(float);
     // k_rb_stream with KL = 2 (lean K loop + coalesced step IO): [side | dump | biases | M ...] with the fp32 transposition tile

@@ -17,6 +17,7 @@ struct RbStreamDesc {  // one resblock (ND = 3: all its pairs) or one pair level
     int k, k_p;
     int dil[3];
     int y_half;  // (jobs[0] decides for the launch) dst streams are fp16; only k_rb_stream itself honours it
+    int x_half;  // (jobs[0]) src is an fp16 stream (round 5: X0 of the streaming stage, option X0_F16); needs the lean-K-loop instantiation
     const int* lens;  // (jobs[0]) ragged batch: item b holds lens[b] * lmul rows (nsf_kernels.hpp item_rows); nullptr = all L
     int lmul;
 };

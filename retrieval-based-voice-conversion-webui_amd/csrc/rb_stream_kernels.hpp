@@ -53,7 +53,7 @@ struct RbStreamArgs {
     long bstride;
     int side_rows;  // rows of the side area (max over jobs)
     int flags;      // bit 2 (4) = lean K loop instantiation; bit 3 (8) = the dst streams are fp16 (pack4_h, nsf_kernels.hpp), same
-                    // element layout
+                    // element layout; bit 4 (16) = the src stream is fp16 (KL = 2 only)
     unsigned long long* ts;  // dev only (RVCMI_RS_STAMPS=1): per-wave cycle sums per phase, [block][wave][16]
 };
 
@@ -67,7 +67,9 @@ __device__ __forceinline__ void rs_copy_rows(char* dst, const char* src, int row
 }
 
 // KL = 2: the lean K loop kconv (nsf_kernels.hpp) instead of conv_prefetch / conv_run
-template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG, int NB, int OCC = 1, int KL = 1>
+// XH = 1 (with KL = 2): the src stream is fp16 (a.flags bit 4) -- its own instantiation: as a runtime switch the fp32 and the fp16 row
+// registers of the step prefetch were both live (472 -> 512 registers + 16 spilled)
+template <typename OpT, int C, int MI, int NJ, int NCO, int ND, int KG, int NB, int OCC = 1, int KL = 1, int XH = 0>
 static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs a) {
     using TL = Tile<C>;
     using frag = typename Op<OpT>::frag;
@@ -199,8 +201,13 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
     constexpr int TSTR = C * 4 + 16;
     static_assert(KL != 2 || (NT % CHR == 0 && R % NG8 == 0 && NCH % 8 == 0 && C * 4 * 8 == 4096), "IO chunk geometry");
     char* T = M;
-    f32x4 xr[KL == 2 ? NCH : 1];
-    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)((size_t)L * C * 4), 0x00020000);
+    f32x4 xr[(KL == 2 && !XH) ? NCH : 1];
+    u32x4_t xrh[(KL == 2 && XH) ? R / (NT / (CHR / 2)) : 1];  // fp16 rows: NCHH chunks per thread
+    constexpr bool xhf = XH != 0;  // fp16 input stream (half the bytes, half the load instructions and LDS round trip)
+    static_assert(!xhf || KL == 2, "fp16 input rows come through the coalesced step IO");
+    const __amdgpu_buffer_rsrc_t rs_src =
+        xhf ? __builtin_amdgcn_make_buffer_rsrc((void*)((const _Float16*)J.src + (size_t)b * a.bstride), 0, (int)((size_t)L * C * 2), 0x00020000)
+            : __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)((size_t)L * C * 4), 0x00020000);
     const bool yh = (a.flags & 8) != 0;  // block-uniform: fp16 output stream
     _Float16* dsth = (_Float16*)J.dst + (size_t)b * a.bstride;
     const __amdgpu_buffer_rsrc_t rs_dst =
@@ -217,6 +224,12 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
     const unsigned io_voff = (unsigned)(g8 * NCH * C * 4 + cch * 16);           // this thread's chunk of its first row, in bytes
     const unsigned io_lds = lds_address(T) + (unsigned)(g8 * NCH * TSTR + cch * 16);
     auto issue_loads = [&](int w0) {
+        if constexpr (xhf) {  // fp16 rows (2 C bytes): thread (g16, c) owns chunk c of NCHH rows, immediates it * 2 C < 4096 on one offset register
+            unsigned v0 = ioh_voff + (unsigned)(w0 * (C * 2));  // (wraps for w0 < 0: far outside the descriptor => zeros)
+            asm volatile("" : "+v"(v0));
+#pragma unroll
+            for (int it = 0; it < NCHH; ++it) xrh[it] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, v0 + (unsigned)(it * (C * 2)), 0, 0);
+        } else {
         // (wraps for w0 < 0: far outside the descriptor => zeros.  Three opaque offset registers, 4096 bytes apart: the rest of a
         //  chunk's offset fits the instruction's 12-bit immediate; left transparent, the compiler hoists 24 per-chunk registers)
         unsigned v0[NCH / 8];
@@ -228,6 +241,7 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
 #pragma unroll
         for (int it = 0; it < NCH; ++it)
             xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_src, v0[it / 8] + (unsigned)((it % 8) * (C * 4)), 0, 0));
+        }
     };
     // D-layout addresses of this lane inside T: tiles 0..2 from one base register, 3..5 from a second (16-bit offset fields)
     const unsigned dl_lds = lds_address(T) + (unsigned)(lrow * TSTR + (ct0 * 32 + half4) * 4);
@@ -238,6 +252,32 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
         f32x16 xin[MI][NJ];
         if constexpr (KL == 2) {
             bar();  // every thread is done with T (the previous step's row-wise reads for its stores)
+            if constexpr (xhf) {
+                using lds_u4i = __attribute__((address_space(3))) u32x4_t;
+                using h4 = __attribute__((ext_vector_type(4))) _Float16;
+                using lds_h4 = __attribute__((address_space(3))) h4;
+                {
+                    unsigned bb = ioh_lds;
+                    asm volatile("" : "+v"(bb));
+#pragma unroll
+                    for (int it = 0; it < NCHH; ++it) *(lds_u4i*)(size_t)(bb + (unsigned)(it * TSTRH)) = xrh[it];
+                }
+                bar();
+                {
+                    unsigned b0 = dlh_lds;
+                    asm volatile("" : "+v"(b0));
+#pragma unroll
+                    for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const h4 v = *(const lds_h4*)(size_t)(b0 + (unsigned)(jt * 32 * TSTRH + (mi * 32 + 8 * g) * 2));
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) xin[mi][jt][4 * g + e] = (float)v[e];
+                            }
+                }
+            } else {
             {
                 unsigned b = io_lds;
                 asm volatile("" : "+v"(b));
@@ -258,6 +298,7 @@ static __global__ void __launch_bounds__(64 * NCO, OCC) k_rb_stream(RbStreamArgs
 #pragma unroll
                             for (int e = 0; e < 4; ++e) xin[mi][jt][4 * g + e] = v[e];
                         }
+            }
             }
             bar();  // before phase A publishes into M (the same LDS)
         } else
