@@ -894,7 +894,7 @@ struct rvcmi_ivf {
     // dev / test options (common.hpp Options): IVF_COARSE_F64 (brute-force fp64 coarse quantizer), IVF_GENERIC (any-d scan kernel),
     // IVF_STAMPS (prints; syncs), IVF_DBG, IVF_SORT (1 = scan the queries in list-sorted, XCD-contiguous order).  Read from RVCMI_<KEY> once at handle creation; later only rvcmi_ivf_set_option.
     rvcmi::Options opt;
-    rvcmi_ivf() { opt.load_env({"IVF_COARSE_F64", "IVF_GENERIC", "IVF_STAMPS", "IVF_DBG", "IVF_SORT", "IVF_LM"}); }
+    rvcmi_ivf() { opt.load_env({"IVF_COARSE_F64", "IVF_GENERIC", "IVF_STAMPS", "IVF_DBG", "IVF_SORT", "IVF_LM", "IVF_LM_MIN"}); }
     const float* centroids() const { return (const float*)(blob + hdr.off_centroids); }
     const float4* centroids_t() const { return (const float4*)(blob + hdr.off_centroids_t); }
     const float* cnorm() const { return (const float*)(blob + hdr.off_cnorm); }
@@ -1160,7 +1160,9 @@ static int num_cus_ivf() {
 // for calls of 64 queries or more: such a call silently costs the 34x row re-reads of the query-major scan otherwise).
 static const char* lm_unusable_reason(const rvcmi_ivf* h, int64_t nq) {
     const BlobHeader& b = h->hdr;
-    if (nq < 64) return "fewer than 64 queries";
+    // from 16 queries on (round 5; 64 before): a realtime chunk's 16 guarded rows take 8 + 11 + 13 us in plan + tiles + select against 51 us in
+    // the query-major kernel, whose one block per query walks a ~300-row list alone (chunk p50 0.487 -> 0.465 ms, ABAB); option IVF_LM_MIN
+    if (nq < h->opt.geti("IVF_LM_MIN", 16)) return "fewer than 16 queries";
     if (std::min<int64_t>(b.nprobe, b.nlist) != 1) return "nprobe > 1";
     if ((b.d % CG_K) != 0) return "d is not a multiple of 32";
     if (b.nlist > LM_MAXL) return "more than 16384 lists (the one-block planner counts them in LDS)";
@@ -1202,7 +1204,7 @@ static void lm_reserve(rvcmi_ivf* h, int64_t nq) {
     // (declining to allocate must also retire an earlier, smaller reservation: reserve() raises cap_nq to the new value, and a later
     //  search with nq <= cap_nq would otherwise run the list-major kernels on buffers sized for fewer queries)
     h->lm_cap_nq = 0;
-    if (!lm_usable(h, std::max<int64_t>(nq, 64))) return;
+    if (!lm_usable(h, std::max<int64_t>(nq, 64))) return;  // (sized for >= 64 queries; option IVF_LM_MIN lowers only the routing threshold)
     const int64_t pitch = (int64_t)align_up((uint64_t)h->lm_maxlen, 32);
     h->lm_S.alloc((size_t)std::max<int64_t>(nq, 1) * pitch * 4);
     h->lm_qinfo.alloc((size_t)std::max<int64_t>(nq, 1) * sizeof(LmQuery));

@@ -40,7 +40,7 @@ def test_search_ids_bit_exact_and_distances(n, d, nq, gpu):
     D0, I0 = h.search(q, 8)
     h.set_option("IVF_SORT", None)
     assert np.array_equal(I0, Ir) and np.array_equal(D0, Dr)
-    # query-major kernel (round 3, IVF_LM=0) and list-major path (default from 64 queries on): the same bits, and the profiler
+    # query-major kernel (round 3, IVF_LM=0) and list-major path (default from 16 queries on): the same bits, and the profiler
     # names say which one ran
     for lm in (0, None):
         h.set_option("IVF_LM", lm)
@@ -49,7 +49,7 @@ def test_search_ids_bit_exact_and_distances(n, d, nq, gpu):
         names = {st["name"] for st in h.profile_read()}
         h.profile(False)
         assert np.array_equal(I1, Ir) and np.array_equal(D1, Dr)
-        assert ("ivf_select" in names) == (lm is None and nq >= 64 and d % 32 == 0), names
+        assert ("ivf_select" in names) == (lm is None and nq >= 16 and d % 32 == 0), names
 
 
 @pytest.mark.parametrize("nprobe", [2, 9])
@@ -359,10 +359,10 @@ def _tiny_index(sizes, d, seed=0, spread=0.05):
     return dict(d=d, ntotal=n, nlist=nlist, nprobe=1, centroids=cent, list_offsets=off, ids=ids, vecs=vecs)
 
 
-@pytest.mark.parametrize("case", ["nlist_16384", "nlist_16385", "list_2048", "list_2049", "d_64", "d_48", "nq_64", "nq_63"])
+@pytest.mark.parametrize("case", ["nlist_16384", "nlist_16385", "list_2048", "list_2049", "d_64", "d_48", "nq_16", "nq_15"])
 def test_list_major_boundaries_pin_the_path_and_both_paths_agree(case, gpu, capfd):
     """The limits of the list-major kernels (ivf.hip ``lm_unusable_reason``): the planner counts at most 16 384 lists in LDS, the selector
-    stages a score row of at most 2048 entries, the MFMA K chunk wants d % 32 == 0, and below 64 queries the one-launch query-major
+    stages a score row of at most 2048 entries, the MFMA K chunk wants d % 32 == 0, and below 16 queries the one-launch query-major
     kernel is kept.  On each side of each limit: WHICH path ran (profiler names), that its answer equals the fp64 oracle, and -- a
     call of 64 queries or more that has to fall back says so ONCE on stderr instead of silently re-reading every list per query."""
     rng = np.random.default_rng(7)
@@ -378,7 +378,7 @@ def test_list_major_boundaries_pin_the_path_and_both_paths_agree(case, gpu, capf
     else:
         nq = int(case.split("_")[1])
         idx = _tiny_index([40, 3, 70, 0, 12, 33], d, seed=4)
-    lm = case in ("nlist_16384", "list_2048", "d_64", "nq_64")
+    lm = case in ("nlist_16384", "list_2048", "d_64", "nq_16")
     # queries near the centroids of a few lists (the long list first), one of them an exact stored row
     pick = rng.integers(0, min(idx["nlist"], 64), size=nq)
     pick[: nq // 2] = 0
