@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -678,12 +678,30 @@ static void launch_conv_jobs(const ConvJobs& js, int Lq, int B, size_t smem, hip
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((Lq + 127) / 128), C / 32, (unsigned)(B * js.njobs)), dim3(256), smem, st, js);
 }
+// K-split form (nsf_kernels.hpp conv_ks_body): 32 rows x 32 channels per block, the four waves split the taps.
+template <typename OpT, int C>
+static void launch_conv_ks_jobs(const ConvJobs& js, int Lq, int B, size_t smem, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    auto kern = &k_conv_ks_jobs<OpT, C, 1>;
+    if (!(attr_done.load() & (1ull << (dev & 63)))) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done.fetch_or(1ull << (dev & 63));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((Lq + 31) / 32), C / 32, (unsigned)(B * js.njobs)), dim3(256), smem, st, js);
+}
 static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvArgs* as, int nj, int B, const char* name, hipStream_t st) {
     ConvJobs js;
     memset(&js, 0, sizeof(js));
     js.njobs = nj;
     double flops = 0, bytes = 0;
     size_t smem = 0;
+    // K-split blocks (32-row tiles, taps over the four waves) where the launch is a few hundred rows: C = 256 (a chunk's 310 rows: 22 -> 18 us
+    // per launch, ABAB).  At C = 128 (3100 rows = 1164 blocks, each staging 82 rows for 32 outputs) they lose: 19 -> 26 us.  Option CONV_KS
+    // = 0 never / 2 both channel counts.
+    const int ksopt = h->opt.geti("CONV_KS", 1);
+    const bool ks = ksopt == 2 || (ksopt == 1 && Ls[0]->cin == 256);
     for (int j = 0; j < nj; ++j) {
         const ConvLayer& L = *Ls[j];
         ConvArgs a = as[j];
@@ -699,8 +717,8 @@ static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvAr
         a.w_ct_stride = L.ct_stride;
         a.ntaps = L.ntaps_p;
         a.roff = 0;
-        a.tile_rows = 128 + (L.ntaps_p - 1) * L.dstep;
-        smem = std::max(smem, (size_t)a.tile_rows * (2 * L.cin + 16));
+        a.tile_rows = (ks ? 32 : 128) + (L.ntaps_p - 1) * L.dstep;
+        smem = std::max(smem, (size_t)a.tile_rows * (2 * L.cin + 16) + (ks ? (size_t)3 * 16 * 64 * 4 : 0));  // (+ the partial sums of 3 waves)
         flops += L.flops_per_pos * (double)a.Lq * B;
         bytes += (double)B * a.Lq * L.cin * (a.in_mode == IN_OP_RAW ? 2 : 4) + (double)B * a.Lq * L.cin * (a.out_mode == OUT_ACT ? 2 : 4) +
                  (a.res ? (double)B * a.Lq * L.cin * 4 : 0) + (double)L.ntaps[0] * L.cin * L.cin * 2;
@@ -708,7 +726,15 @@ static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvAr
     }
     const bool c256 = Ls[0]->cin == 256;
     h->prof.launch(name, flops, bytes, st, [&] {
-        if (h->cfg.operand == RVCMI_OPERAND_BF16) {
+        if (ks) {
+            if (h->cfg.operand == RVCMI_OPERAND_BF16) {
+                if (c256) launch_conv_ks_jobs<__bf16, 256>(js, as[0].Lq, B, smem, st);
+                else launch_conv_ks_jobs<__bf16, 128>(js, as[0].Lq, B, smem, st);
+            } else {
+                if (c256) launch_conv_ks_jobs<_Float16, 256>(js, as[0].Lq, B, smem, st);
+                else launch_conv_ks_jobs<_Float16, 128>(js, as[0].Lq, B, smem, st);
+            }
+        } else if (h->cfg.operand == RVCMI_OPERAND_BF16) {
             if (c256) launch_conv_jobs<__bf16, 256>(js, as[0].Lq, B, smem, st);
             else launch_conv_jobs<__bf16, 128>(js, as[0].Lq, B, smem, st);
         } else {
