@@ -615,7 +615,7 @@ def main():
         # HBM-side bytes per launch of the dominant kernel: NOT measured in this run (PMC counters need their own rocprofv3
         # passes); taken from the newest committed pass of the same command, and labelled as such.
         traffic, traffic_source, traffic_all = None, None, None
-        for tag in ("r04", "r03", "r02", "r01"):
+        for tag in ("r05", "r04", "r03", "r02", "r01"):
             fn = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % tag)
             if not os.path.exists(fn):
                 continue
