@@ -679,17 +679,19 @@ static void launch_conv_jobs(const ConvJobs& js, int Lq, int B, size_t smem, hip
     hipLaunchKernelGGL(kern, dim3((unsigned)((Lq + 127) / 128), C / 32, (unsigned)(B * js.njobs)), dim3(256), smem, st, js);
 }
 // K-split form (nsf_kernels.hpp conv_ks_body): 32 rows x 32 channels per block, the four waves split the taps.
+constexpr int conv_ks_nj(int C) { return C == 256 ? 1 : 3; }  // rows per block / 32 (C = 128: 96-row tiles = 396 blocks for a chunk's 3100 rows)
 template <typename OpT, int C>
 static void launch_conv_ks_jobs(const ConvJobs& js, int Lq, int B, size_t smem, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    auto kern = &k_conv_ks_jobs<OpT, C, 1>;
+    constexpr int NJ = conv_ks_nj(C);
+    auto kern = &k_conv_ks_jobs<OpT, C, 1, NJ>;
     if (!(attr_done.load() & (1ull << (dev & 63)))) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.fetch_or(1ull << (dev & 63));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((Lq + 31) / 32), C / 32, (unsigned)(B * js.njobs)), dim3(256), smem, st, js);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((Lq + 32 * NJ - 1) / (32 * NJ)), C / 32, (unsigned)(B * js.njobs)), dim3(256), smem, st, js);
 }
 static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvArgs* as, int nj, int B, const char* name, hipStream_t st) {
     ConvJobs js;
@@ -697,11 +699,10 @@ static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvAr
     js.njobs = nj;
     double flops = 0, bytes = 0;
     size_t smem = 0;
-    // K-split blocks (32-row tiles, taps over the four waves) where the launch is a few hundred rows: C = 256 (a chunk's 310 rows: 22 -> 18 us
-    // per launch, ABAB).  At C = 128 (3100 rows = 1164 blocks, each staging 82 rows for 32 outputs) they lose: 19 -> 26 us.  Option CONV_KS
-    // = 0 never / 2 both channel counts.
-    const int ksopt = h->opt.geti("CONV_KS", 1);
-    const bool ks = ksopt == 2 || (ksopt == 1 && Ls[0]->cin == 256);
+    // K-split blocks (taps over the four waves, option CONV_KS, default on).  Realtime chunk, ABAB: C = 256 (310 rows, 32-row tiles = 240
+    // blocks) six launches 134 -> 107 us; C = 128 (3100 rows) 113 -> 107 us with 96-row tiles (396 blocks) -- with 32-row tiles it LOST
+    // (155 us: 1164 blocks that each stage 82 rows for 32 outputs).
+    const bool ks = h->opt.geti("CONV_KS", 1) != 0;
     for (int j = 0; j < nj; ++j) {
         const ConvLayer& L = *Ls[j];
         ConvArgs a = as[j];
@@ -717,8 +718,9 @@ static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvAr
         a.w_ct_stride = L.ct_stride;
         a.ntaps = L.ntaps_p;
         a.roff = 0;
-        a.tile_rows = (ks ? 32 : 128) + (L.ntaps_p - 1) * L.dstep;
-        smem = std::max(smem, (size_t)a.tile_rows * (2 * L.cin + 16) + (ks ? (size_t)3 * 16 * 64 * 4 : 0));  // (+ the partial sums of 3 waves)
+        const int ksr = 32 * conv_ks_nj(L.cin);
+        a.tile_rows = (ks ? ksr : 128) + (L.ntaps_p - 1) * L.dstep;
+        smem = std::max(smem, (size_t)a.tile_rows * (2 * L.cin + 16) + (ks ? (size_t)3 * (ksr / 32) * 16 * 64 * 4 : 0));  // (+ the partial sums of 3 waves)
         flops += L.flops_per_pos * (double)a.Lq * B;
         bytes += (double)B * a.Lq * L.cin * (a.in_mode == IN_OP_RAW ? 2 : 4) + (double)B * a.Lq * L.cin * (a.out_mode == OUT_ACT ? 2 : 4) +
                  (a.res ? (double)B * a.Lq * L.cin * 4 : 0) + (double)L.ntaps[0] * L.cin * L.cin * 2;

@@ -1006,15 +1006,16 @@ struct ConvJobs {
 // block's four waves split the TAPS of ONE 32-row x 32 MI-channel output tile (44 k-steps each at k = 11), the partial sums meet in LDS and
 // wave 0 adds them in a fixed order ((w0 + w1) + w2) + w3 and runs the epilogue: a quarter of the dependent weight round trips per wave, no
 // weight byte fetched twice, and row tiles x channel tiles x jobs = 240 blocks.  Grid: x = 32-row tile, y = channel tile, z = batch x jobs.
-// Measured (realtime chunk, ABAB): C = 256 six launches 134 -> 107 us; C = 128 (3100 rows: 1164 blocks that each stage 82 rows for 32 outputs)
-// 114 -> 155 us, so the launcher uses it for C = 256 only.
-template <typename OpT, int CIN, int MI>
+// NJ = row tiles per block.  Measured (realtime chunk, ABAB): C = 256, NJ = 1: six launches 134 -> 107 us; C = 128 (3100 rows): NJ = 1 114 -> 155 us
+// (1164 blocks that each stage 82 rows for 32 outputs), NJ = 3 (396 blocks) 113 -> 107 us.
+template <typename OpT, int CIN, int MI, int NJ>
 __device__ __forceinline__ void conv_ks_body(const ConvArgs& a, int b, char* smem) {
     using TL = Tile<CIN>;
     constexpr int CC = TL::CC;
+    constexpr int TT = 32 * NJ;  // rows per block
     static_assert(CC >= KGROUP, "K split by taps: a tap must be whole k-groups");
     const int cob = (int)blockIdx.y;
-    const int q0 = blockIdx.x * 32;
+    const int q0 = blockIdx.x * TT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ct0 = cob * MI;
     const OpT* wbase = (const OpT*)a.w;
@@ -1024,21 +1025,17 @@ __device__ __forceinline__ void conv_ks_body(const ConvArgs& a, int b, char* sme
     unsigned pf_acc = 0;
     {   // touch this wave's weight slice up front (see conv_mfma_body PFW): the K loop then finds it in the XCD's L2
         const char* wb = (const char*)(wbase + (size_t)ct0 * a.w_ct_stride + (size_t)t0 * CC * 512);
-        const int rounds = (t1 - t0) * CC * MI / 1;  // 1 KB fragments of this wave: (taps x k-steps) per channel tile, MI tiles
         for (int r = 0; r < (t1 - t0) * CC; ++r)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const uint4 v = *(const uint4*)(wb + ((size_t)mi * a.w_ct_stride + (size_t)r * 512) * sizeof(OpT) + lane * 16);
                 pf_acc ^= v.x ^ v.y ^ v.z ^ v.w;
             }
-        (void)rounds;
     }
     // epilogue operands of wave 0, requested before the staging (their round trip runs under it)
     const int cobase = ct0 * 32 + 4 * (lane >> 5);
-    const int q = q0 + (lane & 31);
     const int Lqb = item_rows(a.lens, b, a.lmul_q, a.Lq);
-    const size_t orow = (size_t)min(q, Lqb - 1) * a.out_mul + a.out_add;
-    f32x4 bvec[MI][4], rvec[MI][4];
+    f32x4 bvec[MI][4], rvec[MI][NJ][4];
     if (wave == 0) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -1047,66 +1044,80 @@ __device__ __forceinline__ void conv_ks_body(const ConvArgs& a, int b, char* sme
                 const int co = min(cobase + mi * 32 + 8 * g, a.cout - 4);
                 bvec[mi][g] = a.bias ? *(const f32x4*)(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
                 if (a.cb && a.out_mode != OUT_ACT) bvec[mi][g] += *(const f32x4*)(a.cb + (size_t)b * a.cout + co);
-                rvec[mi][g] = (a.res && a.out_mode != OUT_ACT) ? *(const f32x4*)(a.res + (size_t)b * a.res_bstride + orow * a.out_C + co)
-                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jt = 0; jt < NJ; ++jt) {
+                    const size_t orow = (size_t)min(q0 + jt * 32 + (lane & 31), Lqb - 1) * a.out_mul + a.out_add;
+                    rvec[mi][jt][g] = (a.res && a.out_mode != OUT_ACT) ? *(const f32x4*)(a.res + (size_t)b * a.res_bstride + orow * a.out_C + co)
+                                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
     }
     stage_tile<OpT, CIN>(smem, a, b, q0 + a.in_off - a.roff, a.tile_rows);
     if (pf_acc == 0x9e3779b9u && a.Lq < 0) *(unsigned*)smem = pf_acc;  // never true: keeps the prefetch loads alive
     __syncthreads();
 
-    f32x16 acc[MI][1];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][0][r] = 0.f;
+        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][jt][r] = 0.f;
     const char* lds_lane = smem + (size_t)(lane & 31) * TL::STRIDE + (lane >> 5) * 16;
     if (t1 > t0)  // (wave-uniform)
-        conv_core<OpT, CIN, MI, 1, KGROUP, 4>(acc, lds_lane, wbase + (size_t)ct0 * a.w_ct_stride + (size_t)t0 * CC * 512 + lane * 8, a.w_ct_stride,
-                                              t1 - t0, a.roff + t0 * a.dstep, a.dstep);
-    // partial sums of waves 1..3 -> LDS behind the operand tile ([3][MI][16][64] floats)
+        conv_core<OpT, CIN, MI, NJ, KGROUP, 4>(acc, lds_lane, wbase + (size_t)ct0 * a.w_ct_stride + (size_t)t0 * CC * 512 + lane * 8, a.w_ct_stride,
+                                               t1 - t0, a.roff + t0 * a.dstep, a.dstep);
+    // partial sums of waves 1..3 -> LDS behind the operand tile ([3][MI][NJ][16][64] floats)
     float* red = (float*)(smem + (size_t)a.tile_rows * TL::STRIDE);
     if (wave > 0) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(((wave - 1) * MI + mi) * 16 + r) * 64 + lane] = acc[mi][0][r];
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((((wave - 1) * MI + mi) * NJ + jt) * 16 + r) * 64 + lane] = acc[mi][jt][r];
     }
     __syncthreads();
-    if (wave != 0 || q >= Lqb) return;
+    if (wave != 0) return;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int jt = 0; jt < NJ; ++jt) {
+        const int q = q0 + jt * 32 + (lane & 31);
+        if (q >= Lqb) continue;
+        const size_t orow = (size_t)q * a.out_mul + a.out_add;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = cobase + mi * 32 + 8 * g;
-            if (co >= a.cout) continue;
-            f32x4 v;
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                v[e] = ((acc[mi][0][r] + red[((0 * MI + mi) * 16 + r) * 64 + lane]) + red[((1 * MI + mi) * 16 + r) * 64 + lane]) +
-                       red[((2 * MI + mi) * 16 + r) * 64 + lane];
+            for (int g = 0; g < 4; ++g) {
+                const int co = cobase + mi * 32 + 8 * g;
+                if (co >= a.cout) continue;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    v[e] = ((acc[mi][jt][r] + red[(((0 * MI + mi) * NJ + jt) * 16 + r) * 64 + lane]) + red[(((1 * MI + mi) * NJ + jt) * 16 + r) * 64 + lane]) +
+                           red[(((2 * MI + mi) * NJ + jt) * 16 + r) * 64 + lane];
+                }
+                v += bvec[mi][g];
+                if (a.out_mode == OUT_ACT) {
+                    using o4 = __attribute__((ext_vector_type(4))) OpT;
+                    o4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(lrelu(v[e], a.slope_out));
+                    *(o4*)((OpT*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co) = o;
+                } else {
+                    if (a.res) v += rvec[mi][jt][g];
+                    f32x4* o = (f32x4*)((float*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co);
+                    if (a.accumulate) v += *o;
+                    *o = v;
+                }
             }
-            v += bvec[mi][g];
-            if (a.out_mode == OUT_ACT) {
-                using o4 = __attribute__((ext_vector_type(4))) OpT;
-                o4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = to_op<OpT>(lrelu(v[e], a.slope_out));
-                *(o4*)((OpT*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co) = o;
-            } else {
-                if (a.res) v += rvec[mi][g];
-                f32x4* o = (f32x4*)((float*)a.out + (size_t)b * a.out_bstride + orow * a.out_C + co);
-                if (a.accumulate) v += *o;
-                *o = v;
-            }
-        }
+    }
 }
-template <typename OpT, int CIN, int MI>
+template <typename OpT, int CIN, int MI, int NJ>
 static __global__ void __launch_bounds__(256) k_conv_ks_jobs(ConvJobs js) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int j = (int)blockIdx.z % js.njobs, b = (int)blockIdx.z / js.njobs;
-    conv_ks_body<OpT, CIN, MI>(js.job[j], b, smem);
+    conv_ks_body<OpT, CIN, MI, NJ>(js.job[j], b, smem);
 }
 
 template <typename OpT, int CIN, int MI, int NJ, int WCO>
