@@ -91,6 +91,7 @@ def features_device(self, model, audio0, pitch, pitchf, times, index, index_rate
     return feats, pitch, pitchf, p_len
 
 
+MAX_FILES_PER_GROUP = 64   # inputs of convert_files whose HuBERT frames / waveforms are resident at once (BASELINE configs[2]: 64 clips per GPU)
 MAX_BATCH_QUERIES = 65536  # HuBERT frames per retrieval call of blend_segments (22 minutes of audio; the score scratch stays < 1 GiB)
 
 
@@ -428,10 +429,18 @@ def convert_files(self, model, net_g, sid, audios, times, f0_up_key, f0_method, 
     f0_files = list(f0_files) if f0_files is not None else [None] * len(audios)
     if len(f0_files) != len(audios):
         raise ValueError("f0_files must hold one entry per input")
+    if if_f0 == 2 and len(audios) > 1:
+        raise ValueError("if_f0 == 2 hands ONE precomputed (pitch, pitchf) pair to the pipeline (pipeline.py:268-269); convert such inputs one by one")
     index, needs_ref = _open_index(self, file_index, index_rate)
     if needs_ref or not _ragged_capable(net_g):
         return [self.pipeline(model, net_g, sid, a, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr,
                               resample_sr, rms_mix_rate, version, protect, f) for a, f in zip(audios, f0_files)]
+    if len(audios) > MAX_FILES_PER_GROUP:  # bound what is resident at once (HuBERT frames and waveforms of a group); same order, same draws
+        res = []
+        for lo in range(0, len(audios), MAX_FILES_PER_GROUP):
+            res += convert_files(self, model, net_g, sid, audios[lo: lo + MAX_FILES_PER_GROUP], times, f0_up_key, f0_method, file_index, index_rate,
+                                 if_f0, filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, f0_files[lo: lo + MAX_FILES_PER_GROUP])
+        return res
     from time import time
 
     dev = torch.device(self.device)

@@ -470,3 +470,31 @@ def test_infer_segments_batches_pads_and_draws_noise_like_sequential_calls():
     for i, (o, T) in enumerate(zip(outs, lens)):
         call, b = (0, i) if i < 2 else (1, i - 2)
         assert o.shape == (T * upp,) and torch.equal(o, 100.0 * call + b + torch.arange(T * upp) / 1000.0)
+
+
+def test_convert_files_host_logic_fallback_and_argument_checks():
+    """``rvc_amd.pipeline.convert_files`` without a GPU: a synthesizer that is not the HIP one (or an index only real faiss reads) takes
+    the plain per-file loop over ``self.pipeline`` with the reference's argument order; one f0_file per input; if_f0 == 2 (ONE
+    precomputed pitch pair) is refused for several inputs."""
+    import types
+
+    import rvc_amd.pipeline as pl
+
+    calls = []
+
+    def pipeline(model, net_g, sid, audio, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr, resample_sr,
+                 rms_mix_rate, version, protect, f0_file=None):
+        calls.append((len(audio), f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr, resample_sr, rms_mix_rate, version,
+                      protect, f0_file))
+        return np.full(3, float(len(audio)), np.float32)
+
+    self_ = types.SimpleNamespace(pipeline=pipeline, device="cpu")
+    net_g = types.SimpleNamespace(infer=lambda *a, **k: None)  # not ragged-capable
+    audios = [np.zeros(5, np.float32), np.zeros(9, np.float32)]
+    out = pl.convert_files(self_, "hubert", net_g, 3, audios, [0, 0, 0], -2, "rmvpe", "", 0.75, 1, 3, 48000, 0, 0.25, "v2", 0.33, f0_files=["a", None])
+    assert [o[0] for o in out] == [5.0, 9.0]
+    assert calls == [(5, -2, "rmvpe", "", 0.75, 1, 3, 48000, 0, 0.25, "v2", 0.33, "a"), (9, -2, "rmvpe", "", 0.75, 1, 3, 48000, 0, 0.25, "v2", 0.33, None)]
+    with pytest.raises(ValueError, match="one entry per input"):
+        pl.convert_files(self_, "hubert", net_g, 3, audios, [0, 0, 0], 0, "rmvpe", "", 0.75, 1, 3, 48000, 0, 0.25, "v2", 0.33, f0_files=[None])
+    with pytest.raises(ValueError, match="if_f0 == 2"):
+        pl.convert_files(self_, "hubert", net_g, 3, audios, [0, 0, 0], 0, (None, None), "", 0.75, 2, 3, 48000, 0, 0.25, "v2", 0.33)
