@@ -546,3 +546,28 @@ def test_reduce_features_is_the_large_set_branch_of_the_index_recipe(gpu):
     assert obj < 0.8 * ((x - c0[synth.assign_nearest(x, c0)]) ** 2).sum()
     # the centres-only entry (rvcmi_kmeans) runs the SAME Lloyd iterations as the index build, without the add pass
     assert np.array_equal(c, rvc_amd.IVFFlatHIP.train(x, nlist=64, niter=15, device=gpu).centroids())
+
+
+def test_reduce_features_is_at_least_as_good_as_the_reference_minibatch_kmeans_call(gpu):
+    """web.py:522-536 reduces a training set of more than 2e5 rows to 10k centres with
+    ``MiniBatchKMeans(n_clusters=10000, batch_size=256 * n_cpu, compute_labels=False, init="random").fit(big_npy).cluster_centers_``.
+    sklearn IS installable here, so this one library call of the index recipe can be held against the real thing (scaled down: 30000 x 64
+    rows, 200 centres).  Its stochastic mini-batch trajectory is not reproducible bit for bit -- nothing downstream depends on the
+    individual centres -- so the pin is the quantity the reduction exists for: the k-means objective (fp64, every row to its nearest
+    centre) of ``rvc_amd.reduce_features`` must not be worse than the reference call's, on the same rows."""
+    sk = pytest.importorskip("sklearn.cluster")
+    import rvc_amd
+
+    rng = np.random.default_rng(0)
+    cent = (rng.standard_normal((200, 64)) * 3).astype(np.float32)
+    x = (cent[rng.integers(0, 200, 30000)] + rng.standard_normal((30000, 64))).astype(np.float32)
+
+    def objective(c):
+        a = synth.assign_nearest(x, np.ascontiguousarray(c, np.float32))
+        return float(((x.astype(np.float64) - np.asarray(c, np.float64)[a]) ** 2).sum())
+
+    ref = sk.MiniBatchKMeans(n_clusters=200, verbose=False, batch_size=256 * 8, compute_labels=False, init="random", random_state=0).fit(x).cluster_centers_
+    ours = rvc_amd.reduce_features(x, 200, threshold=1000, niter=10, device=gpu)
+    assert ours.shape == ref.shape == (200, 64)
+    o_ref, o_ours = objective(ref), objective(ours)
+    assert o_ours <= 1.02 * o_ref, "k-means objective %.4g vs the reference MiniBatchKMeans call's %.4g" % (o_ours, o_ref)
