@@ -612,6 +612,23 @@ static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int 
     return true;
 }
 
+// One conv through the K-split blocks (nsf_kernels.hpp conv_ks_body; conv_pre: C_in = 192, 7 taps = 84 k-steps behind L2 per wave otherwise).
+template <typename OpT>
+static void launch_conv_ks_192(const ConvArgs& a, int B, size_t smem, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    auto kern = &k_conv_ks_jobs<OpT, 192, 1, 1>;
+    if (!(attr_done.load() & (1ull << (dev & 63)))) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done.fetch_or(1ull << (dev & 63));
+    }
+    ConvJobs js;
+    memset(&js, 0, sizeof(js));
+    js.njobs = 1;
+    js.job[0] = a;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.Lq + 31) / 32), (unsigned)(a.cout / 32), (unsigned)B), dim3(256), smem, st, js);
+}
 static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const char* name, hipStream_t st) {
     if (!a.cf_stride) a.cf_stride = a.Lin;
     a.cin = L.cin;
@@ -655,6 +672,19 @@ static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const 
         a.ntaps = L.ntaps_p;
         const int span = (L.ntaps_p - 1) * std::abs(L.dstep);
         a.roff = L.dstep < 0 ? span : 0;
+        if (L.cin == 192 && L.nphase == 1 && L.dstep > 0 && L.cout % 32 == 0 && !a.accumulate && (long)B * ((a.Lq + 31) / 32) <= 4 &&
+            h->opt.geti("CONV_KS", 1) != 0) {
+            // conv_pre of a realtime chunk (at most 128 frames): taps over the four waves of a 32-row x 32-channel block (option CONV_KS):
+            // 18 -> 14 us.  NOT for a clip: 608 blocks that each gather 38 channel-first rows took 80 us against 23 (measured)
+            a.tile_rows = 32 + span;
+            const size_t smem = (size_t)a.tile_rows * Tile<192>::STRIDE + (size_t)3 * 16 * 64 * 4;
+            h->prof.launch(name, flops, bytes, st, [&] {
+                if (op == RVCMI_OPERAND_BF16) launch_conv_ks_192<__bf16>(a, B, smem, st);
+                else launch_conv_ks_192<_Float16>(a, B, smem, st);
+            });
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
         a.tile_rows = g.TT + span;
         h->prof.launch(name, flops, bytes, st, [&] {
             if (op == RVCMI_OPERAND_BF16) launch_conv_mfma<__bf16>(a, nj, B, st);
