@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS", "RBF_SMALL"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -517,8 +517,18 @@ static void launch_rbf_inst(const RbFullArgs& ra, int tiles, int nj, int B, hipS
     else if (nb == 3) hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 3, G::OCC, G::NWV>), dim3(tiles, nj, B), dim3(64 * G::NWV), smem, st, ra);
     else hipLaunchKernelGGL((k_rb_full<OpT, C, G::MI, G::NJ, G::KG, 4, G::OCC, G::NWV>), dim3(tiles, nj, B), dim3(64 * G::NWV), smem, st, ra);
 }
+// C = 64 on a launch of a few tiles (a realtime chunk's 6200 rows = 44 tiles of 512 rows on 256 CUs, the launch as long as ONE k = 11 tile:
+// 50 us): 256-row tiles of four waves -- 107 blocks, each half as long.  Two accumulator sets of 64 registers + a 3-deep ring: no spills.
+constexpr int RBF64S_NJ = 2, RBF64S_NWV = 4, RBF64S_ROWS = RBF64S_NWV * 32 * RBF64S_NJ;
 template <typename OpT>
-static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st, const Options& opt) {
+static void launch_rbf_small64(const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
+    constexpr int R = RBF64S_ROWS;
+    const size_t smem = (size_t)(R + 2 * RBF_G + R + 2 * RBF_G2) * Tile<64>::STRIDE + 3 * 2 * 32 * 2 * 4 + 512;
+    hipLaunchKernelGGL((k_rb_full<OpT, 64, 2, RBF64S_NJ, 4, 3, 1, RBF64S_NWV>), dim3(tiles, nj, B), dim3(64 * RBF64S_NWV), smem, st, ra);
+}
+template <typename OpT>
+static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st, const Options& opt, bool small64 = false) {
+    if (small64 && C == 64) return launch_rbf_small64<OpT>(ra, tiles, nj, B, st);
     switch (C) {
         case 64: return launch_rbf_inst<OpT, 64>(ra, tiles, nj, B, st, opt);
         case 32: return launch_rbf_inst<OpT, 32>(ra, tiles, nj, B, st, opt);
@@ -533,6 +543,8 @@ static void set_lds_rbf() {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define RBF_ATTR(C_) RBF_ATTR1(C_, 2) RBF_ATTR1(C_, 3) RBF_ATTR1(C_, 4)
     RBF_ATTR(64) RBF_ATTR(32) RBF_ATTR(16)
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, 64, 2, RBF64S_NJ, 4, 3, 1, RBF64S_NWV>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef RBF_ATTR1
 #undef RBF_ATTR
 }
@@ -612,23 +624,6 @@ static bool try_rb_stream_full(rvcmi_nsf* h, const Stage& s, int op, int C, int 
     return true;
 }
 
-// One conv through the K-split blocks (nsf_kernels.hpp conv_ks_body; conv_pre: C_in = 192, 7 taps = 84 k-steps behind L2 per wave otherwise).
-template <typename OpT>
-static void launch_conv_ks_192(const ConvArgs& a, int B, size_t smem, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0};
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    auto kern = &k_conv_ks_jobs<OpT, 192, 1, 1>;
-    if (!(attr_done.load() & (1ull << (dev & 63)))) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done.fetch_or(1ull << (dev & 63));
-    }
-    ConvJobs js;
-    memset(&js, 0, sizeof(js));
-    js.njobs = 1;
-    js.job[0] = a;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((a.Lq + 31) / 32), (unsigned)(a.cout / 32), (unsigned)B), dim3(256), smem, st, js);
-}
 static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const char* name, hipStream_t st) {
     if (!a.cf_stride) a.cf_stride = a.Lin;
     a.cin = L.cin;
@@ -672,19 +667,8 @@ static void run_conv(rvcmi_nsf* h, const ConvLayer& L, ConvArgs a, int B, const 
         a.ntaps = L.ntaps_p;
         const int span = (L.ntaps_p - 1) * std::abs(L.dstep);
         a.roff = L.dstep < 0 ? span : 0;
-        if (L.cin == 192 && L.nphase == 1 && L.dstep > 0 && L.cout % 32 == 0 && !a.accumulate && (long)B * ((a.Lq + 31) / 32) <= 4 &&
-            h->opt.geti("CONV_KS", 1) != 0) {
-            // conv_pre of a realtime chunk (at most 128 frames): taps over the four waves of a 32-row x 32-channel block (option CONV_KS):
-            // 18 -> 14 us.  NOT for a clip: 608 blocks that each gather 38 channel-first rows took 80 us against 23 (measured)
-            a.tile_rows = 32 + span;
-            const size_t smem = (size_t)a.tile_rows * Tile<192>::STRIDE + (size_t)3 * 16 * 64 * 4;
-            h->prof.launch(name, flops, bytes, st, [&] {
-                if (op == RVCMI_OPERAND_BF16) launch_conv_ks_192<__bf16>(a, B, smem, st);
-                else launch_conv_ks_192<_Float16>(a, B, smem, st);
-            });
-            HIP_CHECK(hipGetLastError());
-            return;
-        }
+        // (conv_pre of a realtime chunk through the K-split blocks was measured: 18 -> 14 us -- and removed: a second summation order for
+        //  calls of at most 128 frames breaks "a ragged batch item is bit-equal to its separate call" for no pinned option)
         a.tile_rows = g.TT + span;
         h->prof.launch(name, flops, bytes, st, [&] {
             if (op == RVCMI_OPERAND_BF16) launch_conv_mfma<__bf16>(a, nj, B, st);
@@ -1161,7 +1145,22 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             stage_half = y_f16(h);
             ra.yh = stage_half ? 1 : 0;
             ra.xh = x0h ? 1 : 0;
-            const int R = rbf_rows(C);
+            // (C = 64) short launches take 256-row tiles: at 512 rows they would be fewer blocks than half the CUs (halo of the k = 11
+            // resblock: 120 rows either way -- the small tiles keep 136 of 256 rows; option RBF_SMALL 0 / 1 pins the choice)
+            bool small64 = false;
+            if (C == 64) {
+                long blocks512 = 0;
+                for (int j = 0; j < nk; ++j) {
+                    int dsum = 0;
+                    for (size_t m = 0; m < s.rb[j].size(); ++m) dsum += s.rb[j][m].first.dstep;
+                    const int k = s.rb[j][0].first.ntaps[0];
+                    const int HL = (k - 1) / 2 * (dsum + (int)s.rb[j].size());
+                    blocks512 += (L + (rbf_rows(64) - 2 * HL) - 1) / (rbf_rows(64) - 2 * HL) * B;
+                    if (RBF64S_ROWS - 2 * HL < RBF64S_ROWS / 4) blocks512 = 1 << 30;  // (halo too large for the small tile)
+                }
+                small64 = h->opt.has("RBF_SMALL") ? h->opt.geti("RBF_SMALL", 0) != 0 && blocks512 < (1 << 30) : blocks512 < num_cus() / 2;
+            }
+            const int R = small64 ? RBF64S_ROWS : rbf_rows(C);
             int order[RVCMI_MAX_RB];
             for (int j = 0; j < nk; ++j) order[j] = j;
             std::sort(order, order + nk, [&](int a1, int b1) { return s.rb[a1][0].first.ntaps[0] > s.rb[b1][0].first.ntaps[0]; });
@@ -1206,13 +1205,13 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
                 ra.ts = h->dbg.as<unsigned long long>();
             }
             h->prof.launch(nm, flops, bytes, st, [&] {
-                if (op == RVCMI_OPERAND_BF16) launch_rbf_t<__bf16>(C, ra, max_tiles, nk, B, st, h->opt);
-                else launch_rbf_t<_Float16>(C, ra, max_tiles, nk, B, st, h->opt);
+                if (op == RVCMI_OPERAND_BF16) launch_rbf_t<__bf16>(C, ra, max_tiles, nk, B, st, h->opt, small64);
+                else launch_rbf_t<_Float16>(C, ra, max_tiles, nk, B, st, h->opt, small64);
             });
             HIP_CHECK(hipGetLastError());
             if (ra.dbg & 32) {  // dev only: per-phase cycle breakdown, averaged per resblock kernel size
                 HIP_CHECK(hipStreamSynchronize(st));
-                const int nwv = C == 64 ? RbFullGeom<64>::NWV : RBF32_NWV;  // waves per block: the stamp rows of a tile
+                const int nwv = C == 64 ? (small64 ? RBF64S_NWV : RbFullGeom<64>::NWV) : RBF32_NWV;  // waves per block: the stamp rows of a tile
                 std::vector<unsigned long long> ts(nblk * nwv * 16);
                 HIP_CHECK(hipMemcpy(ts.data(), h->dbg.p, ts.size() * 8, hipMemcpyDeviceToHost));
                 for (int oj = 0; oj < nk; ++oj) {
