@@ -520,15 +520,17 @@ static void launch_rbf_inst(const RbFullArgs& ra, int tiles, int nj, int B, hipS
 // C = 64 on a launch of a few tiles (a realtime chunk's 6200 rows = 44 tiles of 512 rows on 256 CUs, the launch as long as ONE k = 11 tile:
 // 50 us): 256-row tiles of four waves -- 107 blocks, each half as long.  Two accumulator sets of 64 registers + a 3-deep ring: no spills.
 constexpr int RBF64S_NJ = 2, RBF64S_NWV = 4, RBF64S_ROWS = RBF64S_NWV * 32 * RBF64S_NJ;
-template <typename OpT>
-static void launch_rbf_small64(const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
-    constexpr int R = RBF64S_ROWS;
-    const size_t smem = (size_t)(R + 2 * RBF_G + R + 2 * RBF_G2) * Tile<64>::STRIDE + 3 * 2 * 32 * 2 * 4 + 512;
-    hipLaunchKernelGGL((k_rb_full<OpT, 64, 2, RBF64S_NJ, 4, 3, 1, RBF64S_NWV>), dim3(tiles, nj, B), dim3(64 * RBF64S_NWV), smem, st, ra);
+// (the same 256-row geometry for C <= 32, two blocks per CU: a chunk's 12 400 rows are 122 tiles of 384 rows, 214 of 256)
+template <typename OpT, int C>
+static void launch_rbf_small(const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st) {
+    constexpr int R = RBF64S_ROWS, MI = C == 64 ? 2 : 1, OCCS = C == 64 ? 1 : 2;
+    const size_t smem = (size_t)(R + 2 * RBF_G + R + 2 * RBF_G2) * Tile<C>::STRIDE + 3 * 2 * 32 * MI * 4 + 512;
+    hipLaunchKernelGGL((k_rb_full<OpT, C, MI, RBF64S_NJ, 4, 3, OCCS, RBF64S_NWV>), dim3(tiles, nj, B), dim3(64 * RBF64S_NWV), smem, st, ra);
 }
 template <typename OpT>
 static void launch_rbf_t(int C, const RbFullArgs& ra, int tiles, int nj, int B, hipStream_t st, const Options& opt, bool small64 = false) {
-    if (small64 && C == 64) return launch_rbf_small64<OpT>(ra, tiles, nj, B, st);
+    if (small64 && C == 64) return launch_rbf_small<OpT, 64>(ra, tiles, nj, B, st);
+    if (small64 && C == 32) return launch_rbf_small<OpT, 32>(ra, tiles, nj, B, st);
     switch (C) {
         case 64: return launch_rbf_inst<OpT, 64>(ra, tiles, nj, B, st, opt);
         case 32: return launch_rbf_inst<OpT, 32>(ra, tiles, nj, B, st, opt);
@@ -544,6 +546,8 @@ static void set_lds_rbf() {
 #define RBF_ATTR(C_) RBF_ATTR1(C_, 2) RBF_ATTR1(C_, 3) RBF_ATTR1(C_, 4)
     RBF_ATTR(64) RBF_ATTR(32) RBF_ATTR(16)
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, 64, 2, RBF64S_NJ, 4, 3, 1, RBF64S_NWV>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rb_full<OpT, 32, 1, RBF64S_NJ, 4, 3, 2, RBF64S_NWV>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef RBF_ATTR1
 #undef RBF_ATTR
@@ -1148,17 +1152,17 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             // (C = 64) short launches take 256-row tiles: at 512 rows they would be fewer blocks than half the CUs (halo of the k = 11
             // resblock: 120 rows either way -- the small tiles keep 136 of 256 rows; option RBF_SMALL 0 / 1 pins the choice)
             bool small64 = false;
-            if (C == 64) {
+            if (C == 64 || C == 32) {
                 long blocks512 = 0;
                 for (int j = 0; j < nk; ++j) {
                     int dsum = 0;
                     for (size_t m = 0; m < s.rb[j].size(); ++m) dsum += s.rb[j][m].first.dstep;
                     const int k = s.rb[j][0].first.ntaps[0];
                     const int HL = (k - 1) / 2 * (dsum + (int)s.rb[j].size());
-                    blocks512 += (L + (rbf_rows(64) - 2 * HL) - 1) / (rbf_rows(64) - 2 * HL) * B;
+                    blocks512 += (L + (rbf_rows(C) - 2 * HL) - 1) / (rbf_rows(C) - 2 * HL) * B;
                     if (RBF64S_ROWS - 2 * HL < RBF64S_ROWS / 4) blocks512 = 1 << 30;  // (halo too large for the small tile)
                 }
-                small64 = h->opt.has("RBF_SMALL") ? h->opt.geti("RBF_SMALL", 0) != 0 && blocks512 < (1 << 30) : blocks512 < num_cus() / 2;
+                small64 = h->opt.has("RBF_SMALL") ? h->opt.geti("RBF_SMALL", 0) != 0 && blocks512 < (1 << 30) : blocks512 < num_cus() / 2 * (C == 64 ? 1 : 2);
             }
             const int R = small64 ? RBF64S_ROWS : rbf_rows(C);
             int order[RVCMI_MAX_RB];
@@ -1211,7 +1215,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             HIP_CHECK(hipGetLastError());
             if (ra.dbg & 32) {  // dev only: per-phase cycle breakdown, averaged per resblock kernel size
                 HIP_CHECK(hipStreamSynchronize(st));
-                const int nwv = C == 64 ? (small64 ? RBF64S_NWV : RbFullGeom<64>::NWV) : RBF32_NWV;  // waves per block: the stamp rows of a tile
+                const int nwv = small64 ? RBF64S_NWV : (C == 64 ? RbFullGeom<64>::NWV : RBF32_NWV);  // waves per block: the stamp rows of a tile
                 std::vector<unsigned long long> ts(nblk * nwv * 16);
                 HIP_CHECK(hipMemcpy(ts.data(), h->dbg.p, ts.size() * 8, hipMemcpyDeviceToHost));
                 for (int oj = 0; oj < nk; ++oj) {
