@@ -172,7 +172,8 @@ class IVFFlatHIP:
         return feats
 
     def set_option(self, key: str, value=None) -> None:
-        """Dev / test option of this index (``rvcmi_ivf_set_option``: ``IVF_COARSE_F64``, ``IVF_GENERIC``); ``None`` = default."""
+        """Dev / test option of this index (``rvcmi_ivf_set_option``: ``IVF_COARSE_F64``, ``IVF_GENERIC``, ``IVF_LM`` 0 = never the list-major
+        kernels, ``IVF_LM_MIN`` their routing threshold in queries (default 16), ``IVF_SORT``); ``None`` = default; an unknown key is an error."""
         _lib.set_option(_lib.lib().rvcmi_ivf_set_option, self._h, key, value)
 
     def profile(self, enable: bool) -> None:
