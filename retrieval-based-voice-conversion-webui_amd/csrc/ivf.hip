@@ -1508,6 +1508,84 @@ static int ivf_build_impl(int d, int64_t n, const float* x_host, int64_t nlist, 
                 sz[l] = sz[big] / 2;
                 sz[big] -= sz[l];
             }
+            // Relocation (round 5).  Lloyd iterations from a random start never repair "two centres inside one natural cluster, none in
+            // another": against the reference's MiniBatchKMeans call (web.py:522-536; it re-seeds low-count centres every batch) they ended
+            // 1.43x above its objective on well-separated blobs.  After the update, while settling iterations remain: the centre whose
+            // deletion costs least -- every point of cluster j re-assigned to j's nearest other centre i costs at most n_j |c_j - c_i|^2 --
+            // moves to the farthest point p of the cluster with the largest distortion, if the EXACT gain of a centre at p for that
+            // cluster's own points, sum max(0, |x - c_o|^2 - |x - p|^2), exceeds that cost: the objective of the next assignment cannot
+            // go up (the build's objective stays non-increasing).  Deterministic; at most nlist / 20 moves per iteration; on rows without
+            // cluster structure no move passes the test and the iterations are the plain ones.
+            if (it + 3 < niter && nlist >= 2) {
+                hipLaunchKernelGGL(k_assigned_dist, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, X.as<float>(), Cd.as<float>(), As.as<int64_t>(), n, d,
+                                   Dist.as<double>());  // distance of every row to ITS new mean
+                HIP_CHECK(hipMemcpyAsync(dist.data(), Dist.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+                // nearest OTHER centre of every centre: the two nearest centres of the new means (fp64, the nprobe > 1 kernels)
+                const int64_t cch = std::max<int64_t>(1, std::min<int64_t>(nlist, ((int64_t)256 << 20) / (8 * nlist)));
+                DevBuf CC, NN;
+                CC.alloc((size_t)cch * nlist * 8);
+                NN.alloc((size_t)nlist * 2 * 8);
+                for (int64_t cs = 0; cs < nlist; cs += cch) {
+                    const int64_t nc = std::min<int64_t>(cch, nlist - cs);
+                    hipLaunchKernelGGL(k_coarse_dist, dim3((unsigned)((nc * nlist + 255) / 256)), dim3(256), 0, st, Cd.as<float>() + cs * d, Cd.as<float>(), nc,
+                                       nlist, d, CC.as<double>());
+                    hipLaunchKernelGGL(k_coarse_select, dim3((unsigned)nc), dim3(64), 0, st, CC.as<double>(), nlist, 2, NN.as<int64_t>() + cs * 2);
+                }
+                HIP_CHECK(hipGetLastError());
+                std::vector<int64_t> nn2((size_t)nlist * 2);
+                HIP_CHECK(hipMemcpyAsync(nn2.data(), NN.p, nn2.size() * 8, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                std::vector<double> S(nlist, 0.0), cost(nlist, INFINITY);
+                std::vector<int64_t> nn(nlist, -1);
+                for (int64_t l = 0; l < nlist; ++l)
+                    for (int64_t p = off[l]; p < off[l + 1]; ++p) S[l] += dist[order[p]];
+                for (int64_t l = 0; l < nlist; ++l) {
+                    const int64_t cnt = off[l + 1] - off[l];
+                    if (!cnt) continue;  // (an empty list was just re-seeded above)
+                    int64_t o = nn2[l * 2] == l ? nn2[l * 2 + 1] : nn2[l * 2];
+                    if (o < 0 || o == l || off[o + 1] == off[o]) continue;
+                    double dn = 0.0;
+                    for (int e = 0; e < d; ++e) {
+                        const double t = (double)cent[l * d + e] - (double)cent[o * d + e];
+                        dn += t * t;
+                    }
+                    nn[l] = o;
+                    cost[l] = (double)cnt * dn;
+                }
+                std::vector<int64_t> by_cost(nlist), by_S(nlist);
+                for (int64_t l = 0; l < nlist; ++l) by_cost[l] = by_S[l] = l;
+                std::sort(by_cost.begin(), by_cost.end(), [&](int64_t a1, int64_t b1) { return cost[a1] < cost[b1] || (cost[a1] == cost[b1] && a1 < b1); });
+                std::sort(by_S.begin(), by_S.end(), [&](int64_t a1, int64_t b1) { return S[a1] > S[b1] || (S[a1] == S[b1] && a1 < b1); });
+                std::vector<char> used(nlist, 0);
+                const int64_t maxmoves = std::max<int64_t>(1, nlist / 20);
+                int64_t moves = 0, si = 0;
+                for (int64_t ci = 0; ci < nlist && moves < maxmoves; ++ci) {
+                    const int64_t j = by_cost[ci];
+                    if (used[j] || nn[j] < 0 || !(cost[j] < INFINITY)) continue;
+                    while (si < nlist && (used[by_S[si]] || by_S[si] == j || by_S[si] == nn[j] || off[by_S[si] + 1] - off[by_S[si]] < 2)) ++si;
+                    if (si >= nlist) break;
+                    const int64_t o = by_S[si];
+                    int64_t far = order[off[o]];
+                    for (int64_t p = off[o]; p < off[o + 1]; ++p)
+                        if (dist[order[p]] > dist[far]) far = order[p];
+                    const float* xp = x_host + (size_t)far * d;
+                    double gain = 0.0;
+                    for (int64_t p = off[o]; p < off[o + 1]; ++p) {
+                        const float* xi = x_host + (size_t)order[p] * d;
+                        double dp = 0.0;
+                        for (int e = 0; e < d; ++e) {
+                            const double t = (double)xi[e] - (double)xp[e];
+                            dp += t * t;
+                        }
+                        gain += std::max(0.0, dist[order[p]] - dp);
+                    }
+                    if (!(gain > cost[j])) break;  // the cheapest deletion no longer pays for the best split: done for this iteration
+                    memcpy(&cent[(size_t)j * d], xp, (size_t)d * 4);
+                    used[j] = used[o] = used[nn[j]] = 1;
+                    ++moves;
+                    ++si;
+                }
+            }
         }
         if (centroids_out) {  // every centre is valid: a cluster that lost all its points was re-seeded by splitting the largest one
             memcpy(centroids_out, cent.data(), cent.size() * 4);
