@@ -1153,9 +1153,9 @@ static int num_cus_ivf() {
     return v;
 }
 
-// List-major scan: usable for nprobe 1, d a multiple of the MFMA K chunk, list counts / lengths the planner and the selector
-// hold in LDS, and a score scratch (nq x longest list, fp32) of at most 1 GiB; small query counts (a realtime chunk's 16) keep
-// the one-launch query-major kernel.  Option IVF_LM: 0 = never (round-3 path), default 1.
+// List-major scan: usable for nprobe 1, d a multiple of the MFMA K chunk, a list count the planner holds in LDS, and a score scratch
+// (nq x longest list, fp32) of at most 1 GiB; fewer than 16 queries keep the one-launch query-major kernel.  (A list longer than the
+// 2048-entry LDS row of the selector is worked on in place in the global scratch, round 5.)  Option IVF_LM: 0 = never, default 1.
 // Returns nullptr when the list-major kernels can take a call of nq queries, else the reason they cannot (printed once per handle
 // for calls of 64 queries or more: such a call silently costs the 34x row re-reads of the query-major scan otherwise).
 static const char* lm_unusable_reason(const rvcmi_ivf* h, int64_t nq) {
@@ -1168,7 +1168,6 @@ static const char* lm_unusable_reason(const rvcmi_ivf* h, int64_t nq) {
     if (b.nlist > LM_MAXL) return "more than 16384 lists (the one-block planner counts them in LDS)";
     if (b.ntotal < 1) return "empty index";
     if (!h->lm_ready || h->lm_maxlen < 1) return "list statistics not reserved";
-    if (h->lm_maxlen > LM_MAXPITCH) return "a list of more than 2048 rows (the selector stages a score row in LDS)";
     if (nq >= (1ll << 30)) return "2^30 queries or more";
     const int64_t pitch = (int64_t)align_up((uint64_t)h->lm_maxlen, 32);
     if ((double)nq * (double)pitch * 4.0 > 1073741824.0) return "score scratch (queries x longest list x 4 B) above 1 GiB";
@@ -1326,7 +1325,7 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
         });
         h->prof.launch("ivf_select", 3.0 * nq * 12 * d, (double)nq * (12.0 * d * 4 + pitch * 4.0 + d * 8.0), st, [&] {
             auto kern = d == 768 ? &k_lm_select<3> : (d == 256 ? &k_lm_select<1> : &k_lm_select<0>);
-            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 3) / 4)), dim3(256), (size_t)4 * ((size_t)pitch * 4 + LM_WAVE_EXTRA), st, q, h->lm_qinfo.as<LmQuery>(),
+            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 3) / 4)), dim3(256), (size_t)4 * ((size_t)std::min(pitch, LM_MAXPITCH) * 4 + LM_WAVE_EXTRA), st, q, h->lm_qinfo.as<LmQuery>(),
                                h->ids(), h->vecs(), h->lm_S.as<float>(), (int)nq, (int)b.nlist, d, pitch,
                                h->lm_vmax, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(), bf ? bf->feats : nullptr, bf ? bf->rate : 0.f,
                                bf ? bf->omr : 0.f, h->hdr.pos_last);

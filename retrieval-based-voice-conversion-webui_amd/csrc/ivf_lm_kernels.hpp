@@ -30,7 +30,8 @@ struct LmItem {  // 16 bytes: one store / one load
 static_assert(sizeof(LmItem) == 16, "LmItem is stored and loaded as one 16-byte word");
 
 constexpr int LM_MAXL = 16384;     // lists the one-block planner counts in LDS (2 x 4 B each)
-constexpr int LM_MAXPITCH = 2048;  // longest list the selector stages in LDS (4 waves x 8 KB)
+constexpr int LM_MAXPITCH = 2048;  // longest score row the selector stages in LDS (4 waves x 8 KB); longer lists (round 5) are worked on in place
+                                   // in the query's own row of the global score scratch (L2-hot: the tile kernel just wrote it)
 
 // |v|^2 of every stored row, fp64 accumulation rounded to fp32 (as the centroid norms of the coarse prefilter); one wave per row
 __global__ void __launch_bounds__(256) k_lm_row_norms(const float* __restrict__ vecs, int64_t n, int d, float* __restrict__ rn) {
@@ -249,7 +250,7 @@ __device__ __forceinline__ float lm_unkey(unsigned kx) { return __uint_as_float(
 
 template <int NV>
 __global__ void __launch_bounds__(256) k_lm_select(const float* q, const LmQuery* __restrict__ qinfo, const int64_t* __restrict__ ids,
-                                                   const float* __restrict__ vecs, const float* __restrict__ S, int nq, int nlist, int d,
+                                                   const float* __restrict__ vecs, float* S, int nq, int nlist, int d,
                                                    int pitch, double vmax, int k, float* __restrict__ D, int64_t* __restrict__ I,
                                                    int64_t* __restrict__ P, int* __restrict__ any_short, float* bfeats, float rate, float omr,
                                                    int64_t pos_last) {
@@ -257,9 +258,9 @@ __global__ void __launch_bounds__(256) k_lm_select(const float* q, const LmQuery
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + wave;
     if (p >= nq) return;  // (no block-wide barrier below: waves are independent; a wave's LDS operations execute in order)
-    char* wbase = smem_raw + (size_t)wave * ((size_t)pitch * 4 + LM_WAVE_EXTRA);
-    float* sr = (float*)wbase;
-    double* cd = (double*)(wbase + (size_t)pitch * 4);
+    const int pl = min(pitch, LM_MAXPITCH);  // entries of the LDS score row
+    char* wbase = smem_raw + (size_t)wave * ((size_t)pl * 4 + LM_WAVE_EXTRA);
+    double* cd = (double*)(wbase + (size_t)pl * 4);
     long long* ci = (long long*)(cd + LM_VCAP);
     int* cr = (int*)(ci + LM_VCAP);
     float* bd8 = (float*)(cr + LM_VCAP);
@@ -275,6 +276,10 @@ __global__ void __launch_bounds__(256) k_lm_select(const float* q, const LmQuery
     const LmQuery Q = qinfo[p];
     const int64_t qi = Q.qi, beg = Q.beg;
     const int len = Q.len;
+    // this query's score row: staged in LDS, or -- a list longer than the LDS row -- used where the tile kernel wrote it (wave-uniform; the
+    // candidate compaction below overwrites the row in place either way: it is this query's own)
+    const bool in_lds = len <= pl;
+    float* sr = in_lds ? (float*)wbase : S + (int64_t)p * pitch;
     const float* qp = q + qi * d;
     const int d4 = d >> 2;
     constexpr int NVR = NV ? NV : 1;
@@ -291,9 +296,10 @@ __global__ void __launch_bounds__(256) k_lm_select(const float* q, const LmQuery
         const int c = lane + 64 * j;
         const float v = c < len ? S[(int64_t)p * pitch + c] : __uint_as_float(0x7fc00000u);  // beyond the row: NaN = last in key order
         kv[j] = c < len ? lm_key(v) : 0xffffffffu;
-        if (c < len) sr[c] = v;
+        if (c < len && in_lds) sr[c] = v;
     }
-    for (int c = lane + 64 * KR; c < len; c += 64) sr[c] = S[(int64_t)p * pitch + c];
+    if (in_lds)
+        for (int c = lane + 64 * KR; c < len; c += 64) sr[c] = S[(int64_t)p * pitch + c];
     double qn2 = 0.0;
     if constexpr (NV > 0) {
 #pragma unroll
@@ -344,6 +350,7 @@ __global__ void __launch_bounds__(256) k_lm_select(const float* q, const LmQuery
         if (cand) cl[ncand + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = c;
         ncand += __builtin_popcountll(mask);
     }
+    if (!in_lds) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the compacted list was written to global memory: lanes read each other's slots below)
     // ... and verified EIGHT at a time: every row load of a batch is in flight before the first reduction (a typical query has 8-9
     // candidates).  Verified candidates collect in cd / ci / cr; lane j ranks entry j against all others under (distance, id).
     LM_STAMP();  // 3: compaction

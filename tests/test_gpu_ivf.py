@@ -359,11 +359,12 @@ def _tiny_index(sizes, d, seed=0, spread=0.05):
     return dict(d=d, ntotal=n, nlist=nlist, nprobe=1, centroids=cent, list_offsets=off, ids=ids, vecs=vecs)
 
 
-@pytest.mark.parametrize("case", ["nlist_16384", "nlist_16385", "list_2048", "list_2049", "d_64", "d_48", "nq_16", "nq_15"])
+@pytest.mark.parametrize("case", ["nlist_16384", "nlist_16385", "list_2048", "list_2049", "list_9000", "d_64", "d_48", "nq_16", "nq_15"])
 def test_list_major_boundaries_pin_the_path_and_both_paths_agree(case, gpu, capfd):
-    """The limits of the list-major kernels (ivf.hip ``lm_unusable_reason``): the planner counts at most 16 384 lists in LDS, the selector
-    stages a score row of at most 2048 entries, the MFMA K chunk wants d % 32 == 0, and below 16 queries the one-launch query-major
-    kernel is kept.  On each side of each limit: WHICH path ran (profiler names), that its answer equals the fp64 oracle, and -- a
+    """The limits of the list-major kernels (ivf.hip ``lm_unusable_reason``): the planner counts at most 16 384 lists in LDS, the MFMA K
+    chunk wants d % 32 == 0, and below 16 queries the one-launch query-major kernel is kept.  (Round 5: a list longer than the 2048
+    entries the selector stages in LDS is no longer a limit -- its score row is worked on in place in the global scratch: cases
+    list_2049 / list_9000, e.g. the one list all silence frames of a training set fall into.)  On each side of each limit: WHICH path ran (profiler names), that its answer equals the fp64 oracle, and -- a
     call of 64 queries or more that has to fall back says so ONCE on stderr instead of silently re-reading every list per query."""
     rng = np.random.default_rng(7)
     nq, d = 128, 32
@@ -378,7 +379,7 @@ def test_list_major_boundaries_pin_the_path_and_both_paths_agree(case, gpu, capf
     else:
         nq = int(case.split("_")[1])
         idx = _tiny_index([40, 3, 70, 0, 12, 33], d, seed=4)
-    lm = case in ("nlist_16384", "list_2048", "d_64", "nq_16")
+    lm = case in ("nlist_16384", "list_2048", "list_2049", "list_9000", "d_64", "nq_16")
     # queries near the centroids of a few lists (the long list first), one of them an exact stored row
     pick = rng.integers(0, min(idx["nlist"], 64), size=nq)
     pick[: nq // 2] = 0
@@ -392,7 +393,7 @@ def test_list_major_boundaries_pin_the_path_and_both_paths_agree(case, gpu, capf
     if lm or nq < 64:
         assert "query-major scan" not in err, err
     else:
-        assert err.count("query-major scan") == 1 and {"nlist_16385": "16384 lists", "list_2049": "2048 rows", "d_48": "multiple of 32"}[case] in err, err
+        assert err.count("query-major scan") == 1 and {"nlist_16385": "16384 lists", "d_48": "multiple of 32"}[case] in err, err
         h.search(q, 8)
         assert "query-major scan" not in capfd.readouterr().err  # once per index
     Dr, Ir, _ = ivf_oracle.search_c(idx, q, 8)
