@@ -888,7 +888,9 @@ struct rvcmi_ivf {
     double lm_vmax = 0.0;      // max |v| over the stored rows (error bound of the fp32 prefilter)
     int64_t lm_maxlen = 0;     // longest list
     int64_t lm_cap_items = 0;  // capacity of lm_items
-    int64_t lm_cap_nq = 0;     // queries lm_S / lm_qinfo / lm_items are sized for (0: not reserved -- the list-major kernels never run)
+    int64_t lm_cap_nq = 0;     // queries a call may bring for the list-major kernels (0: not reserved -- they never run)
+    int64_t lm_buf_nq = 0;     // queries lm_S / lm_qinfo / lm_items are sized for = one PASS: a larger call runs several (the score scratch,
+                               // queries x longest list x 4 B, is kept at or below 1 GiB)
     bool lm_warned = false;    // the one-time "large call on the query-major scan" diagnostic was printed
     Profiler prof;
     // dev / test options (common.hpp Options): IVF_COARSE_F64 (brute-force fp64 coarse quantizer), IVF_GENERIC (any-d scan kernel),
@@ -1169,9 +1171,12 @@ static const char* lm_unusable_reason(const rvcmi_ivf* h, int64_t nq) {
     if (b.ntotal < 1) return "empty index";
     if (!h->lm_ready || h->lm_maxlen < 1) return "list statistics not reserved";
     if (nq >= (1ll << 30)) return "2^30 queries or more";
-    const int64_t pitch = (int64_t)align_up((uint64_t)h->lm_maxlen, 32);
-    if ((double)nq * (double)pitch * 4.0 > 1073741824.0) return "score scratch (queries x longest list x 4 B) above 1 GiB";
     return nullptr;
+}
+// queries per pass of the list-major kernels: the fp32 score scratch (queries x longest list) stays at or below 1 GiB
+static int64_t lm_pass_queries(const rvcmi_ivf* h) {
+    const int64_t pitch = (int64_t)align_up((uint64_t)std::max<int64_t>(h->lm_maxlen, 1), 32);
+    return std::max<int64_t>(64, ((int64_t)1 << 30) / (pitch * 4));
 }
 static bool lm_usable(const rvcmi_ivf* h, int64_t nq) { return lm_unusable_reason(h, nq) == nullptr; }
 static void lm_reserve(rvcmi_ivf* h, int64_t nq) {
@@ -1202,14 +1207,16 @@ static void lm_reserve(rvcmi_ivf* h, int64_t nq) {
     }
     // (declining to allocate must also retire an earlier, smaller reservation: reserve() raises cap_nq to the new value, and a later
     //  search with nq <= cap_nq would otherwise run the list-major kernels on buffers sized for fewer queries)
-    h->lm_cap_nq = 0;
-    if (!lm_usable(h, std::max<int64_t>(nq, 64))) return;  // (sized for >= 64 queries; option IVF_LM_MIN lowers only the routing threshold)
+    h->lm_cap_nq = h->lm_buf_nq = 0;
+    if (!lm_usable(h, std::max<int64_t>(nq, 64))) return;  // (option IVF_LM_MIN lowers only the routing threshold)
     const int64_t pitch = (int64_t)align_up((uint64_t)h->lm_maxlen, 32);
-    h->lm_S.alloc((size_t)std::max<int64_t>(nq, 1) * pitch * 4);
-    h->lm_qinfo.alloc((size_t)std::max<int64_t>(nq, 1) * sizeof(LmQuery));
-    // worst case of the planner: every probed list adds at most one partial query tile on top of nq / 32 full ones
-    h->lm_cap_items = (nq / 32 + std::min<int64_t>(nq, b.nlist) + 1) * (pitch / 32);
+    const int64_t nb = std::min<int64_t>(std::max<int64_t>(nq, 1), lm_pass_queries(h));  // queries of one pass
+    h->lm_S.alloc((size_t)nb * pitch * 4);
+    h->lm_qinfo.alloc((size_t)nb * sizeof(LmQuery));
+    // worst case of the planner: every probed list adds at most one partial query tile on top of nb / 32 full ones
+    h->lm_cap_items = (nb / 32 + std::min<int64_t>(nb, b.nlist) + 1) * (pitch / 32);
     h->lm_items.alloc((size_t)h->lm_cap_items * sizeof(LmItem));
+    h->lm_buf_nq = nb;
     h->lm_cap_nq = std::max<int64_t>(nq, 1);
 }
 
@@ -1309,27 +1316,33 @@ static bool search(rvcmi_ivf* h, int64_t nq, const float* q, int k, float* D, in
                     "list-major kernels do not take this call: %s.  Printed once per index.\n", (long long)nq, why);
         }
     }
-    if (lm_wanted && lm_usable(h, nq) && h->lm_S.p && nq <= h->lm_cap_nq) {
+    if (lm_wanted && lm_usable(h, nq) && h->lm_S.p && nq <= h->lm_cap_nq && h->lm_buf_nq > 0) {
         const int pitch = (int)align_up((uint64_t)h->lm_maxlen, 32);
         const double rows = (double)b.ntotal / (double)b.nlist;
-        h->prof.launch("ivf_plan", 0.0, (double)nq * 12 + (double)b.nlist * 8, st, [&] {
-            hipLaunchKernelGGL(k_lm_plan, dim3(1), dim3(1024), (size_t)2 * (b.nlist + 1) * 4, st, h->assign.as<int64_t>(), (int)nq, (int)b.nlist,
-                               h->list_off(), h->lm_qinfo.as<LmQuery>(), h->lm_items.as<LmItem>(), h->lm_n.as<int>(), (int)std::min<int64_t>(h->lm_cap_items, 0x7fffffff));
-        });
-        // (flops / bytes: the SURVEY 8d model -- N / nlist rows per query -- as for the query-major kernel, so that the roofline
-        //  lines of the two paths compare)
-        h->prof.launch("ivf_scan", 2.0 * nq * rows * d, (double)nq * rows * (4.0 * d + 8) + (double)nq * d * 4, st, [&] {
-            const int grid = (int)std::min<int64_t>(h->lm_cap_items, (int64_t)num_cus_ivf() * 3);
-            hipLaunchKernelGGL(k_lm_gemm, dim3((unsigned)std::max(grid, 1)), dim3(256), 0, st, q, h->lm_qinfo.as<LmQuery>(), h->vecs(), h->lm_rn.as<float>(),
-                               h->list_off(), h->lm_items.as<LmItem>(), h->lm_n.as<int>(), d, pitch, h->lm_S.as<float>());
-        });
-        h->prof.launch("ivf_select", 3.0 * nq * 12 * d, (double)nq * (12.0 * d * 4 + pitch * 4.0 + d * 8.0), st, [&] {
-            auto kern = d == 768 ? &k_lm_select<3> : (d == 256 ? &k_lm_select<1> : &k_lm_select<0>);
-            hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 3) / 4)), dim3(256), (size_t)4 * ((size_t)std::min(pitch, LM_MAXPITCH) * 4 + LM_WAVE_EXTRA), st, q, h->lm_qinfo.as<LmQuery>(),
-                               h->ids(), h->vecs(), h->lm_S.as<float>(), (int)nq, (int)b.nlist, d, pitch,
-                               h->lm_vmax, k, D, I, h->P.as<int64_t>(), h->flag.as<int>(), bf ? bf->feats : nullptr, bf ? bf->rate : 0.f,
-                               bf ? bf->omr : 0.f, h->hdr.pos_last);
-        });
+        // passes of at most lm_buf_nq queries (one, unless queries x longest list x 4 B would exceed the 1 GiB score scratch)
+        for (int64_t qs = 0; qs < nq; qs += h->lm_buf_nq) {
+            const int64_t nqp = std::min<int64_t>(h->lm_buf_nq, nq - qs);
+            const float* qp = q + qs * d;
+            const int64_t* asg = h->assign.as<int64_t>() + qs;
+            h->prof.launch("ivf_plan", 0.0, (double)nqp * 12 + (double)b.nlist * 8, st, [&] {
+                hipLaunchKernelGGL(k_lm_plan, dim3(1), dim3(1024), (size_t)2 * (b.nlist + 1) * 4, st, asg, (int)nqp, (int)b.nlist, h->list_off(),
+                                   h->lm_qinfo.as<LmQuery>(), h->lm_items.as<LmItem>(), h->lm_n.as<int>(), (int)std::min<int64_t>(h->lm_cap_items, 0x7fffffff));
+            });
+            // (flops / bytes: the SURVEY 8d model -- N / nlist rows per query -- as for the query-major kernel, so that the roofline
+            //  lines of the two paths compare)
+            h->prof.launch("ivf_scan", 2.0 * nqp * rows * d, (double)nqp * rows * (4.0 * d + 8) + (double)nqp * d * 4, st, [&] {
+                const int grid = (int)std::min<int64_t>(h->lm_cap_items, (int64_t)num_cus_ivf() * 3);
+                hipLaunchKernelGGL(k_lm_gemm, dim3((unsigned)std::max(grid, 1)), dim3(256), 0, st, qp, h->lm_qinfo.as<LmQuery>(), h->vecs(), h->lm_rn.as<float>(),
+                                   h->list_off(), h->lm_items.as<LmItem>(), h->lm_n.as<int>(), d, pitch, h->lm_S.as<float>());
+            });
+            h->prof.launch("ivf_select", 3.0 * nqp * 12 * d, (double)nqp * (12.0 * d * 4 + pitch * 4.0 + d * 8.0), st, [&] {
+                auto kern = d == 768 ? &k_lm_select<3> : (d == 256 ? &k_lm_select<1> : &k_lm_select<0>);
+                hipLaunchKernelGGL(kern, dim3((unsigned)((nqp + 3) / 4)), dim3(256), (size_t)4 * ((size_t)std::min(pitch, LM_MAXPITCH) * 4 + LM_WAVE_EXTRA), st, qp,
+                                   h->lm_qinfo.as<LmQuery>(), h->ids(), h->vecs(), h->lm_S.as<float>(), (int)nqp, (int)b.nlist, d, pitch, h->lm_vmax, k, D + qs * k,
+                                   I + qs * k, h->P.as<int64_t>() + qs * k, h->flag.as<int>(), bf ? bf->feats + qs * d : nullptr, bf ? bf->rate : 0.f,
+                                   bf ? bf->omr : 0.f, h->hdr.pos_last);
+            });
+        }
         HIP_CHECK(hipGetLastError());
         return bf != nullptr;
     }

@@ -406,20 +406,33 @@ def test_list_major_boundaries_pin_the_path_and_both_paths_agree(case, gpu, capf
         assert "ivf_plan" not in names2 and np.array_equal(I2, I) and np.array_equal(D2, D)
 
 
-def test_reserve_beyond_the_scratch_bound_retires_the_list_major_buffers(gpu):
-    """``reserve`` above the 1 GiB score-scratch bound used to leave the list-major buffers at their earlier, smaller
-    size while raising the handle's query capacity -- a later search under the bound then ran the list-major kernels past those
-    buffers.  Now the big reserve retires them and the next call that fits re-reserves them at ITS size: exact results, no overrun."""
+def test_calls_beyond_the_one_gib_score_scratch_run_in_passes(gpu):
+    """The list-major kernels keep their fp32 score scratch (queries x longest list) at or below 1 GiB.  Round 4 fell back to the
+    query-major scan beyond that -- and (ADVICE) a ``reserve`` above the bound left the buffers at an earlier, smaller size while raising
+    the handle's capacity, so that a later call under the bound overran them.  Now a call of any size runs in PASSES of the queries one
+    scratch holds (``lm_buf_nq``): a 200 000-query call against a 1500-row list (1.2 GB of scores) = two passes, every result equal to the
+    oracle, before and after smaller calls on the same handle."""
     idx = _tiny_index([1500, 40, 7, 0, 300], 32, seed=5)
     h = make(idx, gpu)
-    q = (idx["centroids"][np.zeros(4096, np.int64)] + 0.05 * np.random.default_rng(1).standard_normal((4096, 32))).astype(np.float32)
-    (_, I0), names = _path_names(h, lambda: h.search(q[:128], 8))  # list-major scratch sized for 128 queries
-    assert "ivf_plan" in names
-    h.reserve(200_000)  # 200000 x 1504 x 4 B = 1.2 GB > 1 GiB: no list-major scratch for THIS capacity
-    (D, I), names = _path_names(h, lambda: h.search(q, 8))  # 4096 queries <= the handle's capacity, 32x the old scratch
+    rng = np.random.default_rng(1)
+    pick = np.where(rng.random(200_000) < 0.5, 0, rng.integers(0, 5, 200_000))
+    q = (idx["centroids"][pick] + 0.05 * rng.standard_normal((200_000, 32))).astype(np.float32)
+    (_, I0), names = _path_names(h, lambda: h.search(q[:128], 8))  # scratch sized for 128 queries
     assert "ivf_plan" in names
     Dr, Ir, _ = ivf_oracle.search_c(idx, q, 8)
-    assert np.array_equal(I, Ir) and np.array_equal(D, Dr) and np.array_equal(I[:128], I0)
+    h.profile(True)
+    D, I = h.search(q, 8)  # 200000 x 1504 x 4 B = 1.2 GB > 1 GiB: two passes
+    st = {s_["name"]: s_["launches"] for s_ in h.profile_read()}
+    h.profile(False)
+    assert st.get("ivf_plan") == 2 and st.get("ivf_select") == 2, st
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    (D2, I2), names = _path_names(h, lambda: h.search(q[:4096], 8))  # and a single pass again on the same (larger) buffers
+    assert "ivf_plan" in names and np.array_equal(I2, Ir[:4096]) and np.array_equal(D2, Dr[:4096]) and np.array_equal(I2[:128], I0)
+    feats = torch.from_numpy(q).to(gpu).contiguous()
+    h.search_blend(feats, 0.75, 8)  # the fused blend follows its pass
+    exp = ivf_oracle.blend_c(idx, q, Dr, ivf_oracle.search_c(idx, q, 8)[2], 0.75)
+    fin = np.isfinite(exp).all(1)
+    assert float(np.sqrt(np.mean((feats.cpu().numpy()[fin].astype(np.float64) - exp[fin]) ** 2))) <= 1e-5
 
 
 def test_index_build_kmeans_lists_and_roundtrip(gpu, tmp_path):
