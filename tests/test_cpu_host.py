@@ -498,3 +498,41 @@ def test_convert_files_host_logic_fallback_and_argument_checks():
         pl.convert_files(self_, "hubert", net_g, 3, audios, [0, 0, 0], 0, "rmvpe", "", 0.75, 1, 3, 48000, 0, 0.25, "v2", 0.33, f0_files=[None])
     with pytest.raises(ValueError, match="if_f0 == 2"):
         pl.convert_files(self_, "hubert", net_g, 3, audios, [0, 0, 0], 0, (None, None), "", 0.75, 2, 3, 48000, 0, 0.25, "v2", 0.33)
+
+
+def test_blend_segments_concatenates_and_slices_like_the_per_segment_calls(monkeypatch):
+    """``rvc_amd.pipeline.blend_segments`` host logic (CPU tensors, a recording stand-in for the one-launch search + blend + x2 + protect
+    kernel): the HuBERT frames of several segments go through ONE call per ``MAX_BATCH_QUERIES`` frames, every segment's frame-rate pitchf
+    sits at ITS output rows (2 x its first query row), and each segment gets back exactly rows [2 o, 2 o + p_len) of the result."""
+    import rvc_amd.glue as glue
+    import rvc_amd.pipeline as pl
+
+    calls = []
+
+    def fake(out, F, index, index_rate, pf, protect, guard):
+        calls.append((int(F.shape[0]), index, index_rate, None if pf is None else pf.clone(), protect, guard))
+        n = F.shape[0]
+        out[:] = torch.repeat_interleave(F, 2, dim=0)[: out.shape[0]] + (0 if pf is None else pf[: out.shape[0], None])
+
+    monkeypatch.setattr(glue, "_blend_expand_into", fake)
+    d = 4
+    raw, want = [], []
+    for i, (nq, p_len) in enumerate(((5, 9), (3, 6), (7, 13))):
+        f = torch.full((1, nq, d), float(i + 1)) + torch.arange(nq, dtype=torch.float32)[None, :, None] / 10
+        pitchf = torch.full((1, p_len), 100.0 * (i + 1))
+        raw.append((f, torch.zeros(1, p_len, dtype=torch.long), pitchf, p_len))
+        want.append(torch.repeat_interleave(f[0], 2, dim=0)[:p_len] + 100.0 * (i + 1))
+    items = pl.blend_segments(raw, "IDX", 0.75, 0.33)
+    assert len(calls) == 1 and calls[0][0] == 15 and calls[0][1] == "IDX" and calls[0][4] == 0.33 and calls[0][5] is False
+    pf = calls[0][3]
+    assert pf.shape == (30,) and torch.equal(pf[0:9], torch.full((9,), 100.0)) and pf[9] == 1.0  # (padding rows: voiced = untouched)
+    assert torch.equal(pf[10:16], torch.full((6,), 200.0)) and torch.equal(pf[16:29], torch.full((13,), 300.0))
+    for (feats, pt, pff, p_len), w, r in zip(items, want, raw):
+        assert feats.shape == (1, p_len, d) and torch.equal(feats[0], w) and pt is r[1] and pff is r[2]
+    # bounded calls: the same slices from several retrieval calls; no index -> the plain x2 (+ protect) kernel, protect >= 0.5 -> no pitchf
+    monkeypatch.setattr(pl, "MAX_BATCH_QUERIES", 8)
+    del calls[:]
+    items2 = pl.blend_segments(raw, None, 0.75, 0.5)
+    assert [c[0] for c in calls] == [8, 7] and all(c[1] is None and c[3] is None for c in calls)
+    for (feats, _, _, p_len), r in zip(items2, raw):
+        assert torch.equal(feats[0], torch.repeat_interleave(r[0][0], 2, dim=0)[:p_len])
