@@ -61,6 +61,7 @@ def parse():
     p.add_argument("--no-gpu-torch-baseline", action="store_true")
     p.add_argument("--torch-gpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-extra", action="store_true", help="skip the batch64 / stream / bf16 objects of the default N=1 line")
     p.add_argument("--stream", action="store_true",
                    help="BASELINE configs[4]: realtime chunks (v1/40k generator, T=31 frames -> n_res, 16 queries); prints p50 latency")
     a = p.parse_args()
@@ -95,12 +96,12 @@ def ensure_world(a):
 
 
 def dist_selftest(a):
-    """The multi-rank skeleton of main() without GPU work, on gloo: rendezvous, one broadcast of a blob only rank 0 knows,
-    every rank checks it received rank 0's bytes, contiguous shards cover the clip list, max-over-ranks timing."""
-    import hashlib
-
+    """The multi-rank skeleton of main() without GPU work, on gloo: rendezvous, ONE broadcast of a blob only rank 0 knows
+    (`rvc_amd.dist.broadcast_bytes`, what `broadcast_index` moves), `ranks_agree` on the received bytes AND on a value derived from
+    them (the stand-in for every rank's first search), contiguous shards of the clip list (`--config 3`: 64 clips per rank, i.e.
+    512 on 8 ranks = BASELINE configs[3]'s partition; otherwise a count that does not divide), barrier + max-over-ranks timing."""
     import torch.distributed as dist
-    from rvc_amd.dist import broadcast_bytes, shard_range
+    from rvc_amd.dist import broadcast_bytes, ranks_agree, shard_range
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dist.init_process_group(backend="gloo")
@@ -112,24 +113,29 @@ def dist_selftest(a):
     t0 = time.perf_counter()
     got = broadcast_bytes(blob, src=0, device=torch.device("cpu"))
     t_b = time.perf_counter() - t0
-    h = torch.tensor(list(hashlib.sha256(got.numpy().tobytes()).digest()), dtype=torch.int64)
-    h0 = h.clone()
-    dist.broadcast(h0, src=0)
-    ok = torch.tensor([int(bool((h == h0).all()))])
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    clips = 64 * world + 3
+    agree = ranks_agree(got)
+    first = got.to(torch.float32).reshape(1024, 1024).sum(1)  # "first search": a function of THIS rank's copy of the blob
+    agree = agree and ranks_agree(first)
+    per_rank = 64 if a.config == 3 else None
+    clips = per_rank * world if per_rank else 64 * world + 3
     lo, hi = shard_range(clips, rank, world)
     cover = torch.zeros(clips, dtype=torch.int64)
     cover[lo:hi] = 1
     dist.all_reduce(cover)
+    sizes = torch.zeros(world, dtype=torch.int64)
+    sizes[rank] = hi - lo
+    dist.all_reduce(sizes)
     tt = torch.tensor([t_b], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ok = bool(agree) and bool((cover == 1).all()) and (per_rank is None or bool((sizes == per_rank).all()))
     if rank == 0:
         emit({"selftest": True, "backend": "gloo", "n_gpus": dist.get_world_size(), "index_blob_bytes": int(got.numel()),
-                          "index_broadcast_s": float(tt.item()), "ranks_agree": bool(ok.item()), "shards_cover": bool((cover == 1).all())})
+              "index_broadcast_s": float(tt.item()), "ranks_agree": bool(agree), "shards_cover": bool((cover == 1).all()),
+              "clips": clips, "clips_per_rank": [int(x) for x in sizes.tolist()], "scaling": "weak",
+              "config": {"workload": "dry run of the N-rank skeleton%s: no GPU work" % (" of BASELINE configs[3] (64 clips per rank)" if per_rank else "")}})
     dist.barrier()
     dist.destroy_process_group()
-    if not bool(ok.item()) or not bool((cover == 1).all()):
+    if not ok:
         raise SystemExit(3)
 
 
@@ -169,10 +175,13 @@ def cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, index_rate):
 
     ref_net = _reference_generator(cfg, w)
 
+    last = {}
+
     def gen_fwd(zz, ff, gg, nn):
         if ref_net is not None:
             return ref_net(zz, ff, g=gg)  # draws its own noise (same work)
-        return nsf_oracle.generator_forward(cfg, w, zz, ff, gg, nn)
+        last["o"] = nsf_oracle.generator_forward(cfg, w, zz, ff, gg, nn)  # injected noise: comparable with the HIP output (parity leg)
+        return last["o"]
 
     ncpu = os.cpu_count() or 1
     # torch's intra-op pool scales badly past a few dozen threads on this op mix (61 s/clip with 256 threads on
@@ -218,7 +227,8 @@ def cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, index_rate):
     t_gen = float(np.median([r[1] for r in runs]))
     tot = sorted(r[0] + r[1] for r in runs)
     kind = "reference" if ref_net is not None else "port"
-    return {"value": CLIP_SECONDS / (t_ivf + t_gen), "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": kind,
+    return {"_oracle_out": last.get("o") if last.get("o") is not None and last["o"].shape[-1] == z.shape[-1] * cfg.upp else None,
+            "value": CLIP_SECONDS / (t_ivf + t_gen), "unit": "x real-time (audio-sec/wall-sec)", "cores": cores, "kind": kind,
             "spread_s": [tot[0], tot[-1]],
             "sample": "1 clip: 599 queries vs %dx%d IVF (C restatement, fp32, OpenMP) %.3fs + generator T=%d (%s, torch-CPU fp32) %.3fs; "
                       "3 warm-ups (2 short clips + 1 full), median of 5; torch threads chosen from {8,16,32,64}"
@@ -317,10 +327,11 @@ def _time_chunks(fn, n=300, warm=30, graph=True):
     return _percentiles(lat), captured
 
 
-def stream_mode(a):
+def stream_mode(a, chunks=300, warm=30, index=None, breakdown=True):
     """Realtime chunk latency (gui.py geometry): block 0.256 s -> decoder T=31 frames
     (n_res = 31, no formant shift), retrieval on the last 16 HuBERT frames; v1/40k generator, 768-d index.
-    p50 / p90 / p99 over 300 chunks after 30 warm-ups, replayed from a hipGraph of the fixed-shape chunk (--graph 0: eager)."""
+    p50 / p90 / p99 over `chunks` chunks after `warm` warm-ups (--stream: 300 / 30; the `stream` object of the default line: 200 / 20,
+    SURVEY 8d config 5), replayed from a hipGraph of the fixed-shape chunk (--graph 0: eager).  Returns the JSON line as a dict."""
     import rvc_amd
     from oracle import nsf_oracle, synth
 
@@ -330,8 +341,10 @@ def stream_mode(a):
     T, NQ = 31, 16
     z, f0, g = synth.make_dec_inputs(cfg, 1, T)
     noise = nsf_oracle.reference_noise(1, T, cfg.upp)
-    idx = synth.make_ivf(a.index_n, a.index_d, seed=4321, kmeans_iters=1)
-    index = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=dev).reserve(NQ)
+    if index is None:
+        idx = synth.make_ivf(a.index_n, a.index_d, seed=4321, kmeans_iters=1)
+        index = rvc_amd.IVFFlatHIP.from_arrays(idx["centroids"], idx["list_offsets"], idx["ids"], idx["vecs"], device=dev)
+    index.reserve(NQ)
     gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=dev, operand=a.operand, max_B=1, max_T=64)
     zd, fd, gd, nd = z.to(dev), f0.to(dev), g.to(dev), noise.to(dev)
     feats = synth.make_phone(1, NQ, a.index_d)[0].to(dev).contiguous()
@@ -343,7 +356,7 @@ def stream_mode(a):
         index.search_blend(fbuf, a.index_rate, 8, skip_if_short=True)
         hold["o"] = gen(zd, fd, gd, noise=nd)
 
-    st, cap = _time_chunks(hot, graph=bool(a.graph))
+    st, cap = _time_chunks(hot, n=chunks, warm=warm, graph=bool(a.graph))
     assert torch.isfinite(hold["o"]).all()
 
     def kernel_breakdown(fn, handles, n=50):
@@ -360,10 +373,10 @@ def stream_mode(a):
             h_.profile(False)
         return out
 
-    hot_kernels = kernel_breakdown(hot, [index, gen])
+    hot_kernels = kernel_breakdown(hot, [index, gen]) if breakdown else None
     line = {"metric": "realtime chunk latency p50 (retrieval + NSF decode), v1/40k, 256 ms block", "value": st["p50_ms"],
             "unit": "ms", "p90": st["p90_ms"], "p99": st["p99_ms"], "higher_is_better": False, "n_gpus": 1, "dtype": a.operand,
-            "data": "synthetic", "hot_path": dict(st, kernels_us_per_chunk=hot_kernels),
+            "data": "synthetic", "hot_path": dict(st, **({"kernels_us_per_chunk": hot_kernels} if breakdown else {})),
             "config": {"workload": "BASELINE configs[4] (hot path only): T=31 frames -> 12400 samples, 16 queries", "hipgraph": cap}}
     if a.operand != "fp32" and a.index_d == 768:
         # the whole RVC.infer of the realtime loop after HuBERT / f0 (infer/lib/rtrvc.py:163-251, gui.py:1057-1090):
@@ -396,11 +409,140 @@ def stream_mode(a):
             wav = rvc_amd.infer_hip(net, front, ph, None, sid0, pitch_all, pitchf_all, SKIP, RET, RET)[0, 0]  # :236-247
             hold["w"] = rvc_amd.glue.sola(wav.contiguous(), sola_buf, fade_in, fade_out, blk, Ls)  # gui.py:1057-1090
 
-        st2, cap2 = _time_chunks(whole, graph=bool(a.graph))
+        st2, cap2 = _time_chunks(whole, n=chunks, warm=warm, graph=bool(a.graph))
         assert torch.isfinite(hold["w"]).all()
-        st2 = dict(st2, kernels_us_per_chunk=kernel_breakdown(whole, [index, front, gen]))
+        if breakdown:
+            st2 = dict(st2, kernels_us_per_chunk=kernel_breakdown(whole, [index, front, gen]))
         line["whole_chunk"] = dict(st2, what="retrieval (16 rows, guarded) + x2 + protect + enc_p(282) + flow(56) + decode(31) + SOLA", hipgraph=cap2)
-    emit(line)
+    return line
+
+
+
+def _ubench_ceiling():
+    """What the K loop's instruction mix reaches when it has the chip to itself, from the NEWEST committed run of
+    tools/ubench/kloop2 (tools/gpu_round.sh runs it every round and stores profiles/rNN_ubench_kloop2_issue_model.txt)."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench_kloop2_issue_model.txt")))
+    if not files:
+        return None
+    out = {"source": "profiles/" + os.path.basename(files[-1]), "kind": "parsed from the newest committed micro-benchmark run, NOT measured in this run"}
+    for ln in open(files[-1]):
+        m = re.search(r"\((\d+) TF/s, eff\. clock ([0-9.]+) GHz\)\s+(.*)$", ln)
+        if not m or "waves/SIMD=1" not in ln or "MI=1 NJ=6" not in ln or "FILL=0" not in ln:
+            continue
+        if m.group(3).startswith("MFMA only"):
+            out["mfma_only_tflops"], out["mfma_only_clock_ghz"] = float(m.group(1)), float(m.group(2))
+        elif m.group(3).startswith("the K loop as shipped"):
+            out["kloop_tflops"], out["kloop_clock_ghz"] = float(m.group(1)), float(m.group(2))
+    return out if "kloop_tflops" in out else None
+
+
+def _time_hot(gen, index, phone_d, zd, f0d, gd, nd, index_rate, steps, warmup, use_graph=True):
+    """K timed passes of the hot path (feats copy + search_blend + generator) on resident inputs, replayed from a hipGraph.
+    Returns (seconds per step, last output, the eager step function, captured?)."""
+    feats = torch.empty_like(phone_d)
+    hold = {}
+
+    def step():
+        feats.copy_(phone_d)
+        index.search_blend(feats, index_rate, 8)
+        hold["o"] = gen(zd, f0d, gd, noise=nd)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    run, cap = step, False
+    if use_graph:
+        try:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                step()
+            torch.cuda.synchronize()
+            run, cap = gr.replay, True
+        except Exception as e:  # noqa
+            print("[bench] graph capture failed (%s); timing eager launches" % e, file=sys.stderr)
+            torch.cuda.synchronize()
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(hold["o"]).all(), "non-finite generator output"
+    return dt, hold["o"], step, cap
+
+
+def leg_batch64(a, dev, cfg, w, index, B=64, steps=3, warmup=1):
+    """BASELINE configs[2] inside the default line: 64 x 10 s clips per step on one GPU, hipGraph-captured, 3 timed steps."""
+    import rvc_amd
+    from oracle import nsf_oracle, synth
+
+    T = a.frames
+    z, f0, g = synth.make_dec_inputs(cfg, B, T, seed=1234)
+    noise = nsf_oracle.reference_noise(B, T, cfg.upp, 114514)
+    phone = synth.make_phone(B, NQ_CLIP, a.index_d, seed=1234)
+    index.reserve(B * NQ_CLIP)
+    gen = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=dev, operand=a.operand, max_B=B, max_T=T)
+    phone_d = phone.to(dev).reshape(B * NQ_CLIP, a.index_d).contiguous()
+    dt, _, step, cap = _time_hot(gen, index, phone_d, z.to(dev), f0.to(dev), g.to(dev), noise.to(dev), a.index_rate, steps, warmup, bool(a.graph))
+    gen.profile(True)
+    step()
+    torch.cuda.synchronize()
+    gs = gen.profile_read()
+    gen.profile(False)
+    dom = max(gs, key=lambda s_: s_["ms"])
+    ach = dom["flops"] / (dom["ms"] * 1e-3)
+    tot_ms = sum(s_["ms"] for s_ in gs)
+    out = {"what": "BASELINE configs[2]: %d x 10 s clips per step, v2/48k, T=%d, %d queries, same index; hipGraph-captured; %d warm-up + %d timed steps"
+                   % (B, T, B * NQ_CLIP, warmup, steps),
+           "ms_per_step": 1e3 * dt, "ms_per_clip": 1e3 * dt / B, "value": B * CLIP_SECONDS * (T / T_CLIP) / dt, "unit": "x real-time", "steps": steps,
+           "hipgraph": cap, "workspace_GB": gen.workspace_bytes / 1e9,
+           "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": ach / 1e12, "peak": PEAK[a.operand] / 1e12, "unit": "TFLOP/s",
+                        "frac": ach / PEAK[a.operand], "avg_launch_us": 1e3 * dom["ms"] / dom["launches"],
+                        "generator_all_kernels_frac": GEN_FLOP_PER_CLIP * B * (T / T_CLIP) / (tot_ms * 1e-3) / PEAK[a.operand]},
+           "kernels_ms_per_step": {s_["name"]: round(s_["ms"], 3) for s_ in gs if s_["ms"] >= 0.5}}
+    del gen
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_operands(a, dev, cfg, w, index, phone_d, zd, f0d, gd, nd, out_default, oracle_out=None):
+    """BASELINE configs[1] AS WRITTEN (bf16 operands) timed beside the default operand type, and what each costs in parity:
+    RMS distance of the waveform to the exact-fp32 HIP kernels on the same inputs (operand='fp32': <= 2e-5 of the reference,
+    tests/test_gpu_generator.py) and -- when the cpu_baseline leg ran the oracle restatement on this clip with the same
+    injected noise -- to the oracle's waveform itself."""
+    import warnings
+
+    import rvc_amd
+
+    T = a.frames
+    res = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g32 = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=dev, operand="fp32", max_B=1, max_T=T)
+        ref = g32(zd[:1], f0d[:1], gd[:1], noise=nd[:1]).float()
+        del g32
+        gb = rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=dev, operand="bf16", max_B=1, max_T=T)
+        dt, ob, _, cap = _time_hot(gb, index, phone_d[:NQ_CLIP], zd[:1], f0d[:1], gd[:1], nd[:1], a.index_rate, a.steps, a.warmup, bool(a.graph))
+        del gb
+    rms = lambda x_, y_: float((x_.float() - y_.float()).pow(2).mean().sqrt())
+    res["what"] = ("BASELINE configs[1] with bf16 MFMA operands (as BASELINE.json writes it), same step / inputs / graph as the headline; parity = RMS of the "
+                   "waveform against the exact-fp32 HIP kernels%s; north-star bar 1e-3" % ("" if oracle_out is None else " and against the CPU oracle"))
+    res["bf16"] = {"ms_per_step": 1e3 * dt, "value": CLIP_SECONDS * (T / T_CLIP) / dt, "unit": "x real-time", "hipgraph": cap,
+                   "rms_vs_fp32_kernels": rms(ob[:1], ref), "meets_1e-3": rms(ob[:1], ref) <= 1e-3}
+    res[a.operand] = {"rms_vs_fp32_kernels": rms(out_default[:1], ref), "meets_1e-3": rms(out_default[:1], ref) <= 1e-3}
+    res["output_rms"] = float(ref.pow(2).mean().sqrt())
+    if oracle_out is not None:
+        oc = oracle_out.to(dev).reshape(ref.shape)
+        res["bf16"]["rms_vs_cpu_oracle"] = rms(ob[:1], oc)
+        res[a.operand]["rms_vs_cpu_oracle"] = rms(out_default[:1], oc)
+        res["fp32_kernels_rms_vs_cpu_oracle"] = rms(ref, oc)
+    torch.cuda.empty_cache()
+    return res
 
 
 _REAL_STDOUT = None
@@ -443,7 +585,7 @@ def main():
         _REAL_STDOUT = os.fdopen(os.dup(1), "w")
         os.dup2(2, 1)
     if a.stream:
-        return stream_mode(a)
+        return emit(stream_mode(a))
     if a.dist_selftest:
         return dist_selftest(a)
     rank = int(os.environ.get("RANK", "0"))
@@ -638,13 +780,11 @@ def main():
                 "generator_all_kernels": {"ms_per_step": tot_ms, "achieved": gen_ach / 1e12, "frac": gen_ach / peak},
                 "kernels_ms_per_step": {s["name"]: round(s["ms"] / 3.0, 4) for s in gs + ivs}}
         # Context, not a different yardstick: what the SAME K loop (MFMA + LDS B fragments + L2 weight fragments, nothing else)
-        # reaches when it has the chip to itself.  The power management holds such a loop at ~1.5 of the 2.4 GHz the 2.5 PF
-        # figure assumes (tools/ubench/kloop2.hip, profiles/r03_ubench_kloop2_issue_model.txt: 34.0 cycles per MFMA at an
-        # effective 1.52 GHz = 1505 TFLOP/s; an MFMA-only loop: 1804 TFLOP/s at 1.74 GHz).
-        if a.operand in ("fp16", "bf16"):
-            roof["ubench_ceiling"] = {"kloop_tflops": 1505.0, "mfma_only_tflops": 1804.0, "frac_of_kloop_ceiling": ach / 1505e12,
-                                      "kind": "constants from a committed micro-benchmark run, NOT measured in this run",
-                                      "source": "profiles/r03_ubench_kloop2_issue_model.txt (measured on an MI355X of this pool, round 3)"}
+        # reaches when it has the chip to itself (tools/ubench/kloop2.hip; the power management holds such a loop well below the
+        # 2.4 GHz the 2.5 PF figure assumes).  Parsed from the newest committed run of the micro-benchmark.
+        ub = _ubench_ceiling() if a.operand in ("fp16", "bf16") else None
+        if ub is not None:
+            roof["ubench_ceiling"] = dict(ub, frac_of_kloop_ceiling=ach / (ub["kloop_tflops"] * 1e12))
         def scan_total(stats):
             """The scan as one unit: the query-major kernel (`ivf_scan`), or the three launches of the list-major path
             (`ivf_plan` + `ivf_scan` = score tiles + `ivf_select`; round 4) -- time summed, bytes = the SURVEY 8d model of `ivf_scan`."""
@@ -764,8 +904,26 @@ def main():
             print("[bench] whole-infer leg failed: %s" % e, file=sys.stderr)
 
     cpu = None
+    oracle_out = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and idx is not None:
         cpu = cpu_baseline(cfg, w, idx, phone, z, f0, g, noise, a.index_rate)
+        oracle_out = cpu.pop("_oracle_out", None)
+
+    # ---- the other BASELINE configurations under the same clock (N = 1, default line only): configs[2] = batch64, configs[4] = stream,
+    #      configs[1] as written = bf16 operands + what each operand type costs in parity ----
+    extra = {}
+    if rank == 0 and world == 1 and not a.no_extra and not a.whole and B == 1 and a.operand == "fp16" and T == T_CLIP and a.index_d == 768:
+        for name, fn in (("bf16", lambda: leg_operands(a, dev, cfg, w, index, phone_d, zd, f0d, gd, nd, out_holder["o"], oracle_out)),
+                         ("batch64", lambda: leg_batch64(a, dev, cfg, w, index)),
+                         ("stream", lambda: (lambda l_: {"what": l_["config"]["workload"] + "; v1/40k generator (configs/v1/40k.json + v2 encoder), 20 warm-ups + 200 chunks, hipGraph replay",
+                                                         "hot_path": l_["hot_path"], "whole_chunk": l_.get("whole_chunk"), "unit": "ms"})(
+                             stream_mode(a, chunks=200, warm=20, index=index, breakdown=False)))):
+            try:
+                t_leg = time.perf_counter()
+                extra[name] = fn()
+                extra[name]["leg_wall_s"] = round(time.perf_counter() - t_leg, 2)
+            except Exception as e:  # noqa
+                extra[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     tgpu = None
     if rank == 0 and world == 1 and not a.no_gpu_torch_baseline and not a.no_cpu_baseline:
         tgpu = torch_gpu_baseline(a)
@@ -805,6 +963,7 @@ def main():
             line["whole_infer"] = whole
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        line.update(extra)
         if tgpu is not None:
             line["gpu_torch_baseline"] = tgpu
         if rep_stats is not None:

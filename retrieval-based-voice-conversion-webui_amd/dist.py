@@ -77,6 +77,24 @@ def broadcast_index(index, src: int = 0, device=None, group=None):
     return IVFFlatHIP.from_blob(buf)
 
 
+MAX_GATHER_ELEMENTS = 1 << 16  # per tensor / array inside a gathered result (a 10 s waveform has 480 000)
+
+
+def _largest_array(obj) -> int:
+    """Element count of the largest tensor / ndarray inside ``obj`` (tuples, lists and dicts are walked)."""
+    import numpy as np
+
+    if isinstance(obj, torch.Tensor):
+        return int(obj.numel())
+    if isinstance(obj, np.ndarray):
+        return int(obj.size)
+    if isinstance(obj, dict):
+        return max([_largest_array(v) for v in obj.values()] + [0])
+    if isinstance(obj, (tuple, list)):
+        return max([_largest_array(v) for v in obj] + [0])
+    return 0
+
+
 def convert_batch(paths, convert_one=None, index=None, src: int = 0, group=None, gather: bool = True, device=None, convert_many=None):
     """``VC.vc_multi`` (infer/modules/vc/modules.py:201-266: one ``vc_single`` per file of a folder, sequentially) across the
     ranks of one node.  Rank r converts the contiguous shard ``shard_range(len(paths), r, world)`` of ``paths`` -- the same list
@@ -98,7 +116,10 @@ def convert_batch(paths, convert_one=None, index=None, src: int = 0, group=None,
     raises, the shard is converted again file by file (``convert_many([p], index)``) so that the failure stays with its file.
 
     Results travel as Python objects (``gather_object``): return what ``vc_multi`` keeps -- an info string, or the path of the file the
-    rank wrote -- not the waveforms of a 512-clip folder."""
+    rank wrote -- not the waveforms of a 512-clip folder.  This is ENFORCED when results are gathered: a result that carries a tensor /
+    array of more than ``MAX_GATHER_ELEMENTS`` elements (anywhere inside tuples / lists / dicts) raises ``ValueError`` on its rank
+    before the collective, naming the file (``gather=False`` keeps big results on their rank)."""
+    import sys
     import traceback
 
     paths = list(paths)
@@ -127,6 +148,10 @@ def convert_batch(paths, convert_one=None, index=None, src: int = 0, group=None,
                 raise ValueError("convert_many returned %d results for %d files" % (len(res), len(shard)))
             mine = list(zip(shard, res))
         except Exception:  # noqa  (find the file that failed: one call per file, failures become that file's result)
+            # the batch's own traceback is logged ONCE: a systematic failure (out of memory, a bad argument) would otherwise only show
+            # up as N per-file tracebacks after the whole shard was converted a second time
+            print("[rvc_amd.dist] rank %d: convert_many failed on its shard of %d files; converting file by file.  The batch's error:\n%s"
+                  % (rank, len(shard), traceback.format_exc()), file=sys.stderr)
             convert_one = lambda p, ix: convert_many([p], ix)[0]  # noqa: E731
     if not mine:
         for p in shard:
@@ -136,6 +161,17 @@ def convert_batch(paths, convert_one=None, index=None, src: int = 0, group=None,
                 mine.append((p, traceback.format_exc()))
     if not (on and world > 1 and gather):
         return mine
+    # the bound on what may be gathered: every rank checks its OWN shard, then all ranks agree (one MAX all-reduce) BEFORE the
+    # collective, so a violation raises on every rank instead of leaving the others waiting inside gather_object
+    over = [(p, _largest_array(r)) for p, r in mine if _largest_array(r) > MAX_GATHER_ELEMENTS]
+    cdev = device if device is not None else (
+        torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+    bad = torch.tensor([1 if over else 0], dtype=torch.int64, device=cdev)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if int(bad.item()):
+        where = ("file %r holds a tensor / array of %d elements" % over[0]) if over else "a result on another rank holds a large tensor / array"
+        raise ValueError("convert_batch(gather=True): %s (bound MAX_GATHER_ELEMENTS = %d); return info strings or output paths, "
+                         "or call with gather=False" % (where, MAX_GATHER_ELEMENTS))
     parts = [None] * world if rank == src else None
     dist.gather_object(mine, parts, dst=src, group=group)
     if rank != src:

@@ -120,6 +120,8 @@ def blend_segments(raw, index, index_rate, protect):
             pf = torch.ones(2 * n, device=dev, dtype=torch.float32)
             o = 0
             for f, _, pff, p_len in grp:
+                if pff.numel() < p_len:  # the message of glue.retrieve_blend_expand (the per-segment path) instead of a slice-size mismatch
+                    raise ValueError("pitchf has %d frames, p_len is %d" % (pff.numel(), p_len))
                 pf[2 * o: 2 * o + p_len] = pff.reshape(-1)[:p_len].to(dev, torch.float32)
                 o += int(f.shape[1])
         out = torch.empty(2 * n, F.shape[1], device=dev, dtype=torch.float32)
@@ -424,15 +426,18 @@ def convert_files(self, model, net_g, sid, audios, times, f0_up_key, f0_method, 
     input.  -> list of numpy arrays in input order.  Every item is computed exactly as its own call would compute it (same noise
     draws in the same order, ragged batch items = separate calls; bit-equal with the shape-dependent kernel choices pinned --
     generator ``RB_STREAM`` / ``NO_RB_SPLIT``, front ``FR_NJ`` / ``FR_FFN_SPLIT`` -- and equal to operand rounding otherwise), so the result does not depend on how the files are grouped.  A synthesizer that is not the HIP one, or an
-    index only real faiss reads, takes the plain per-file loop over ``self.pipeline``."""
+    index only real faiss reads, or ``RVCMI_PIPELINE_BATCH=0``, takes the plain per-file loop over ``self.pipeline``."""
     audios = list(audios)
     f0_files = list(f0_files) if f0_files is not None else [None] * len(audios)
     if len(f0_files) != len(audios):
         raise ValueError("f0_files must hold one entry per input")
     if if_f0 == 2 and len(audios) > 1:
         raise ValueError("if_f0 == 2 hands ONE precomputed (pitch, pitchf) pair to the pipeline (pipeline.py:268-269); convert such inputs one by one")
+    import os
+
     index, needs_ref = _open_index(self, file_index, index_rate)
-    if needs_ref or not _ragged_capable(net_g):
+    # RVCMI_PIPELINE_BATCH=0 (the switch pipeline_hip honours for a file's segments) turns cross-file batching off too
+    if needs_ref or not _ragged_capable(net_g) or os.environ.get("RVCMI_PIPELINE_BATCH", "1") == "0":
         return [self.pipeline(model, net_g, sid, a, times, f0_up_key, f0_method, file_index, index_rate, if_f0, filter_radius, tgt_sr,
                               resample_sr, rms_mix_rate, version, protect, f) for a, f in zip(audios, f0_files)]
     if len(audios) > MAX_FILES_PER_GROUP:  # bound what is resident at once (HuBERT frames and waveforms of a group); same order, same draws

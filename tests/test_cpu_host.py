@@ -172,6 +172,13 @@ def _convert_batch_worker(rank, world, port, n_files):
         assert own == exp and len(batches) == 1
     with pytest.raises(ValueError):
         convert_batch(paths, gather=False, device=torch.device("cpu"))
+    # what may be GATHERED is bounded: a waveform-sized array inside ONE rank's results raises on EVERY rank before the collective
+    # (nobody is left waiting in gather_object); the same results stay legal with gather=False
+    big = lambda p, ix: ("Success", (48000, np.zeros(480000, np.int16))) if p == "clip_05.wav" else "Success"
+    with pytest.raises(ValueError, match="MAX_GATHER_ELEMENTS"):
+        convert_batch(paths, big, gather=True, device=torch.device("cpu"))
+    kept = convert_batch(paths, big, gather=False, device=torch.device("cpu"))
+    assert [p for p, _ in kept] == paths[lo:hi]
     dist.barrier()
     dist.destroy_process_group()
 
@@ -209,6 +216,21 @@ def test_bench_gpus_flag_launches_that_many_ranks_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_agree"] and d["shards_cover"] and d["index_blob_bytes"] == 1 << 20
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+
+
+def test_bench_config3_world_8_dry_run_gloo():
+    """BASELINE configs[3]'s partition without hardware: `bench.py --gpus 8 --config 3 --dist-selftest` self-launches 8 gloo ranks,
+    64 clips per rank (512 in all), ONE broadcast of rank 0's blob, `ranks_agree` on the bytes and on a value derived from them,
+    rank 0 alone prints the line.  (No scaling curve is simulated: the line carries no throughput.)"""
+    import json
+
+    r = _run_bench(["--gpus", "8", "--config", "3", "--dist-selftest"], timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_agree"] and d["shards_cover"] and d["clips"] == 512 and d["clips_per_rank"] == [64] * 8
+    assert "value" not in d and "--nproc-per-node=8" in r.stderr
 
 
 def test_bench_refuses_a_mislabelled_multi_gpu_run():

@@ -584,6 +584,84 @@ def test_convert_files_batches_several_files_and_equals_the_per_file_pipeline(rv
     assert not hasattr(pl.Pipeline, "convert_files")
 
 
+def test_convert_files_with_the_launcher_defaults_meets_the_reference_golden(rvc_tree, gpu, tmp_path, monkeypatch, capsys):
+    """What PRODUCTION runs: ``Pipeline.convert_files`` on five files with NO option pinned -- the 13-segment ragged batch picks the
+    kernel families, tile heights and the FFN realisation the launchers choose for that shape (not the ones a single file's call picks,
+    which is what the bit-equality test above pins).  The fixture file (reference noise injected for its three segments) must be within
+    1e-3 RMS of the waveform the REAL reference ``Pipeline.pipeline`` returned (golden pipeline_v2_48k_webui); the same for the file
+    converted alone (the other set of launcher choices).  The distance between the two realisations is stated as an RMS (the round-5
+    note "1.3e-3 of full scale apart" was a max-abs figure) and bounded: a file's waveform may depend on what it was batched with only
+    far inside the parity bar."""
+    import functools
+    import types
+
+    import rvc_amd
+    from oracle import ivf_oracle as io
+    from rvc_amd.front import infer_hip
+
+    d = load_golden("pipeline_v2_48k_webui")
+    seed = int(d["seed"])
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    rvc_amd.install(device=gpu, operand="fp16")
+    import infer.modules.vc.pipeline as pl
+    import rvc.synthesizer as rs
+
+    net_g, _ = rs.get_synthesizer(make_cpt(seed), gpu)  # launcher defaults: nothing pinned
+    config = types.SimpleNamespace(device=gpu, **{k[4:]: (bool(d[k]) if k == "cfg_is_half" else int(d[k])) for k in d if k.startswith("cfg_")})
+    pipe = pl.Pipeline(cfg.sr, config)
+    pipe.f0_gen = types.SimpleNamespace(rmvpe=synth.FakeRMVPE(gpu, seed), is_half=False, device=gpu)
+    path = str(tmp_path / "added.index")
+    io.write_index(synth.make_ivf(int(d["index_n"]), int(d["index_d"]), seed=int(d["index_seed"])), path)
+    n0 = int(d["n_audio"])
+    audios = [synth.make_audio16k(n0, seed), synth.make_audio16k(16000 * 2 + 77, seed + 1), synth.make_audio16k(n0 // 2 + 4321, seed + 2),
+              synth.make_audio16k(16000, seed + 3), synth.make_audio16k(50000, seed + 4)]
+    hub = synth.FakeHubert(768, seed)
+    tail = (int(d["f0_up_key"]), "rmvpe", path, float(d["index_rate"]), 1, int(d["filter_radius"]), cfg.sr, 0, float(d["rms_mix_rate"]),
+            "v2", float(d["protect"]))
+    noise = synth.infer_noise([int(x) for x in d["seg_frames"]], cfg.upp)
+    raw_infer = functools.partial(infer_hip, net_g, net_g._rvcmi_front)
+    shapes = []
+
+    def infer_with_reference_noise(phone, lengths, sid, *a, **k):
+        shapes.append([int(x) for x in lengths.tolist()])
+        nz, nd = k["noise_zp"].clone(), k["noise_dec"].clone()
+        for b, (z_b, d_b) in enumerate(noise):  # items 0..2 = the fixture file's segments
+            n = z_b.shape[2]
+            assert int(lengths[b]) == n
+            nz[b, :, :n], nd[b, :n * cfg.upp] = z_b[0].to(gpu), d_b[0].to(gpu)
+        k["noise_zp"], k["noise_dec"] = nz, nd
+        return raw_infer(phone, lengths, sid, *a, **k)
+
+    infer_with_reference_noise._rvcmi_ragged = True
+    net_g.infer = infer_with_reference_noise
+    ref = d["out"] / 32768.0
+
+    def convert(files):
+        torch.manual_seed(5)
+        return pipe.convert_files(hub, net_g, int(d["sid"]), [a.copy() for a in files], [0, 0, 0], *tail)[0] / 32768.0
+
+    in_batch = convert(audios)
+    assert len(shapes) == 1 and len(shapes[0]) == 13, shapes  # ONE 13-segment ragged batch
+    alone = convert(audios[:1])
+    assert shapes[1] == [int(x) for x in d["seg_frames"]]
+    e_batch, e_alone, apart = rms(in_batch, ref), rms(alone, ref), rms(in_batch, alone)
+    # the two FFN realisations on the SAME batch (everything else as the launcher chose): the front's contribution alone
+    net_g._rvcmi_front.set_option("FR_FFN_SPLIT", 1)
+    split = convert(audios)
+    net_g._rvcmi_front.set_option("FR_FFN_SPLIT", 0)
+    fused = convert(audios)
+    net_g._rvcmi_front.set_option("FR_FFN_SPLIT", None)
+    ffn_rms, ffn_max = rms(split, fused), float(np.abs(split - fused).max())
+    with capsys.disabled():
+        print("\n[convert_files, launcher defaults] fixture file vs the reference golden: in the 13-segment batch RMS %.3e, alone %.3e; "
+              "batch vs alone RMS %.3e (max abs %.3e); split-FFN vs fused-FFN on the same batch RMS %.3e (max abs %.3e); waveform RMS %.3f"
+              % (e_batch, e_alone, apart, float(np.abs(in_batch - alone).max()), ffn_rms, ffn_max, float(np.sqrt((ref ** 2).mean()))))
+    assert in_batch.shape == ref.shape and e_batch <= 1e-3, "fixture file inside the un-pinned five-file batch: RMS %.3e vs the reference" % e_batch
+    assert e_alone <= 1e-3, "fixture file alone, un-pinned: RMS %.3e vs the reference" % e_alone
+    assert apart <= 5e-4 and ffn_rms <= 5e-4, "a file's waveform moves by RMS %.3e with its batch (FFN realisations %.3e apart)" % (apart, ffn_rms)
+    rvc_amd.uninstall()
+
+
 def test_front_at_benchmark_size_matches_the_reference_modules(gpu):
     """enc_p + z_p + flow^-1 at T = 1198 (global attention over the whole 10 s clip) against the REFERENCE modules' own output
     (fixture bigfront_v2_B1_T1198_z), not only against the oracle restatement."""

@@ -275,3 +275,131 @@ def test_front_batch_16_equals_single_clips(gpu):
     with torch.no_grad():
         zr, m1, _ = front_oracle.infer_front(fcfg, wf, phone[15:16], pitch[15:16], lengths[15:16], sid[15:16], nz[15:16])
     assert rms(z[15:16].cpu(), zr * m1) <= Z_BAR["fp16"]
+
+
+def _f0_with_voiced_fraction(T, frac):
+    """synth.make_f0's contour (220 * 2^sin(2 pi t / 300) Hz) with the first (1 - frac) of every 200 frames unvoiced."""
+    f0 = synth.make_f0(1, T).clone()
+    t = torch.arange(T)
+    f0[0] = 220.0 * torch.pow(2.0, torch.sin(2 * np.pi * t.float() / 300.0))
+    f0[0, (t % 200) < int(round(200 * (1.0 - frac)))] = 0.0
+    return f0
+
+
+def _scale_z_path(wd, gain):
+    """`gain` on the decoder's z path: conv_pre and cond (weights and biases) x gain.  The leaky-ReLU stack is positively homogeneous
+    up to the 0.1-sized biases, so the stage activations -- and the pre-tanh waveform -- scale with it, while the excitation path
+    (noise_convs on the harmonic source) keeps its amplitude: gain 0.5 = source-dominated, small waveform; gain 2 = z-dominated, tanh
+    driven harder.  (A gain on every conv instead would compound over 76 layers.)"""
+    w = dict(wd)
+    for k in ("conv_pre.weight", "conv_pre.bias", "cond.weight", "cond.bias"):
+        w[k] = wd[k] * gain
+    return w
+
+
+def test_whole_infer_parity_sweep_over_weight_draws_gains_and_voicing(gpu, capsys):
+    """The parity headroom of the shipped arithmetic (fp16 MFMA operands + fp16 inter-stage streams) is not a property of ONE weight
+    draw: whole ``infer`` (rvc/layers/synthesizers.py:160-203) on a full 10 s clip, T = 1198, against the oracle (pinned to the reference
+    at 2e-6 by the goldens) for 5 weight seeds x z-path gains {0.5, 1, 2} x voiced fractions {0.2, 0.8} -- 30 clips.  Every one must
+    meet the north star's 1e-3 RMS; the worst is printed."""
+    import rvc_amd
+
+    T = 1198
+    fcfg, cfg = FrontConfig(), nsf_oracle.CONFIGS["v2_48k"]
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 8 else 16))
+    rows = []
+    for seed in (1234, 7, 99, 2024, 31337):
+        wf, wd0 = synth.make_front_weights(fcfg, seed), synth.make_dec_weights(cfg, seed)
+        fr = hip_front(fcfg, wf, "fp16", gpu, max_B=1, max_T=T)
+        phone = synth.make_phone(1, T, 768, seed)
+        lengths, sid = torch.tensor([T]), torch.tensor([seed % 100])
+        nz = torch.randn(1, 192, T, generator=torch.Generator().manual_seed(seed + 8))
+        noise = nsf_oracle.reference_noise(1, T, cfg.upp, 114514 + seed)
+        for frac in (0.2, 0.8):
+            pitchf = _f0_with_voiced_fraction(T, frac)
+            pitch = synth.make_pitch(pitchf)
+            with torch.no_grad():
+                zr, m1, g = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, nz)
+            z = fr(phone.to(gpu), pitch.to(gpu), lengths.to(gpu), g.to(gpu), 0, noise=nz.to(gpu))
+            for gain in (0.5, 1.0, 2.0):
+                wd = _scale_z_path(wd0, gain)
+                with torch.no_grad():
+                    ref = nsf_oracle.generator_forward(cfg, wd, zr * m1, pitchf, g, noise)
+                dec = rvc_amd.NSFGeneratorHIP(vars(cfg), wd, device=gpu, operand="fp16", max_B=1, max_T=T)
+                out = dec(z, pitchf.to(gpu), g.to(gpu), noise=noise.to(gpu)).cpu()
+                del dec
+                assert torch.isfinite(out).all()
+                rows.append((rms(out, ref), seed, gain, frac, float(ref.pow(2).mean().sqrt()), float((ref.abs() > 0.99).float().mean())))
+    rows.sort(reverse=True)
+    with capsys.disabled():
+        print("\n[whole-infer parity sweep, T=1198, fp16 operands + fp16 streams] %d clips: worst RMS %.3e, median %.3e, best %.3e; the five worst:"
+              % (len(rows), rows[0][0], rows[len(rows) // 2][0], rows[-1][0]))
+        for r in rows[:5]:
+            print("    rms %.3e  seed %-6d gain %.1f voiced %.1f  waveform rms %.3f  beyond +-0.99: %.4f" % r)
+    assert rows[0][0] <= 1e-3, "whole infer parity sweep: worst RMS %.3e (seed %d, gain %.1f, voiced fraction %.1f)" % rows[0][:4]
+
+
+def _scale_homogeneously(wd, G):
+    """The SAME function with every activation of the stack G times larger: the leaky-ReLU stack is positively homogeneous, so scaling
+    what enters it (conv_pre, cond, the noise convs: weights and biases) and every bias inside it (ups, ResBlock convs) by G and
+    conv_post by 1 / G changes nothing in exact arithmetic -- and with G a power of two nothing in fp32 either."""
+    w = {}
+    for k, v in wd.items():
+        if k.startswith(("conv_pre.", "cond.", "noise_convs.")) or (k.endswith(".bias") and k.startswith(("ups.", "resblocks."))):
+            w[k] = v * G
+        elif k == "conv_post.weight":
+            w[k] = v / G
+        else:
+            w[k] = v
+    return w
+
+
+def test_fp16_range_headroom_and_saturation_against_the_fp32_reference(gpu, capsys):
+    """fp16 MFMA operands and fp16 inter-stage streams have a RANGE (+-65504) as well as a precision.  The generator is rescaled
+    homogeneously (`_scale_homogeneously`: same function, bit-identical fp32 reference for a power-of-two G, every activation G x larger):
+
+      * G puts the largest tapped activation at ~1/8 of the fp16 range: the waveform must equal the unscaled run's to rounding (same
+        mantissas, other exponents) -- the parity claim does not depend on the absolute scale of a checkpoint's activations;
+      * G puts it 1.25-2.5x BEYOND the range (asserted on the oracle's fp32 taps): the publish path converts with SATURATION
+        (`v_med3_f32(x, 0.1 x, 65504)` in pack4_lrelu, `pack4_h` for the streams; csrc/nsf_kernels.hpp), so the clipped peaks cost accuracy
+        locally but the waveform stays finite and close to the fp32 reference; an overflowing conversion would produce inf, and inf - inf =
+        NaN in the next conv."""
+    import rvc_amd
+
+    T = 200
+    cfg = nsf_oracle.CONFIGS["v2_48k"]
+    wd = synth.make_dec_weights(cfg, 1234)
+    z, f0, g = synth.make_dec_inputs(cfg, 1, T)
+    noise = nsf_oracle.reference_noise(1, T, cfg.upp)
+    taps = {}
+    with torch.no_grad():
+        ref = nsf_oracle.generator_forward(cfg, wd, z, f0, g, noise, taps=taps)
+    amax = max(float(v.abs().max()) for k, v in taps.items() if k != "har")
+    run = lambda w: rvc_amd.NSFGeneratorHIP(vars(cfg), w, device=gpu, operand="fp16", max_B=1, max_T=T)(
+        z.to(gpu), f0.to(gpu), g.to(gpu), noise=noise.to(gpu)).cpu()
+    out0 = run(wd)
+    e0 = rms(out0, ref)
+    G_in = 2.0 ** np.floor(np.log2(65504.0 / 8 / amax))
+    G_sat = 2.0 ** np.ceil(np.log2(1.25 * 65504.0 / amax))
+    res = {}
+    for name, G in (("inside", G_in), ("beyond", G_sat)):
+        w = _scale_homogeneously(wd, G)
+        tp = {}
+        with torch.no_grad():
+            r = nsf_oracle.generator_forward(cfg, w, z, f0, g, noise, taps=tp)
+        assert torch.equal(r, ref), "the rescaled fp32 reference must be bit-identical (G = %g)" % G
+        peak = max(float(v.abs().max()) for k, v in tp.items() if k != "har")
+        frac = float(np.mean([float((v.abs() > 65504).float().mean()) for k, v in tp.items() if k != "har"]))
+        o = run(w)
+        assert torch.isfinite(o).all(), "%s the fp16 range (G = %g): non-finite waveform" % (name, G)
+        res[name] = (G, peak, frac, rms(o, ref), rms(o, out0))
+    with capsys.disabled():
+        print("\n[fp16 range] unscaled: largest tapped activation %.1f, RMS vs the reference %.3e" % (amax, e0))
+        for name in ("inside", "beyond"):
+            print("    %s: G = 2^%d, largest tapped activation %.3g (%.2f x 65504), %.4f %% of the tapped values beyond the range; "
+                  "RMS vs the fp32 reference %.3e, vs the unscaled HIP run %.3e" % ((name, int(np.log2(res[name][0])), res[name][1],
+                                                                                   res[name][1] / 65504.0, 100 * res[name][2]) + res[name][3:]))
+    assert res["inside"][1] < 65504 / 4 and res["inside"][3] <= 1e-3 and res["inside"][4] <= 1e-4, res["inside"]
+    assert res["beyond"][1] > 65504, "the case must drive activations beyond the fp16 range (peak %.3g)" % res["beyond"][1]
+    assert res["beyond"][3] <= 5e-2, "saturating conversions: RMS %.3e vs the fp32 reference with %.4f %% of the activations clipped" % (
+        res["beyond"][3], 100 * res["beyond"][2])

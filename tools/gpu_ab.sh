@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 for r in $(seq 1 $rounds); do
   for v in A B; do
     if [ $v = A ]; then e="$ea"; else e="$eb"; fi
-    env $e python bench.py --no-cpu-baseline --no-gpu-torch-baseline --repeats 5 > gpurun_out/ab_${name}_${v}${r}.json 2> gpurun_out/ab_${name}_${v}${r}.err
+    env $e python bench.py --no-cpu-baseline --no-gpu-torch-baseline --no-extra --repeats 5 > gpurun_out/ab_${name}_${v}${r}.json 2> gpurun_out/ab_${name}_${v}${r}.err
     python - "$name" $v $r "$e" <<'PY'
 import json, sys
 name, v, r, e = sys.argv[1:5]

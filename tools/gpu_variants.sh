@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for r in $(seq 1 $rounds); do
   i=0
   for e in "$@"; do
-    env $e python bench.py --no-cpu-baseline --no-gpu-torch-baseline --repeats 3 ${BENCH_ARGS} > gpurun_out/var_${name}_${i}_${r}.json 2> gpurun_out/var_${name}_${i}_${r}.err
+    env $e python bench.py --no-cpu-baseline --no-gpu-torch-baseline --no-extra --repeats 3 ${BENCH_ARGS} > gpurun_out/var_${name}_${i}_${r}.json 2> gpurun_out/var_${name}_${i}_${r}.err
     python - "$name" $i $r "$e" <<'PY'
 import json, sys
 name, i, r, e = sys.argv[1:5]
