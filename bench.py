@@ -62,6 +62,9 @@ def parse():
     p.add_argument("--torch-gpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-extra", action="store_true", help="skip the batch64 / stream / bf16 objects of the default N=1 line")
+    p.add_argument("--e2e", action="store_true",
+                   help="end-to-end Pipeline.convert_files with HuBERT / RMVPE architecture proxies on PyTorch-ROCm: wall per clip and its split, 1 and N files")
+    p.add_argument("--e2e-files", type=int, default=64)
     p.add_argument("--stream", action="store_true",
                    help="BASELINE configs[4]: realtime chunks (v1/40k generator, T=31 frames -> n_res, 16 queries); prints p50 latency")
     a = p.parse_args()
@@ -545,6 +548,131 @@ def leg_operands(a, dev, cfg, w, index, phone_d, zd, f0d, gd, nd, out_default, o
     return res
 
 
+def e2e_mode(a):
+    """BASELINE.md section 3's end-to-end picture (`--e2e`): what a user's `VC.vc_multi` / `vc_single` costs per 10 s clip once the hot
+    path is the HIP one -- `Pipeline.convert_files` (bound by `rvc_amd.install()` on the RVC-shaped skeleton of tests/skeleton) with the
+    WebUI defaults (rmvpe, index file + index_rate 0.75, rms_mix_rate 0.25, protect 0.33), fed by ARCHITECTURE PROXIES of the two networks the
+    north star leaves on PyTorch-ROCm (tools/e2e_proxies.py: HuBERT-base via transformers, the RMVPE U-Net + GRU restated; random weights),
+    for 1 file and for 64 files.  Two passes per case: (1) the plain call, wall clock, no extra synchronisation = the figure a user sees;
+    (2) the same call with every stage bracketed by `torch.cuda.synchronize()` + `perf_counter` = the split (its total is a little larger:
+    the brackets remove the overlap of host work with queued GPU work).  Stages: host high-pass `filtfilt` (pipeline.py:216) and cut-point
+    search (:219-232), reading the index file (the reference re-reads it per call too, :205-218), RMVPE proxy incl. mel + salience decode, HuBERT proxy, retrieval + blend, `net_g.infer` (front + generator), finish
+    (`change_rms`, scaling, D2H copy), other (padding, slicing, Python)."""
+    import tempfile
+    import types
+
+    import rvc_amd
+    import rvc_amd.pipeline as rp
+    from oracle import ivf_oracle, nsf_oracle, synth
+    from oracle.front_oracle import FrontConfig
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "skeleton"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from e2e_proxies import HubertProxy, RmvpeProxy
+
+    dev = torch.device("cuda", 0)
+    half = a.operand != "fp32"
+    rvc_amd.install(device=dev, operand=a.operand)
+    import infer.modules.vc.pipeline as pl
+    import rvc.synthesizer as rs
+
+    cfg, fcfg = nsf_oracle.CONFIGS["v2_48k"], FrontConfig()
+    weight = dict(synth.make_front_weights(fcfg, 1234))
+    weight.update({"dec." + k: v for k, v in synth.make_dec_weights(cfg, 1234).items()})
+    cpt = dict(weight=weight, f0=1, version="v2", info="synthetic", sr="48k",
+               config=[1025, 32, 192, 192, 768, 2, 6, 3, 0, "1", cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes, cfg.upsample_rates,
+                       cfg.upsample_initial_channel, cfg.upsample_kernel_sizes, 109, cfg.gin_channels, cfg.sr])
+    net_g, _ = rs.get_synthesizer(cpt, dev)
+    if half:
+        net_g = net_g.half()  # infer/modules/vc/modules.py:94-95
+    # configs/config.py: x_pad 1 / x_query 6 / x_center 38 / x_max 41 (the geometry BASELINE's T = 1198 frames per 10 s clip assumes)
+    config = types.SimpleNamespace(device=dev, is_half=half, x_pad=1, x_query=6, x_center=38, x_max=41)
+    pipe = pl.Pipeline(cfg.sr, config)
+    pipe.f0_gen = types.SimpleNamespace(rmvpe=RmvpeProxy(dev, half=half), is_half=half, device=dev)
+    hub = HubertProxy(dev, half=half)
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "added.index")
+    ivf_oracle.write_index(synth.make_ivf(a.index_n, 768, seed=4321, kmeans_iters=1), path)
+    tail = (0, "rmvpe", path, a.index_rate, 1, 3, cfg.sr, 0, 0.25, "v2", 0.33)
+
+    acc = {}
+    orig = {}
+
+    def timed(name, fn):
+        def w(*args, **kw):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn(*args, **kw)
+            torch.cuda.synchronize()
+            acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+            return r
+        return w
+
+    def instrument(on):
+        names = (("index_read_file_h2d", "_open_index"), ("cut_points_host", "_cut_points"), ("rmvpe_proxy_mel_net_decode", "_rmvpe_on_device"), ("hubert_proxy", "hubert_device"),
+                 ("retrieval_blend", "blend_segments"), ("infer_front_generator", "infer_segments"), ("finish_rms_scale_d2h", "_finish_file"))
+        if on:
+            for label, attr in names:
+                orig[attr] = getattr(rp, attr)
+                setattr(rp, attr, timed(label, orig[attr]))
+            orig["signal"] = pl.signal
+            pl.signal = types.SimpleNamespace(filtfilt=timed("highpass_filtfilt_host", orig["signal"].filtfilt), butter=orig["signal"].butter)
+        else:
+            for label, attr in names:
+                setattr(rp, attr, orig[attr])
+            pl.signal = orig["signal"]
+
+    def convert(audios):
+        return pipe.convert_files(hub, net_g, 0, [x.copy() for x in audios], [0, 0, 0], *tail)
+
+    cases = {}
+    for n, warm, reps in ((1, 3, 7), (a.e2e_files, 1, 3)):
+        audios = [synth.make_audio16k(160000, 1234 + i) for i in range(n)]
+        for _ in range(warm):
+            out = convert(audios)
+        torch.cuda.synchronize()
+        walls = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = convert(audios)
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+        assert len(out) == n and all(np.isfinite(o).all() and o.shape[0] == 480000 for o in out), [o.shape for o in out]
+        walls.sort()
+        wall = walls[len(walls) // 2]
+        instrument(True)
+        acc.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        convert(audios)
+        torch.cuda.synchronize()
+        tot = time.perf_counter() - t0
+        instrument(False)
+        split = {k: round(1e3 * v / n, 3) for k, v in acc.items()}
+        split["other_host_pad_slice_python"] = round(1e3 * (tot - sum(acc.values())) / n, 3)
+        feeders = split["hubert_proxy"] + split["rmvpe_proxy_mel_net_decode"]
+        host = split["highpass_filtfilt_host"] + split["cut_points_host"] + split["other_host_pad_slice_python"] + split["index_read_file_h2d"]
+        hot = split["retrieval_blend"] + split["infer_front_generator"]
+        cases["files_%d" % n] = {"files": n, "wall_ms_per_clip": round(1e3 * wall / n, 3), "rtf": CLIP_SECONDS * n / wall, "runs": reps,
+                                 "wall_ms_per_clip_min_max": [round(1e3 * walls[0] / n, 3), round(1e3 * walls[-1] / n, 3)],
+                                 "instrumented_total_ms_per_clip": round(1e3 * tot / n, 3), "split_ms_per_clip": split,
+                                 "groups_ms_per_clip": {"feeders_pytorch_rocm_proxies": round(feeders, 3), "host": round(host, 3),
+                                                        "hip_hot_path_retrieval_infer": round(hot, 3), "finish": split["finish_rms_scale_d2h"]},
+                                 "long_pole": max(split, key=split.get)}
+    rvc_amd.uninstall()
+    big = cases["files_%d" % a.e2e_files]
+    return {"metric": "end-to-end real-time factor per GPU, Pipeline.convert_files on 10 s clips (feeders = architecture proxies on PyTorch-ROCm)",
+            "value": big["rtf"], "unit": "x real-time (audio-sec/wall-sec), %d files per call" % a.e2e_files, "n_gpus": 1, "higher_is_better": True,
+            "dtype": "%s (is_half=%s: HuBERT / RMVPE proxies and net_g in half like infer/modules/vc/modules.py:94-95)" % (a.operand, half),
+            "data": "synthetic (seeded audio, weights, index; random-weight architecture proxies for HuBERT-base and RMVPE)",
+            "config": {"workload": "Pipeline.convert_files via rvc_amd.install() on tests/skeleton: WebUI defaults (rmvpe, index file %dx768 index_rate %.2f, "
+                                   "rms_mix_rate 0.25, protect 0.33, x_pad 1), 10 s / 16 kHz inputs -> 48 kHz" % (a.index_n, a.index_rate)},
+            "cases": cases,
+            "reading": "hot path (retrieval + net_g.infer) vs everything around it: see groups_ms_per_clip; the split pass synchronises around every "
+                       "stage, the wall figures do not"}
+
+
 _REAL_STDOUT = None
 
 
@@ -577,7 +705,7 @@ def main():
     a = parse()
     if a.torch_gpu_baseline_worker:
         return torch_gpu_baseline_worker(a)
-    if not a.stream:
+    if not a.stream and not a.e2e:
         ensure_world(a)  # may replace this process with the N-rank launcher (before fd 1 is touched)
     if _REAL_STDOUT is None:
         # libraries write banners to fd 1 (RCCL prints its version block at the first communicator): keep stdout for the JSON line
@@ -586,6 +714,8 @@ def main():
         os.dup2(2, 1)
     if a.stream:
         return emit(stream_mode(a))
+    if a.e2e:
+        return emit(e2e_mode(a))
     if a.dist_selftest:
         return dist_selftest(a)
     rank = int(os.environ.get("RANK", "0"))

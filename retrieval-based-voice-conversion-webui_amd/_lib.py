@@ -127,6 +127,25 @@ ERR_IO = -3
 _lib = None
 
 
+def _unit_deps(src: str) -> List[str]:
+    """`src` and every local header it includes, transitively (`#include "x.hpp"` next to it, `rvcmi.h` under include/)."""
+    import re
+
+    seen, todo = [], [src]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f, errors="replace").read(), re.M):
+            for base in (os.path.dirname(f), os.path.join(_HERE, "..", "include")):
+                cand = os.path.normpath(os.path.join(base, inc))
+                if os.path.exists(cand):
+                    todo.append(cand)
+                    break
+    return seen
+
+
 def build(verbose: bool = True, force: bool = False) -> str:
     """Compile librvcmi.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
@@ -137,9 +156,14 @@ def build(verbose: bool = True, force: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    for s in srcs:  # compile the translation units in parallel
+    flags_key = " ".join([os.environ.get(k, "") for k in ("RVCMI_DEFINES", "RVCMI_DEV_STAMPS", "RVCMI_NO_MFMA_VGPR_FORM", "HIPCC")])
+    stamp = os.path.join(CSRC, ".build_flags")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == flags_key
+    for s in srcs:  # compile the translation units in parallel; a unit whose object is newer than it and every header it includes is kept
         o = os.path.join(CSRC, os.path.basename(s) + ".o")
         objs.append(o)
+        if not force and same_flags and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in _unit_deps(s)):
+            continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
         if not os.environ.get("RVCMI_NO_MFMA_VGPR_FORM"):
             # MFMA results in VGPRs wherever the 256 architectural VGPRs allow it: by default LLVM puts every accumulator in an
@@ -157,6 +181,8 @@ def build(verbose: bool = True, force: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode:
             raise RvcmiError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    with open(stamp, "w") as f:
+        f.write(flags_key)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print("[rvcmi build]", " ".join(cmd), file=sys.stderr)

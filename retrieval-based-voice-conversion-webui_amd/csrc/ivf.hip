@@ -1164,13 +1164,22 @@ static const char* lm_unusable_reason(const rvcmi_ivf* h, int64_t nq) {
     const BlobHeader& b = h->hdr;
     // from 16 queries on (round 5; 64 before): a realtime chunk's 16 guarded rows take 8 + 11 + 13 us in plan + tiles + select against 51 us in
     // the query-major kernel, whose one block per query walks a ~300-row list alone (chunk p50 0.487 -> 0.465 ms, ABAB); option IVF_LM_MIN
-    if (nq < h->opt.geti("IVF_LM_MIN", 16)) return "fewer than 16 queries";
+    const int lm_min = h->opt.geti("IVF_LM_MIN", 16);
+    if (nq < lm_min) {
+        static thread_local char why[64];
+        snprintf(why, sizeof(why), "fewer than %d queries%s", lm_min, lm_min == 16 ? "" : " (option IVF_LM_MIN)");
+        return why;
+    }
     if (std::min<int64_t>(b.nprobe, b.nlist) != 1) return "nprobe > 1";
     if ((b.d % CG_K) != 0) return "d is not a multiple of 32";
     if (b.nlist > LM_MAXL) return "more than 16384 lists (the one-block planner counts them in LDS)";
     if (b.ntotal < 1) return "empty index";
     if (!h->lm_ready || h->lm_maxlen < 1) return "list statistics not reserved";
     if (nq >= (1ll << 30)) return "2^30 queries or more";
+    // a pass holds at least 64 queries (lm_pass_queries): with one list of more than 2^22 rows even that pass would exceed the 1 GiB bound of
+    // the score scratch (the bound was documented but the 64-query floor could break it by a wide margin)
+    if ((int64_t)align_up((uint64_t)h->lm_maxlen, 32) * 4 * 64 > ((int64_t)1 << 30))
+        return "a list of more than 4 194 304 rows (64 queries x the longest list x 4 B would exceed the 1 GiB score scratch)";
     return nullptr;
 }
 // queries per pass of the list-major kernels: the fp32 score scratch (queries x longest list) stays at or below 1 GiB
@@ -1568,15 +1577,23 @@ static int ivf_build_impl(int d, int64_t n, const float* x_host, int64_t nlist, 
                 for (int64_t l = 0; l < nlist; ++l) by_cost[l] = by_S[l] = l;
                 std::sort(by_cost.begin(), by_cost.end(), [&](int64_t a1, int64_t b1) { return cost[a1] < cost[b1] || (cost[a1] == cost[b1] && a1 < b1); });
                 std::sort(by_S.begin(), by_S.end(), [&](int64_t a1, int64_t b1) { return S[a1] > S[b1] || (S[a1] == S[b1] && a1 < b1); });
-                std::vector<char> used(nlist, 0);
+                // used[]: centres that took part in a move of this iteration (the moved centre, the split cluster, the receiving centre) -- none
+                // of them is deleted or split again.  moved[]: centres that are GONE from their old place: a later candidate whose nearest centre
+                // was moved has a stale cost (n_j |c_j - c_nn|^2 against a centre that is no longer there) and is skipped, so every accepted
+                // move still satisfies gain > cost and the objective cannot go up.
+                std::vector<char> used(nlist, 0), moved(nlist, 0);
                 const int64_t maxmoves = std::max<int64_t>(1, nlist / 20);
                 int64_t moves = 0, si = 0;
                 for (int64_t ci = 0; ci < nlist && moves < maxmoves; ++ci) {
                     const int64_t j = by_cost[ci];
-                    if (used[j] || nn[j] < 0 || !(cost[j] < INFINITY)) continue;
-                    while (si < nlist && (used[by_S[si]] || by_S[si] == j || by_S[si] == nn[j] || off[by_S[si] + 1] - off[by_S[si]] < 2)) ++si;
-                    if (si >= nlist) break;
-                    const int64_t o = by_S[si];
+                    if (used[j] || nn[j] < 0 || !(cost[j] < INFINITY) || moved[nn[j]]) continue;
+                    // the global cursor passes only clusters that are out for EVERY later candidate (used, or too small to split); the clusters
+                    // excluded for this candidate alone (j itself, its receiver) are stepped over by the local cursor
+                    while (si < nlist && (used[by_S[si]] || off[by_S[si] + 1] - off[by_S[si]] < 2)) ++si;
+                    int64_t sj = si;
+                    while (sj < nlist && (used[by_S[sj]] || by_S[sj] == j || by_S[sj] == nn[j] || off[by_S[sj] + 1] - off[by_S[sj]] < 2)) ++sj;
+                    if (sj >= nlist) break;
+                    const int64_t o = by_S[sj];
                     int64_t far = order[off[o]];
                     for (int64_t p = off[o]; p < off[o + 1]; ++p)
                         if (dist[order[p]] > dist[far]) far = order[p];
@@ -1594,8 +1611,8 @@ static int ivf_build_impl(int d, int64_t n, const float* x_host, int64_t nlist, 
                     if (!(gain > cost[j])) break;  // the cheapest deletion no longer pays for the best split: done for this iteration
                     memcpy(&cent[(size_t)j * d], xp, (size_t)d * 4);
                     used[j] = used[o] = used[nn[j]] = 1;
+                    moved[j] = 1;
                     ++moves;
-                    ++si;
                 }
             }
         }

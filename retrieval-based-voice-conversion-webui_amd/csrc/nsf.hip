@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS", "RBF_SMALL"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "UPS_NJ_256", "UPS_VPW_256", "POST_DMA", "POST_DMA_OCC", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS", "RBF_SMALL"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -423,11 +423,21 @@ template <typename OpT, int CIN, int MI, int WV>
 static void launch_ups_inst(UpsArgs a, int nj, int B, hipStream_t st) {
     const int TQ = 32 * nj * (4 / WV);
     size_t smem = (size_t)a.tile_rows * Tile<CIN>::STRIDE + (a.nz_k1 ? (size_t)(TQ * a.u * a.ns + 16) * 2 : 0);
+    // option UPS_BL: [2][cout] fp32 LDS copy of bias / bn.  Reserved FIRST so that both bounds below see it (appended after
+    // the checks, a 52 KB block became 54 KB -- two resident blocks instead of three -- and a tile near 160 KB would have failed at launch);
+    // dropped where it would break the 160 KB limit
+    if (a.bias_off && a.cout % 4 == 0 && (smem + 15) / 16 * 16 + (size_t)2 * a.cout * 4 <= 160 * 1024) {
+        smem = (smem + 15) / 16 * 16;
+        a.bias_off = (int)smem;
+        smem += (size_t)2 * a.cout * 4;
+    } else {
+        a.bias_off = 0;
+    }
     if (smem > 160 * 1024) RVCMI_FAIL(RVCMI_ERR_INVALID, "upsampler LDS tile too large (%zu B)", smem);
     const int per_block = WV * a.vpw;
     dim3 grid((a.Lin + TQ - 1) / TQ, (a.nvt + per_block - 1) / per_block, B);
     // row-wise output through an LDS tile when the block owns whole rows (all phases and channels) and the tile keeps the block small
-    // enough for three per CU; (cout * esz) must be whole 16-byte chunks
+    // enough for three per CU (everything counted: operand tile, har copy, bias copy, output tile); (cout * esz) must be whole 16-byte chunks
     {
         const int esz = a.out_half ? 2 : 4;
         const size_t ot = (size_t)TQ * a.u * ((size_t)a.cout * esz + 16);
@@ -438,13 +448,6 @@ static void launch_ups_inst(UpsArgs a, int nj, int B, hipStream_t st) {
         } else {
             a.out_tr = 0;
         }
-    }
-    if (a.bias_off && a.cout % 4 == 0) {  // option UPS_BL: [2][cout] fp32 LDS copy of bias / bn behind everything else
-        smem = (smem + 15) / 16 * 16;
-        a.bias_off = (int)smem;
-        smem += (size_t)2 * a.cout * 4;
-    } else {
-        a.bias_off = 0;
     }
     if (nj == 4) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 4>), grid, dim3(256), smem, st, a);
     else if (nj == 2) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 2>), grid, dim3(256), smem, st, a);
@@ -897,7 +900,13 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
         for (int j = 0; j < nk; ++j) maxnd0 = std::max(maxnd0, s.rb[j].size());
         // X0 of this stage is fp16: where the consumer is k_rb_full (C <= 64), and -- round 5 -- where the whole resblocks WILL run on the
         // streaming kernel with its coalesced step IO (C = 128 on clips long enough for strips; decided by a dry run of the planner)
-        const bool x0h_stream = op != RVCMI_OPERAND_F32 && C > 64 && y_f16(h) && h->opt.geti("X0_F16", 1) != 0 && !h->opt.on("X0_F16_NOSTREAM") &&
+        // ... decided HERE, once, together with the branch the ResBlocks will take below: the conv-by-conv path for a handful of rows reads X0
+        // as fp32 (IN_F32_ACT) and comes BEFORE the streaming kernel in that chain, so it must veto the fp16 X0 explicitly (ADVICE round 5:
+        // the two could not coincide only because the planner happens to refuse such short launches)
+        const bool rb_split = op != RVCMI_OPERAND_F32 &&
+                              ((C == 256 && (long)B * L <= RB_SPLIT_MAX_ROWS) || (C == 128 && (long)B * L <= RB_SPLIT_MAX_ROWS_128 && !h->opt.on("NO_RB_SPLIT128"))) &&
+                              nk <= 3 && !h->opt.on("NO_RB_SPLIT") && rb_stream_mode(h) != 1;
+        const bool x0h_stream = op != RVCMI_OPERAND_F32 && !rb_split && C > 64 && y_f16(h) && h->opt.geti("X0_F16", 1) != 0 && !h->opt.on("X0_F16_NOSTREAM") &&
                                 try_rb_stream_full(h, s, op, C, (int)L, B, nk, nullptr, st, lens, lm, true, true);
         const bool x0h = op != RVCMI_OPERAND_F32 && (x0_f16(h, C, maxnd0) || x0h_stream);
         char nm[48];
@@ -1017,11 +1026,16 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
                 const int v = h->opt.geti("UPS_NJ", nj);
                 if (v == 1 || v == 2 || v == 4) nj = v;
             }
+            if (s.cin == 256 && h->opt.has("UPS_NJ_256")) {  // dev: the stage whose launch is not HBM-bound (19 GFLOP in ~450 blocks)
+                const int v = h->opt.geti("UPS_NJ_256", nj);
+                if (v == 1 || v == 2 || v == 4) nj = v;
+            }
             const int TQ = 32 * nj * (4 / wv);
             ua.tile_rows = TQ + (hi - lo);
             const long qtiles = (Lin + TQ - 1) / TQ;
             int vpw = (ua.nvt + wv - 1) / wv;  // everything in one block ...
             while (vpw > 1 && qtiles * B * ((ua.nvt + wv * vpw - 1) / (wv * vpw)) < 300) --vpw;  // ... unless the grid would starve
+            if (s.cin == 256 && h->opt.has("UPS_VPW_256")) vpw = std::min(std::max(1, h->opt.geti("UPS_VPW_256", vpw)), (ua.nvt + wv - 1) / wv);
             ua.vpw = vpw;
             snprintf(nm, sizeof(nm), "ups_c%d", s.cin);
             const double flops = U.flops_per_pos * (double)Lin * B + 2.0 * s.nk * (double)L * C * B;
@@ -1083,8 +1097,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
                     run_conv(h, s.rb[j][m].second, a, B, nm, st);
                     src[j] = dst;
                 }
-        } else if (((C == 256 && (long)B * L <= RB_SPLIT_MAX_ROWS) || (C == 128 && (long)B * L <= RB_SPLIT_MAX_ROWS_128 && !h->opt.on("NO_RB_SPLIT128"))) &&
-                   nk <= 3 && !h->opt.on("NO_RB_SPLIT") && rb_stream_mode(h) != 1) {
+        } else if (rb_split) {
             // a handful of rows (realtime chunk): conv1 / conv2 of all resblocks as two output-channel-split launches per pair level
             snprintf(nm, sizeof(nm), "rb_split_c%d", C);
             for (size_t m = 0; m < maxnd; ++m) {
@@ -1356,6 +1369,19 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
     // ---- x = tanh(conv_post(leaky_relu(x)))                                    nsf.py:187-189
     const int nkk = c.n_resblock_kernels;
     h->prof.launch("conv_post", 2.0 * 7 * Cprev * (double)L * B, (double)B * L * (Cprev * nkk * (yhalf ? 2 : 4) + 4), st, [&] {
+        // round 6: three fp16 streams (every shipped config) through the LDS-DMA kernel: persistent blocks, next tile in flight (option POST_DMA)
+        if (yhalf && y[1] && y[2] && div == 3.f && (Cprev == 32 || Cprev == 16) && h->opt.geti("POST_DMA", 1) != 0) {
+            const int ntiles = (int)((L + POSTD_TT - 1) / POSTD_TT);
+            const int slots = std::max(1, num_cus() * h->opt.geti("POST_DMA_OCC", 3) / B);
+            const dim3 grid((unsigned)std::min(ntiles, slots), B);
+            if (Cprev == 32)
+                hipLaunchKernelGGL(k_post_dma<32>, grid, dim3(POSTD_TT), post_dma_smem<32>(), st, (const _Float16*)y[0], (const _Float16*)y[1],
+                                   (const _Float16*)y[2], h->post_w.as<float>(), out, (int)L, lens, lm);
+            else
+                hipLaunchKernelGGL(k_post_dma<16>, grid, dim3(POSTD_TT), post_dma_smem<16>(), st, (const _Float16*)y[0], (const _Float16*)y[1],
+                                   (const _Float16*)y[2], h->post_w.as<float>(), out, (int)L, lens, lm);
+            return;
+        }
         const size_t smem = (size_t)(7 * Cprev + (POST_TT + 6) * (Cprev + 4)) * 4;
         hipLaunchKernelGGL(k_post, dim3((unsigned)((L + POST_TT - 1) / POST_TT), B), dim3(256), smem, st, y[0], y[1], y[2],
                            h->post_w.as<float>(), out, (int)L, Cprev, div, yhalf ? 1 : 0, lens, lm);

@@ -426,6 +426,100 @@ static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ x
     }
 }
 
+// ---- k_post with register-free staging (round 6) ------------------------------------------------------------------------------
+// Same arithmetic as k_post for the shipped case (three fp16 streams, div = 3); what changes is HOW the bytes arrive.  k_post's block is a
+// chain load (15 x 16 B per thread held in registers) -> convert -> barrier -> conv -> barrier, and every value held across the load costs
+// registers.  Here a PERSISTENT block walks its tiles and the raw fp16 rows of tile i + 1 travel global -> LDS by LDS-DMA
+// (`global_load_lds_dwordx4`: no VGPR round trip, lane-linear 1 KB pieces; a tile's rows are contiguous in a [L][C] stream) while tile i
+// is converted (one LDS -> LDS pass: (a + b) + c, div3_exact, lrelu 0.01, fp32) and convolved.  Ordering: the pieces a wave issued are
+// retired by ITS `s_waitcnt vmcnt(0)`, then a barrier publishes all waves' pieces (the documented RAW rule for LDS-DMA); `raw` is free for
+// the next tile after the barrier that ends the convert pass.
+constexpr int POSTD_TT = 128;  // output rows per tile = threads per block (two waves); three blocks per CU
+template <int C>
+static __global__ void __launch_bounds__(POSTD_TT) k_post_dma(const _Float16* __restrict__ xa, const _Float16* __restrict__ xb,
+                                                             const _Float16* __restrict__ xc, const float* __restrict__ Wp /*[7][C]*/,
+                                                             float* __restrict__ out, int Lmax, const int* __restrict__ lens, int lmul) {
+    constexpr int TT = POSTD_TT, NW = TT / 64, S = C + 4, C8 = C / 8, ROWB = C * 2;
+    constexpr int TILEB = (TT + 6) * ROWB;                 // bytes of one stream's rows of a tile
+    constexpr int NP = (TILEB + 1023) / 1024, RAWB = NP * 1024;  // 1 KB DMA pieces per stream
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* w = (float*)smem_raw;                           // [7][C]
+    float* tile = w + 7 * C;                               // [TT + 6][C + 4] fp32
+    char* raw = (char*)(tile + (TT + 6) * S);              // [3][RAWB] fp16 rows as they lie in HBM
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 7 * C; i += TT) w[i] = Wp[i];
+    const int L = item_rows(lens, b, lmul, Lmax);
+    const size_t boff = (size_t)b * Lmax * C;
+    const int nvalid = (L + TT - 1) / TT, nall = (Lmax + TT - 1) / TT;
+    const char* src[3] = {(const char*)(xa + boff), (const char*)(xb + boff), (const char*)(xc + boff)};
+
+    auto issue = [&](int ti) {  // the (TT + 6) rows [t0 - 3, t0 + TT + 3) of the three streams; rows outside [0, L) are clamped here, zeroed in convert
+        const int t0 = ti * TT;
+#pragma unroll
+        for (int p0 = 0; p0 < (3 * NP + NW - 1) / NW; ++p0) {
+            const int p = p0 * NW + wave;  // wave-uniform
+            if (p < 3 * NP) {
+                const int st = p / NP, pp = p - st * NP;
+                const int o = pp * 1024 + lane * 16;
+                const int r = o / ROWB, col = o - r * ROWB;
+                const int tc = min(max(t0 - 3 + r, 0), L - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[st] + (size_t)tc * ROWB + col),
+                                                 (__attribute__((address_space(3))) void*)(raw + st * RAWB + pp * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    int ti = blockIdx.x;
+    if (ti < nvalid) issue(ti);
+    for (; ti < nvalid; ti += gridDim.x) {
+        const int t0 = ti * TT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's pieces of this tile have landed; the previous tile's conv is done with `tile`
+        for (int idx = tid; idx < (TT + 6) * C8; idx += TT) {
+            const int r = idx / C8, c8 = idx - r * C8;
+            const int t = t0 - 3 + r;
+            float v[8], u[8];
+            unpack8_h(*(const uint4*)(raw + r * ROWB + c8 * 16), v);
+            unpack8_h(*(const uint4*)(raw + RAWB + r * ROWB + c8 * 16), u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += u[e];
+            unpack8_h(*(const uint4*)(raw + 2 * RAWB + r * ROWB + c8 * 16), u);
+            const bool in = t >= 0 && t < L;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = in ? lrelu(div3_exact(v[e] + u[e]), 0.01f) : 0.f;
+            *(float4*)(tile + r * S + c8 * 8) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(tile + r * S + c8 * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        __syncthreads();  // the tile is complete and `raw` is free
+        if (ti + (int)gridDim.x < nvalid) issue(ti + gridDim.x);  // flies during the conv below (and the next wait)
+        const int t = t0 + tid;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const float4* row = (const float4*)(tile + (tid + j) * S);
+            const float4* wj = (const float4*)(w + j * C);
+#pragma unroll
+            for (int c = 0; c < C / 4; ++c) {  // same accumulation order as k_post / the scalar loop
+                const float4 xv = row[c], wv = wj[c];
+                acc = fmaf(xv.x, wv.x, acc);
+                acc = fmaf(xv.y, wv.y, acc);
+                acc = fmaf(xv.z, wv.z, acc);
+                acc = fmaf(xv.w, wv.w, acc);
+            }
+        }
+        if (t < L) out[(size_t)b * Lmax + t] = tanhf(acc);
+        else if (t < Lmax) out[(size_t)b * Lmax + t] = 0.f;
+    }
+    for (ti = blockIdx.x; ti < nall; ti += gridDim.x)  // (ragged batch) tiles behind the item's end
+        if (ti >= nvalid && ti * TT + tid < Lmax) out[(size_t)b * Lmax + ti * TT + tid] = 0.f;
+}
+template <int C>
+static constexpr size_t post_dma_smem() {
+    return (size_t)(7 * C + (POSTD_TT + 6) * (C + 4)) * 4 + (size_t)3 * (((POSTD_TT + 6) * C * 2 + 1023) / 1024) * 1024;
+}
+
 // ... of fp16 streams (Y_F16)
 static __global__ void __launch_bounds__(256) k_sum3h(const _Float16* __restrict__ a, const _Float16* __restrict__ b,
                                                const _Float16* __restrict__ c, float* __restrict__ y, size_t n) {

@@ -28,21 +28,24 @@ def lloyd(x,k,niter,reloc,seed=0,R_frac=0.05):
             cost=n*dn
             order_rm=np.argsort(cost)
             order_sp=np.argsort(-S)
-            used=set(); nrel=0; R=max(1,int(k*R_frac)); si=0
+            # used: moved centre / split cluster / receiver of a move of this iteration; moved: centres no longer at their old place -- a later
+            # candidate whose nearest centre was moved has a stale cost and is skipped (same rule as csrc/ivf.hip)
+            used=set(); moved=set(); nrel=0; R=max(1,int(k*R_frac)); si=0
+            small=lambda o: n[o]<2
             for j in order_rm[:4*R]:
                 if nrel>=R: break
-                if j in used: continue
-                # best split target not used
-                while si<k and (order_sp[si] in used or order_sp[si]==j or order_sp[si]==nn[j]): si+=1
-                if si>=k: break
-                o=order_sp[si]
+                if j in used or nn[j] in moved: continue
+                while si<k and (order_sp[si] in used or small(order_sp[si])): si+=1      # out for every later candidate
+                sj=si
+                while sj<k and (order_sp[sj] in used or small(order_sp[sj]) or order_sp[sj]==j or order_sp[sj]==nn[j]): sj+=1  # out for this one
+                if sj>=k: break
+                o=order_sp[sj]
                 idx=np.nonzero(a==o)[0]
-                if len(idx)<2: si+=1; continue
                 p=xs[idx[dist[idx].argmax()]]
                 dp=((xs[idx]-p)**2).sum(1)
                 gain=np.maximum(dist[idx]-dp,0).sum()
                 if gain>cost[j]:
-                    c[j]=p; used.update([j,o,nn[j]]); nrel+=1; si+=1
+                    c[j]=p; used.update([j,o,nn[j]]); moved.add(j); nrel+=1
                 else:
                     break
     return c.astype(np.float32), objs
