@@ -1,6 +1,7 @@
 #!/bin/bash
-# One GPU session that refreshes every artefact of a round: tools/gpu_round.sh r04   (run through gpurun; ~10 min)
-TAG=${1:-r04}
+# One GPU session that refreshes every artefact of a round: tools/gpu_round.sh r06   (run through gpurun; ~15 min).
+# Build tools/ubench/kloop2 first (hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o kloop2 kloop2.hip: the binary travels with the snapshot).
+TAG=${1:-r06}
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/${TAG}_pytest_gpu_tail.txt; cat gpurun_out/${TAG}_pytest_gpu_tail.txt
 python __graft_entry__.py smoke 2>&1 | tail -1
@@ -9,6 +10,9 @@ python bench.py --batch 64 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline -
 python bench.py --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/${TAG}_bench_b16_T1198.json 2>/dev/null
 python bench.py --whole --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/${TAG}_bench_whole_b16_T1198.json 2>/dev/null
 python bench.py --stream > gpurun_out/${TAG}_bench_stream_v1_40k.json 2>/dev/null
+python bench.py --e2e > gpurun_out/${TAG}_bench_e2e.json 2>gpurun_out/${TAG}_bench_e2e.err
+# the K loop's own ceiling on THIS chip, re-measured every round (bench.py parses the newest profiles/rNN_ubench_kloop2_issue_model.txt)
+[ -x tools/ubench/kloop2 ] && (cd tools/ubench && timeout 300 ./kloop2) > gpurun_out/${TAG}_ubench_kloop2_issue_model.txt 2>&1
 bash tools/profile.sh $TAG > gpurun_out/prof_${TAG}.log 2>&1; tail -1 gpurun_out/prof_${TAG}.log
 python - $TAG <<'PY'
 import json, sys

@@ -79,6 +79,16 @@ for pm in sorted(glob.glob(os.path.join(root, "pmc*"))):
             n[(lg, r["Counter_Name"])] += 1
     for (lg, c), v in acc.items():
         vals[lg][c] = v / n[(lg, c)]
+# average launch duration per logical kernel from the kernel-trace pass (for the effective clock)
+dur = {}
+if stats:
+    acc_d, n_d = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(stats[0])):
+        lg = logical(r["Name"])
+        if lg:
+            acc_d[lg] += float(r["TotalDurationNs"])
+            n_d[lg] += int(r["Calls"])
+    dur = {k: acc_d[k] / max(1, n_d[k]) for k in acc_d}
 out = {"source": "rocprofv3 --pmc passes of `bench.py --steps 5 --warmup 2 --graph 0` (tools/profile.sh); per-dispatch averages; "
                  "bytes_per_launch = FETCH_SIZE KB x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE KB",
        "kernels": {}}
@@ -89,7 +99,20 @@ for lg, d in sorted(vals.items()):
         for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum"):
             if c in d:
                 e[c] = d[c]
+        if lg in dur:
+            e["avg_launch_ns"] = dur[lg]
+            if "GRBM_GUI_ACTIVE" in d and dur[lg] > 0:
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles per XCD / wall time = the clock the chip actually ran at under this kernel
+                e["effective_clock_ghz"] = d["GRBM_GUI_ACTIVE"] / 8.0 / dur[lg]
+            if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["GRBM_GUI_ACTIVE"] > 0:
+                e["mfma_duty"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)  # busy cycles / (cycles x 1024 SIMDs)
         out["kernels"][lg] = e
 if out["kernels"]:
     json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
     print("== wrote pmc_traffic.json for", sorted(out["kernels"]))
+    print("== per kernel: bytes per launch (FETCH x2 + WRITE), effective clock, MFMA duty (the power story: a busy matrix pipe lowers the clock)")
+    print("%-24s %12s %10s %10s %10s" % ("kernel", "MB/launch", "avg_us", "clock_GHz", "mfma_duty"))
+    for lg, e in sorted(out["kernels"].items(), key=lambda kv: -kv[1].get("avg_launch_ns", 0)):
+        print("%-24s %12.1f %10.1f %10s %10s" % (lg, e["bytes_per_launch"] / 1e6, e.get("avg_launch_ns", 0) / 1e3,
+                                                 "%.2f" % e["effective_clock_ghz"] if "effective_clock_ghz" in e else "-",
+                                                 "%.2f" % e["mfma_duty"] if "mfma_duty" in e else "-"))
