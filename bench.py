@@ -598,13 +598,17 @@ def e2e_mode(a):
     acc = {}
     orig = {}
 
-    def timed(name, fn):
+    sub = {}  # nested timers (parts of a stage): kept apart from `acc`, whose entries are disjoint
+
+    def timed(name, fn, store=None):
+        store = acc if store is None else store
+
         def w(*args, **kw):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             r = fn(*args, **kw)
             torch.cuda.synchronize()
-            acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+            store[name] = store.get(name, 0.0) + time.perf_counter() - t0
             return r
         return w
 
@@ -617,10 +621,15 @@ def e2e_mode(a):
                 setattr(rp, attr, timed(label, orig[attr]))
             orig["signal"] = pl.signal
             pl.signal = types.SimpleNamespace(filtfilt=timed("highpass_filtfilt_host", orig["signal"].filtfilt), butter=orig["signal"].butter)
+            rm = pipe.f0_gen.rmvpe  # inside the RMVPE stage: the mel front end and the bidirectional GRU (sequential over ~1200 frames)
+            orig["mel"], orig["gru"] = rm.mel_extractor, rm.model.gru.forward
+            rm.mel_extractor = timed("mel_stft", orig["mel"], sub)
+            rm.model.gru.forward = timed("bigru", orig["gru"], sub)
         else:
             for label, attr in names:
                 setattr(rp, attr, orig[attr])
             pl.signal = orig["signal"]
+            pipe.f0_gen.rmvpe.mel_extractor, pipe.f0_gen.rmvpe.model.gru.forward = orig["mel"], orig["gru"]
 
     def convert(audios):
         return pipe.convert_files(hub, net_g, 0, [x.copy() for x in audios], [0, 0, 0], *tail)
@@ -643,6 +652,7 @@ def e2e_mode(a):
         wall = walls[len(walls) // 2]
         instrument(True)
         acc.clear()
+        sub.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         convert(audios)
@@ -659,6 +669,9 @@ def e2e_mode(a):
                                  "instrumented_total_ms_per_clip": round(1e3 * tot / n, 3), "split_ms_per_clip": split,
                                  "groups_ms_per_clip": {"feeders_pytorch_rocm_proxies": round(feeders, 3), "host": round(host, 3),
                                                         "hip_hot_path_retrieval_infer": round(hot, 3), "finish": split["finish_rms_scale_d2h"]},
+                                 "rmvpe_proxy_parts_ms_per_clip": {"mel_stft": round(1e3 * sub.get("mel_stft", 0.0) / n, 3),
+                                                                   "bigru_384_256_bidirectional": round(1e3 * sub.get("bigru", 0.0) / n, 3),
+                                                                   "unet_head_linear_decode": round(split["rmvpe_proxy_mel_net_decode"] - 1e3 * (sub.get("mel_stft", 0.0) + sub.get("bigru", 0.0)) / n, 3)},
                                  "long_pole": max(split, key=split.get)}
     rvc_amd.uninstall()
     big = cases["files_%d" % a.e2e_files]

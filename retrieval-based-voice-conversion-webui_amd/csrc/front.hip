@@ -148,9 +148,54 @@ void launch_wn_nj(rvcmi_front* h, FrWnArgs a, const ConvLayer& Lin, const ConvLa
         fprintf(stderr, "\n");
     }
 }
+// Split form of a WN layer for small grids (round 6; option FR_WN_SPLIT, default by grid size like the split FFN): the in_layer + gate as
+// one launch whose blocks take a THIRD of the (tanh, sigmoid) channel pairs each (grid.y = 3: 114 blocks of two waves for a single clip
+// instead of 38 blocks of six, each streaming 246 KB of weights instead of 737 KB), the gate activations through an OpT buffer (h->A,
+// free during the flow), then the 1x1 res_skip with the residual / skip update as a second launch split the same way.  Same K loops, same
+// epilogue arithmetic in the same order as k_fr_wn: bit-identical results.
+template <typename OpT, bool LAST>
+void launch_wn_split(rvcmi_front* h, const FrWnArgs& w, const ConvLayer& Lin, const ConvLayer& Lrs, int B, hipStream_t st) {
+    constexpr int H = 192;
+    {
+        FrConvArgs a = {};
+        a.in = w.x; a.in_op = 0; a.in_bstride = w.bstride; a.T = w.T; a.t_off = w.t_off; a.len = w.len;
+        a.pad = (Lin.ntaps[0] - 1) / 2; a.H = H;
+        a.out_op = h->A.p; a.out_op_bstride = (long)w.T * H;
+        a.gc = w.gc; a.gc_bstride = w.gc_bstride;
+        const int mode = h->opt.geti("FR_WN_SPLIT", 2);  // 1 = channel split only (bit-identical to k_fr_wn), 2 = taps over the waves (default)
+        if (mode == 2 && Lin.ntaps[0] >= 2 && Lin.ntaps[0] <= 8) {
+            a.w = Lin.w_pack.p; a.ct_stride = Lin.ct_stride; a.ntaps = Lin.ntaps[0]; a.bias = Lin.bias.as<float>(); a.cout = Lin.cout;
+            const int rows = 32 + a.ntaps - 1 + 2;
+            const size_t smem = (size_t)rows * Tile<H>::STRIDE + (size_t)(a.ntaps - 1) * 2 * 16 * 64 * sizeof(float);
+            auto kern = k_fr_gate_ks<OpT, H, 1>;
+            static std::atomic<unsigned long long> attr_done{0};
+            ensure_dyn_lds(reinterpret_cast<const void*>(kern), attr_done);
+            h->prof.launch("flow_wn_gate", Lin.flops_per_pos * (double)a.T * B, 0.0, st, [&] {
+                hipLaunchKernelGGL(kern, dim3((a.T + 31) / 32, H / 32, B), dim3(64 * a.ntaps), smem, st, a);
+            });
+            HIP_CHECK(hipGetLastError());
+        } else {
+            launch_conv_nj<OpT, H, 2, 2, FR_GATE, 1>(h, "flow_wn_gate", a, Lin, B, st);
+        }
+    }
+    {
+        FrConvArgs a = {};
+        a.in = h->A.p; a.in_op = 1; a.in_bstride = (long)w.T * H; a.T = w.T; a.t_off = w.t_off; a.len = w.len; a.H = H;
+        a.res = w.x; a.out = w.x_out; a.out_bstride = w.bstride; a.out_C = H; a.skip = w.skip; a.first = w.first;
+        if constexpr (LAST) {
+            a.out = w.skip;  // (strides only; the last layer writes skip alone)
+            launch_conv_nj<OpT, H, 1, 2, FR_WN_RS_LAST, 1>(h, "flow_wn_rs", a, Lrs, B, st);
+        } else {
+            launch_conv_nj<OpT, H, 2, 2, FR_WN_RS, 1>(h, "flow_wn_rs", a, Lrs, B, st);
+        }
+    }
+}
 template <typename OpT, bool LAST>
 void launch_wn(rvcmi_front* h, const FrWnArgs& a, const ConvLayer& Lin, const ConvLayer& Lrs, int B, hipStream_t st) {
-    if (pick_nj(h, B, a.T) == 1) launch_wn_nj<OpT, LAST, 1>(h, a, Lin, Lrs, B, st);
+    const int nj = pick_nj(h, B, a.T);
+    const long tiles = (long)((a.T + 32 * nj - 1) / (32 * nj)) * B;
+    if (nj == 1 && h->opt.geti("FR_WN_SPLIT", tiles <= 96 ? 1 : 0) != 0) return launch_wn_split<OpT, LAST>(h, a, Lin, Lrs, B, st);
+    if (nj == 1) launch_wn_nj<OpT, LAST, 1>(h, a, Lin, Lrs, B, st);
     else launch_wn_nj<OpT, LAST, 2>(h, a, Lin, Lrs, B, st);
 }
 
@@ -424,7 +469,7 @@ rvcmi_front* front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* wei
     WeightMap wm;
     for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
     std::unique_ptr<rvcmi_front> h(new rvcmi_front);
-    h->opt.load_env({"FR_NJ", "FR_NO_FFN_FUSION", "FR_FFN_SPLIT", "FR_STAMPS"});
+    h->opt.load_env({"FR_NJ", "FR_NO_FFN_FUSION", "FR_FFN_SPLIT", "FR_WN_SPLIT", "FR_STAMPS"});
     h->cfg = c;
     h->device = device;
     h->max_B = max_B;

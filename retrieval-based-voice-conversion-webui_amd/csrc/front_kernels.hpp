@@ -25,7 +25,12 @@ enum FrEpi : int {
     FR_RELU_OP = 3,   // relu(acc + b) * mask                                                 -> OpT    attentions.py:263-268
     FR_PROJ_ZP = 4,   // (m, logs) = (acc + b) * mask; (m + exp(logs) * noise * 0.66666) * mask -> fp32  synthesizers.py:182-183
     FR_F32_MASK = 5,  // (acc + b) * mask                                                     -> fp32   residuals.py:222
-    FR_COUPLE = 6     // x1 <- (x1 - (acc + b) * mask) * mask, in place in the flow stream               residuals.py:224-236
+    FR_COUPLE = 6,    // x1 <- (x1 - (acc + b) * mask) * mask, in place in the flow stream               residuals.py:224-236
+    // round 6: one WN layer as TWO launches for small grids (a single clip = 38 time tiles on 256 CUs), so that the in_layer's weight
+    // stream (737 KB, 84 % of the layer's) is split over 3x the blocks -- each block a third of the (tanh, sigmoid) channel pairs:
+    FR_GATE = 7,      // tanh(acc_t + b_t + gc_t) * sigmoid(acc_s + b_s + gc_s) of a paired (tanh, sigmoid) tile -> OpT   norms.py:111-114, utils.py:47-55
+    FR_WN_RS = 8,     // paired (res, skip) tiles: x' = (x + acc_r + b_r) * mask -> out; skip (+)= acc_s + b_s             norms.py:116-122
+    FR_WN_RS_LAST = 9 // last layer: skip tiles only: skip (+)= acc + b                                                   norms.py:121-122
 };
 
 struct FrConvArgs {
@@ -61,9 +66,17 @@ struct FrConvArgs {
     int H;               // hidden channels (FR_QKV split point, FR_PROJ_ZP pairing)
     const float* noise;  // FR_PROJ_ZP: [B][C][T] channel-first (what randn_like(m_p) is)
     int phys_base;       // FR_COUPLE: first physical channel of the x1 half (flip folded)
+    const float* gc;     // FR_GATE: cond_layer(g) slice of this layer, [B][gc_bstride] -> 2H values (or nullptr)
+    long gc_bstride;
+    float* skip;         // FR_WN_RS / _LAST: running sum of the skip parts, layout of `out`
+    int first;           // FR_WN_RS / _LAST: 1 = skip is written, not accumulated
 };
 
 constexpr int FR_NB = 4;  // weight ring depth of the front kernels (k-groups)
+
+// tanh / sigmoid through the hardware exp: the result is rounded to a 16-bit operand right after
+__device__ __forceinline__ float fast_sigmoid(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 2.f * fast_sigmoid(2.f * v) - 1.f; }
 
 __device__ __forceinline__ bool fr_valid(const FrConvArgs& a, int b, int row) {
     return a.len == nullptr || (long long)(row + a.t_off) < a.len[b];
@@ -119,6 +132,32 @@ __device__ __forceinline__ void fr_stage(char* smem, const void* in, int in_op, 
                 *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = o;
             }
         }
+    }
+}
+
+// fr_stage with the thread count as a runtime value (k_fr_gate_ks with a kernel size other than the shipped 5)
+template <typename OpT, int CIN>
+__device__ __forceinline__ void fr_stage_dyn(char* smem, const void* in, int in_op, long boff, int T, int g0, int rows, int lenrow, int NT) {
+    using frag = typename Op<OpT>::frag;
+    constexpr int STRIDE = Tile<CIN>::STRIDE, C8 = CIN / 8;
+    const int hi = min(T, lenrow);
+    for (int idx = threadIdx.x; idx < rows * C8; idx += NT) {
+        const int r = idx / C8, c8 = idx - r * C8, gr = g0 + r, grc = min(max(gr, 0), T - 1);
+        frag o;
+        if (in_op) {
+            o = *(const frag*)((const OpT*)in + boff + (size_t)grc * CIN + c8 * 8);
+        } else {
+            const float4* p = (const float4*)((const float*)in + boff + (size_t)grc * CIN + c8 * 8);
+            const float4 lo = p[0], h4 = p[1];
+            const float f[8] = {lo.x, lo.y, lo.z, lo.w, h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = to_op<OpT>(f[e]);
+        }
+        if (!(gr >= 0 && gr < hi)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (OpT)0.f;
+        }
+        *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = o;
     }
 }
 
@@ -260,6 +299,63 @@ static __global__ void __launch_bounds__(64 * NW) k_fr_conv(FrConvArgs a) {
                 *(f32x4*)(a.out + (size_t)b * a.out_bstride + (size_t)tt[jt] * a.out_C + pc + 8 * g) = o;
             }
         }
+    } else if constexpr (EPI == FR_GATE) {
+        static_assert(MI == 2, "paired (tanh, sigmoid) tiles");
+        using o4 = __attribute__((ext_vector_type(4))) OpT;
+        const int pc = (ct0 / 2) * 32 + 4 * hl;
+        f32x4 bt[4], bs[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bt[g] = *(const f32x4*)(a.bias + pc + 8 * g);
+            bs[g] = *(const f32x4*)(a.bias + a.H + pc + 8 * g);
+            if (a.gc) {  // (uniform; the same sum the fused kernel stages in LDS: b_in + cond slice)
+                bt[g] += *(const f32x4*)(a.gc + (size_t)b * a.gc_bstride + pc + 8 * g);
+                bs[g] += *(const f32x4*)(a.gc + (size_t)b * a.gc_bstride + a.H + pc + 8 * g);
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            if (tt[jt] >= a.T) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                o4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = to_op<OpT>(fast_tanh(acc[0][jt][4 * g + e] + bt[g][e]) * fast_sigmoid(acc[1][jt][4 * g + e] + bs[g][e]));
+                *(o4*)((OpT*)a.out_op + (size_t)b * a.out_op_bstride + (size_t)tt[jt] * a.H + pc + 8 * g) = o;
+            }
+        }
+    } else if constexpr (EPI == FR_WN_RS || EPI == FR_WN_RS_LAST) {
+        static_assert(MI == (EPI == FR_WN_RS ? 2 : 1), "paired (res, skip) tiles, or skip tiles alone on the last layer");
+        const int pc = (EPI == FR_WN_RS ? ct0 / 2 : ct0) * 32 + 4 * hl;
+        f32x4 br[MI][4], xv[NJ][4], sk[NJ][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) br[mi][g] = *(const f32x4*)(a.bias + mi * a.H + pc + 8 * g);
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+                const size_t o = (size_t)b * a.out_bstride + (size_t)tcl[jt] * a.out_C + pc + 8 * g;
+                if constexpr (EPI == FR_WN_RS) xv[jt][g] = *(const f32x4*)(a.res + o);
+                sk[jt][g] = *(const f32x4*)(a.skip + o);  // garbage on the first layer, not used there
+            }
+        }
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) {
+            if (tt[jt] >= a.T) continue;
+            const size_t o = (size_t)b * a.out_bstride + (size_t)tt[jt] * a.out_C + pc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (EPI == FR_WN_RS) {
+                    f32x4 r = {acc[0][jt][4 * g + 0], acc[0][jt][4 * g + 1], acc[0][jt][4 * g + 2], acc[0][jt][4 * g + 3]};
+                    *(f32x4*)(a.out + o + 8 * g) = (xv[jt][g] + (r + br[0][g])) * mk[jt];
+                }
+                f32x4 sv = {acc[MI - 1][jt][4 * g + 0], acc[MI - 1][jt][4 * g + 1], acc[MI - 1][jt][4 * g + 2], acc[MI - 1][jt][4 * g + 3]};
+                sv += br[MI - 1][g];
+                if (!a.first) sv += sk[jt][g];
+                *(f32x4*)(a.skip + o + 8 * g) = sv;
+            }
+        }
     } else {
         f32x4 bv[MI][4];
         int cog[MI][4];
@@ -351,6 +447,88 @@ static __global__ void __launch_bounds__(64 * NW) k_fr_conv(FrConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// in_layer + gate of one WN layer with the TAPS split over the block's waves (round 6; the K-split idea of conv_ks_body, nsf_kernels.hpp).
+// Measured first (ABAB, B = 1): splitting the layer's CHANNELS over 3x the blocks (FR_GATE epilogue of k_fr_conv + a res_skip launch)
+// changes nothing -- 15.0 + 7.8 us against 22.3 us fused: a wave's K loop runs at the latency of ITS cold weight stream (60 k-steps with
+// 16 in flight = four dependent trips to the far memory side), however few blocks share a CU.  Here block = (time tile, one (tanh, sigmoid)
+// channel pair), wave w = tap w: its 12 k-steps are ALL requested by conv_prefetch before the tile is staged -- one trip --, the partial
+// sums of waves 1.. meet in LDS and wave 0 adds them in the fixed order (((w0 + w1) + w2) + w3) + w4 and runs the gate epilogue.
+// Not bit-identical to k_fr_wn (another summation order over the taps; option FR_WN_SPLIT pins the form).
+// ------------------------------------------------------------------------------------------------
+template <typename OpT, int H, int NJ>
+static __global__ void __launch_bounds__(512) k_fr_gate_ks(FrConvArgs a) {
+    using TL = Tile<H>;
+    constexpr int STRIDE = TL::STRIDE, CC = TL::CC, TT = NJ * 32;
+    static_assert(CC % KGROUP == 0 && CC / KGROUP <= FR_NB - 1, "one tap = at most NB - 1 k-groups: requested whole by conv_prefetch");
+    using o4 = __attribute__((ext_vector_type(4))) OpT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.z, q0 = blockIdx.x * TT, pair = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hl = lane >> 5;
+    const int rows = TT + a.ntaps - 1 + 2;
+    const OpT* wlane = (const OpT*)a.w + (size_t)(2 * pair) * a.ct_stride + (size_t)wave * CC * 512 + lane * 8;  // this wave's tap
+    typename Op<OpT>::frag Aw[FR_NB][KGROUP][2];
+    conv_prefetch<OpT, H, 2, KGROUP, FR_NB>(Aw, wlane, a.ct_stride, 1);
+    // gate operands of wave 0, requested before the staging
+    const int pc = pair * 32 + 4 * hl;
+    f32x4 bt[4], bs[4];
+    if (wave == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bt[g] = *(const f32x4*)(a.bias + pc + 8 * g);
+            bs[g] = *(const f32x4*)(a.bias + a.H + pc + 8 * g);
+            if (a.gc) {
+                bt[g] += *(const f32x4*)(a.gc + (size_t)b * a.gc_bstride + pc + 8 * g);
+                bs[g] += *(const f32x4*)(a.gc + (size_t)b * a.gc_bstride + a.H + pc + 8 * g);
+            }
+        }
+    }
+    // (blockDim = 64 * ntaps threads stage the tile; fr_stage's thread count is a template parameter: the shipped k = 5)
+    if (blockDim.x == 320) fr_stage<OpT, H, 320>(smem, a.in, a.in_op, (long)b * a.in_bstride, a.T, q0 - a.pad, rows, a.T);
+    else fr_stage_dyn<OpT, H>(smem, a.in, a.in_op, (long)b * a.in_bstride, a.T, q0 - a.pad, rows, a.T, (int)blockDim.x);
+    __syncthreads();
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][jt][e] = 0.f;
+    const char* lds_lane = smem + (size_t)(lane & 31) * STRIDE + hl * 16;
+    conv_run<OpT, H, 2, NJ, KGROUP, FR_NB>(acc, Aw, lds_lane, wlane, a.ct_stride, 1, wave, 1);
+    float* red = (float*)(smem + (size_t)rows * STRIDE);  // [ntaps - 1][2][NJ][16][64]
+    if (wave > 0) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[((((wave - 1) * 2 + mi) * NJ + jt) * 16 + e) * 64 + lane] = acc[mi][jt][e];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < a.ntaps; ++w)  // fixed order: ((w0 + w1) + w2) + ...
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][jt][e] += red[((((w - 1) * 2 + mi) * NJ + jt) * 16 + e) * 64 + lane];
+#pragma unroll
+    for (int jt = 0; jt < NJ; ++jt) {
+        const int t = q0 + jt * 32 + (lane & 31);
+        if (t >= a.T) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            o4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = to_op<OpT>(fast_tanh(acc[0][jt][4 * g + e] + bt[g][e]) * fast_sigmoid(acc[1][jt][4 * g + e] + bs[g][e]));
+            *(o4*)((OpT*)a.out_op + (size_t)b * a.out_op_bstride + (size_t)t * a.H + pc + 8 * g) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // One WN layer (norms.py:104-123) in one launch: in_layer (k taps) -> + cond -> tanh * sigmoid -> LDS -> res_skip 1x1
 // -> x' = (x + res) * mask, skip += skip part.
 // ------------------------------------------------------------------------------------------------
@@ -374,9 +552,6 @@ struct FrWnArgs {
     unsigned long long* stamps;  // dev only (RVCMI_FR_STAMPS): phase time stamps of block (1, 0)
 };
 
-// tanh / sigmoid through the hardware exp: the result is rounded to a 16-bit operand right after
-__device__ __forceinline__ float fast_sigmoid(float v) { return 1.f / (1.f + __expf(-v)); }
-__device__ __forceinline__ float fast_tanh(float v) { return 2.f * fast_sigmoid(2.f * v) - 1.f; }
 
 template <typename OpT, int H, int NJ, bool LAST>
 static __global__ void __launch_bounds__(64 * (H / 32)) k_fr_wn(FrWnArgs a) {

@@ -161,7 +161,9 @@ class FrontHIP(torch.nn.Module):
         return self._run(phone, pitch, lengths, g, noise, flow_head, tap=what)
 
     def set_option(self, key: str, value=None) -> None:
-        """Dev / test option of this handle (``rvcmi_front_set_option``: ``FR_NJ``, ``FR_NO_FFN_FUSION``, ``FR_FFN_SPLIT``); ``None`` = default."""
+        """Dev / test option of this handle (``rvcmi_front_set_option``: ``FR_NJ``, ``FR_NO_FFN_FUSION``, ``FR_FFN_SPLIT``, ``FR_WN_SPLIT`` 0 / 1 / 2 = a WN
+        layer as one launch / gate + res_skip launches, channel pairs over 3x the blocks (bit-identical to 0) / the gate's taps over the waves
+        (default for small grids)); ``None`` = default."""
         _lib.set_option(_lib.lib().rvcmi_front_set_option, self._handle, key, value)  # raises on a key this handle does not honour
         if not hasattr(self, "_options"):
             self._options = {}

@@ -280,6 +280,10 @@ def _rmvpe_on_device(self, audio_pad, p_len, f0_up_key):
     return glue.rmvpe_f0(hidden.squeeze(0).float(), p_len, int(f0_up_key), RMVPE_THRED)
 
 
+INDEX_CACHE_ENTRIES = 2  # index files kept resident (a WebUI session alternates between very few voices)
+_INDEX_CACHE = {}
+
+
 def _open_index(self, file_index, index_rate):
     """pipeline.py:205-218.  -> (IVFFlatHIP or None, needs_reference): ``needs_reference`` = an index kind only real faiss reads
     (not IVF-Flat / L2 ...) while the reference's own pipeline and the real faiss module are bound: the caller hands the whole
@@ -292,8 +296,23 @@ def _open_index(self, file_index, index_rate):
     if not (file_index != "" and os.path.exists(file_index) and index_rate != 0):
         return None, False
     try:
-        # on THIS pipeline's device (config.device), not the process's current GPU; big_npy is never materialised
-        return ivf.read_index(file_index, device=torch.device(self.device)), False
+        # on THIS pipeline's device (config.device), not the process's current GPU; big_npy is never materialised.
+        # The reference re-reads the file on every call (pipeline.py:205-218: faiss.read_index + reconstruct_n); here the parsed index stays
+        # resident on the GPU between calls, keyed by (path, size, mtime, device) -- a 10000 x 768 index is 31 MB of file read + upload per
+        # call otherwise (round 6, bench.py --e2e: the largest single item around the hot path at one file per call).  RVCMI_INDEX_CACHE=0 turns it off.
+        dev = torch.device(self.device)
+        st = os.stat(file_index)
+        key = (os.path.abspath(file_index), st.st_size, st.st_mtime_ns, str(dev))
+        if os.environ.get("RVCMI_INDEX_CACHE", "1") != "0":
+            hit = _INDEX_CACHE.get(key)
+            if hit is not None:
+                return hit, False
+        index = ivf.read_index(file_index, device=dev)
+        if os.environ.get("RVCMI_INDEX_CACHE", "1") != "0":
+            while len(_INDEX_CACHE) >= INDEX_CACHE_ENTRIES:
+                _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))  # oldest entry out (dicts keep insertion order)
+            _INDEX_CACHE[key] = index
+        return index, False
     except _lib.RvcmiError as e:
         orig = getattr(pipeline_hip, "_rvcmi_original", None)
         real = getattr(getattr(_ref_module(self), "faiss", None), "_rvcmi_real", None)

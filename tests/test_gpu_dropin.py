@@ -507,7 +507,7 @@ def test_convert_files_batches_several_files_and_equals_the_per_file_pipeline(rv
     net_g, _ = rs.get_synthesizer(make_cpt(seed), gpu)
     for key, val in (("RB_STREAM", 0), ("NO_RB_SPLIT", 1)):  # same kernel family for every batch size
         net_g.dec.set_option(key, val)
-    for key, val in (("FR_NJ", 1), ("FR_FFN_SPLIT", 1)):  # ... in the front too (tile height and the split FFN follow the tile count)
+    for key, val in (("FR_NJ", 1), ("FR_FFN_SPLIT", 1), ("FR_WN_SPLIT", 1)):  # ... in the front too (tile height, the split FFN and the tap-split WN gate follow the tile count)
         net_g._rvcmi_front.set_option(key, val)
     config = types.SimpleNamespace(device=gpu, **{k[4:]: (bool(d[k]) if k == "cfg_is_half" else int(d[k])) for k in d if k.startswith("cfg_")})
     pipe = pl.Pipeline(cfg.sr, config)

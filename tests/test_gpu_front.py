@@ -166,6 +166,29 @@ def test_front_rejects_bad_input(gpu):
         rvc_amd.FrontHIP(vars(FrontConfig(n_heads=4)), wf, device=gpu)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_wn_layer_forms_agree(mode, gpu):
+    """One WN layer exists in three forms (option FR_WN_SPLIT): 0 = k_fr_wn (one launch), 1 = gate + res_skip launches with the channel pairs
+    split over 3x the blocks (bit-identical to 0: same K loops, same epilogue order), 2 = the gate with the TAPS split over the waves (the
+    default for small grids; another summation order).  Every form against the reference goldens; 1 bit-equal to 0."""
+    for name in ("front_v2_B2_T50", "front_v2_B1_T100_head6"):
+        d = load_golden(name)
+        fcfg, wf = front_weights(d, int(d["in_channels"]))
+        fr = hip_front(fcfg, wf, "fp16", gpu)
+        fh = max(int(d["flow_head"]), 0)
+        args = (dev(d, "phone", gpu), dev(d, "pitch", gpu), dev(d, "lengths", gpu), dev(d, "g", gpu))
+        fr.set_option("FR_WN_SPLIT", mode)
+        z = fr(*args, fh, noise=dev(d, "noise", gpu))
+        e = rms(z.cpu(), d["z"])
+        assert e <= Z_BAR["fp16"], "%s (FR_WN_SPLIT=%d): z RMS error %.3e" % (name, mode, e)
+        fr.set_option("FR_WN_SPLIT", 0)
+        z0 = fr(*args, fh, noise=dev(d, "noise", gpu))
+        if mode == 1:
+            assert torch.equal(z, z0)
+        else:
+            assert rms(z.cpu(), z0.cpu()) <= 2e-3
+
+
 @pytest.mark.parametrize("fused_ffn", [True, False, "split", "split_nj1"])
 def test_front_large_batch_tile_height_and_unfused_ffn(fused_ffn, gpu):
     """Large batches run 64-row time tiles (pick_nj) and the FFN exists in three forms -- one fused launch (k_fr_ffn, large
@@ -259,8 +282,10 @@ def test_front_batch_16_equals_single_clips(gpu):
     nz = torch.randn(B, 192, T, generator=torch.Generator().manual_seed(8))
     g = wf["emb_g.weight"][sid].unsqueeze(-1)
     fr = hip_front(fcfg, wf, "fp16", gpu, max_B=B, max_T=T)
-    # (the FFN form pinned: a single clip would otherwise take the split form, whose partial sums add in another order)
+    # (the FFN form pinned: a single clip would otherwise take the split form, whose partial sums add in another order; the same for the
+    #  tap-split gate of the WN layers, round 6)
     fr.set_option("FR_FFN_SPLIT", 0)
+    fr.set_option("FR_WN_SPLIT", 0)
     z = fr(phone.to(gpu), pitch.to(gpu), lengths.to(gpu), g.to(gpu), 0, noise=nz.to(gpu))
     assert z.shape == (B, 192, T) and torch.isfinite(z).all()
     for b in (0, 5, 15):
@@ -270,6 +295,7 @@ def test_front_batch_16_equals_single_clips(gpu):
         if int(lengths[b]) < T:
             assert float(z[b, :, int(lengths[b]):].abs().max()) == 0.0  # masked tail
     fr.set_option("FR_FFN_SPLIT", None)   # the launcher's own choice for one clip (split): same z to operand rounding
+    fr.set_option("FR_WN_SPLIT", None)
     one = fr(phone[5:6].to(gpu), pitch[5:6].to(gpu), lengths[5:6].to(gpu), g[5:6].to(gpu), 0, noise=nz[5:6].to(gpu))
     assert rms(one[0].cpu(), z[5].cpu()) <= 2e-3
     with torch.no_grad():
