@@ -13,6 +13,9 @@ python bench.py --stream > gpurun_out/${TAG}_bench_stream_v1_40k.json 2>/dev/nul
 python bench.py --e2e > gpurun_out/${TAG}_bench_e2e.json 2>gpurun_out/${TAG}_bench_e2e.err
 # the K loop's own ceiling on THIS chip, re-measured every round (bench.py parses the newest profiles/rNN_ubench_kloop2_issue_model.txt)
 [ -x tools/ubench/kloop2 ] && (cd tools/ubench && timeout 300 ./kloop2) > gpurun_out/${TAG}_ubench_kloop2_issue_model.txt 2>&1
+# the RCCL path at world size 1 (the one-GPU lease): configs[1] and configs[3] (64 clips, 1M x 256 index built on the GPU, ONE timed broadcast, agreement check)
+RVCMI_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --no-cpu-baseline --no-gpu-torch-baseline --no-extra > gpurun_out/${TAG}_bench_config1_rccl_world1.json 2>/dev/null
+RVCMI_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 1 --config 3 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/${TAG}_bench_config3_rccl_world1.json 2>/dev/null
 bash tools/profile.sh $TAG > gpurun_out/prof_${TAG}.log 2>&1; tail -1 gpurun_out/prof_${TAG}.log
 python - $TAG <<'PY'
 import json, sys
