@@ -68,12 +68,13 @@ const float* wdata(const WeightMap& wm, const std::string& name, std::initialize
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set it once per (kernel instantiation, device).
-static void ensure_dyn_lds(const void* kern, std::atomic<unsigned long long>& done) {
+static void ensure_dyn_lds(const void* kern, std::atomic<unsigned long long>& done, int bytes = 160 * 1024) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (done.load(std::memory_order_acquire) & bit) return;
-    HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // (`bytes`: a kernel with STATIC LDS of its own must ask for less than the whole 160 KB -- static + dynamic is what has to fit)
+    HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     done.fetch_or(bit, std::memory_order_release);
 }
 
@@ -315,19 +316,19 @@ void front_forward_t(rvcmi_front* h, int B, int T, const float* phone, const lon
                 if (w8) {
                     static std::atomic<unsigned long long> ad21{0}, ad31{0};
                     if (c.window_size <= 10) {
-                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 21, 8>), ad21);
+                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 21, 8>), ad21, (int)ol8);
                         hipLaunchKernelGGL((k_fr_attn<OpT, 96, 21, 8>), grid, dim3(512), ol8, st, a);
                     } else {
-                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 31, 8>), ad31);
+                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 31, 8>), ad31, (int)ol8);
                         hipLaunchKernelGGL((k_fr_attn<OpT, 96, 31, 8>), grid, dim3(512), ol8, st, a);
                     }
                 } else {
                     static std::atomic<unsigned long long> bd21{0}, bd31{0};
                     if (c.window_size <= 10) {
-                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 21, 4>), bd21);
+                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 21, 4>), bd21, (int)ol4);
                         hipLaunchKernelGGL((k_fr_attn<OpT, 96, 21, 4>), grid, dim3(256), ol4, st, a);
                     } else {
-                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 31, 4>), bd31);
+                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 31, 4>), bd31, (int)ol4);
                         hipLaunchKernelGGL((k_fr_attn<OpT, 96, 31, 4>), grid, dim3(256), ol4, st, a);
                     }
                 }
