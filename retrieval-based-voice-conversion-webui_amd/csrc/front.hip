@@ -68,13 +68,12 @@ const float* wdata(const WeightMap& wm, const std::string& name, std::initialize
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: set it once per (kernel instantiation, device).
-static void ensure_dyn_lds(const void* kern, std::atomic<unsigned long long>& done, int bytes = 160 * 1024) {
+static void ensure_dyn_lds(const void* kern, std::atomic<unsigned long long>& done) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
     if (done.load(std::memory_order_acquire) & bit) return;
-    // (`bytes`: a kernel with STATIC LDS of its own must ask for less than the whole 160 KB -- static + dynamic is what has to fit)
-    HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done.fetch_or(bit, std::memory_order_release);
 }
 
@@ -306,32 +305,9 @@ void front_forward_t(rvcmi_front* h, int B, int T, const float* phone, const lon
             const bool want_stamps = h->opt.on("FR_STAMPS");
             if (want_stamps && !stamps) HIP_CHECK(hipMalloc((void**)&stamps, 256 * 8));
             a.stamps = want_stamps ? stamps : nullptr;
-            // eight waves per block where the grid is small and the clip long (a single 10 s clip: 76 blocks, ten key tiles per wave with four);
-            // option FR_ATTN_W8 = 0 / 1 pins the choice.  Bit-identity with the four-wave form is not expected (another merge order).
-            const long ablocks = (long)((T + 31) / 32) * c.n_heads * B;
-            const bool w8 = h->opt.geti("FR_ATTN_W8", (ablocks <= 256 && T >= 512) ? 1 : 0) != 0;
-            const size_t ol4 = (size_t)4 * 32 * 97 * sizeof(float), ol8 = (size_t)8 * 32 * 97 * sizeof(float);
             h->prof.launch("enc_attn", flops, 0.0, st, [&] {
-                const dim3 grid((T + 31) / 32, c.n_heads, B);
-                if (w8) {
-                    static std::atomic<unsigned long long> ad21{0}, ad31{0};
-                    if (c.window_size <= 10) {
-                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 21, 8>), ad21, (int)ol8);
-                        hipLaunchKernelGGL((k_fr_attn<OpT, 96, 21, 8>), grid, dim3(512), ol8, st, a);
-                    } else {
-                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 31, 8>), ad31, (int)ol8);
-                        hipLaunchKernelGGL((k_fr_attn<OpT, 96, 31, 8>), grid, dim3(512), ol8, st, a);
-                    }
-                } else {
-                    static std::atomic<unsigned long long> bd21{0}, bd31{0};
-                    if (c.window_size <= 10) {
-                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 21, 4>), bd21, (int)ol4);
-                        hipLaunchKernelGGL((k_fr_attn<OpT, 96, 21, 4>), grid, dim3(256), ol4, st, a);
-                    } else {
-                        ensure_dyn_lds(reinterpret_cast<const void*>(&k_fr_attn<OpT, 96, 31, 4>), bd31, (int)ol4);
-                        hipLaunchKernelGGL((k_fr_attn<OpT, 96, 31, 4>), grid, dim3(256), ol4, st, a);
-                    }
-                }
+                if (c.window_size <= 10) hipLaunchKernelGGL((k_fr_attn<OpT, 96, 21>), dim3((T + 31) / 32, c.n_heads, B), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((k_fr_attn<OpT, 96, 31>), dim3((T + 31) / 32, c.n_heads, B), dim3(256), 0, st, a);
             });
             HIP_CHECK(hipGetLastError());
             if (a.stamps) {
@@ -493,7 +469,7 @@ rvcmi_front* front_create(const rvcmi_front_config* cfg, const rvcmi_tensor* wei
     WeightMap wm;
     for (int i = 0; i < n_weights; ++i) wm.m[weights[i].name] = &weights[i];
     std::unique_ptr<rvcmi_front> h(new rvcmi_front);
-    h->opt.load_env({"FR_NJ", "FR_NO_FFN_FUSION", "FR_FFN_SPLIT", "FR_WN_SPLIT", "FR_ATTN_W8", "FR_STAMPS"});
+    h->opt.load_env({"FR_NJ", "FR_NO_FFN_FUSION", "FR_FFN_SPLIT", "FR_WN_SPLIT", "FR_STAMPS"});
     h->cfg = c;
     h->device = device;
     h->max_B = max_B;

@@ -689,11 +689,8 @@ struct FrAttnArgs {
     unsigned long long* stamps;  // dev only
 };
 
-// NWA = waves per block (4, or -- round 6, small grids -- 8: a wave then walks five key tiles of a 10 s clip instead of ten, i.e. two dependent
-// trips to the K / V blocks instead of four; the merge buffer of eight partial outputs lives in dynamic LDS)
-template <typename OpT, int DK, int NBAND, int NWA = 4>  // NBAND >= 2*ws + 1 (21 for the shipped window of 10)
-static __global__ void __launch_bounds__(64 * NWA) k_fr_attn(FrAttnArgs a) {
-    constexpr int NTH = 64 * NWA;
+template <typename OpT, int DK, int NBAND>  // NBAND >= 2*ws + 1 (21 for the shipped window of 10)
+static __global__ void __launch_bounds__(256) k_fr_attn(FrAttnArgs a) {
     using frag = typename Op<OpT>::frag;
     using o4 = __attribute__((ext_vector_type(4))) OpT;
     constexpr int KS = DK / 16;   // k-steps of the score product
@@ -702,11 +699,11 @@ static __global__ void __launch_bounds__(64 * NWA) k_fr_attn(FrAttnArgs a) {
     constexpr int DG = DK / 8;    // channels per thread in the output phase (256 threads = 32 queries x 8 groups)
     static_assert(DK % 32 == 0, "head dim must be a multiple of 32");
     __shared__ float Rl[32 * 33];
-    __shared__ float Ml[NWA * 32], Ll[NWA * 32];
-    extern __shared__ __attribute__((aligned(16))) float Ol[];  // [NWA * 32 * OS] (dynamic: 99 KB at NWA = 8)
+    __shared__ float Ml[4 * 32], Ll[4 * 32];
+    __shared__ float Ol[4 * 32 * OS];
     __shared__ float Sb[32 * 32 + 32];  // masked scores of the relative band, Sb[q][j - q + ws] (+ 32 dump slots)
     __shared__ float Mf[32], Lf[32];
-    __shared__ float Wl[NWA * 32];     // merge weights exp(m_w - M) / L
+    __shared__ float Wl[4 * 32];       // merge weights exp(m_w - M) / L
     __shared__ __attribute__((aligned(16))) float Ev[32 * DK];  // relative value embeddings (2ws+1 <= 31 rows, rest zero)
     const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int q0 = qt * 32;
@@ -727,19 +724,18 @@ static __global__ void __launch_bounds__(64 * NWA) k_fr_attn(FrAttnArgs a) {
         for (int s = 0; s < KS; ++s) Bq[s] = *(const frag*)(qp + 16 * s);
     }
     // relative value table: requested now (unconditional, clamped), parked in registers, written to LDS after the key loop
-    constexpr int EVN = 32 * DK / NTH;
-    static_assert((32 * DK) % NTH == 0, "relative value table: whole rounds of the block");
+    constexpr int EVN = 32 * DK / 256;
     float evr[EVN];
     {
         const int nev = (2 * a.ws + 1) * DK;
 #pragma unroll
         for (int u = 0; u < EVN; ++u) {
-            const int i = threadIdx.x + u * NTH;
+            const int i = threadIdx.x + u * 256;
             const float v = a.relv[min(i, nev - 1)];
             evr[u] = i < nev ? v : 0.f;
         }
     }
-    for (int i = threadIdx.x; i < 32 * 32; i += NTH) Sb[i] = -INFINITY;
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) Sb[i] = -INFINITY;
     if (wave == 0) {  // R[q][r] = q . E_k[r]
         f32x16 r = {0};
 #pragma unroll
@@ -837,27 +833,27 @@ static __global__ void __launch_bounds__(64 * NWA) k_fr_attn(FrAttnArgs a) {
         KV t0, t1, t2;
         int kt = wave;
         load_tile(kt, t0);
-        load_tile(kt + NWA, t1);
+        load_tile(kt + 4, t1);
         while (kt < nkt) {
-            load_tile(kt + 2 * NWA, t2);
+            load_tile(kt + 8, t2);
             __builtin_amdgcn_sched_barrier(0);
             compute_tile(kt, t0);
-            kt += NWA;
+            kt += 4;
             if (kt >= nkt) break;
-            load_tile(kt + 2 * NWA, t0);
+            load_tile(kt + 8, t0);
             __builtin_amdgcn_sched_barrier(0);
             compute_tile(kt, t1);
-            kt += NWA;
+            kt += 4;
             if (kt >= nkt) break;
-            load_tile(kt + 2 * NWA, t1);
+            load_tile(kt + 8, t1);
             __builtin_amdgcn_sched_barrier(0);
             compute_tile(kt, t2);
-            kt += NWA;
+            kt += 4;
         }
     }
     FR_STAMP(2);
 #pragma unroll
-    for (int u = 0; u < EVN; ++u) Ev[threadIdx.x + u * NTH] = evr[u];
+    for (int u = 0; u < EVN; ++u) Ev[threadIdx.x + u * 256] = evr[u];
     l_run += __shfl_xor(l_run, 32, 64);
     if (hl == 0) {
         Ml[wave * 32 + ql] = m_run;
@@ -870,37 +866,35 @@ static __global__ void __launch_bounds__(64 * NWA) k_fr_attn(FrAttnArgs a) {
     __syncthreads();
     if (threadIdx.x < 32) {
         const int x = threadIdx.x;
-        float M = Ml[x];
-#pragma unroll
-        for (int w = 1; w < NWA; ++w) M = fmaxf(M, Ml[w * 32 + x]);
+        float M = fmaxf(fmaxf(Ml[x], Ml[32 + x]), fmaxf(Ml[64 + x], Ml[96 + x]));
         float L = 0.f;
 #pragma unroll
-        for (int w = 0; w < NWA; ++w) L += Ll[w * 32 + x] * __expf(Ml[w * 32 + x] - M);
+        for (int w = 0; w < 4; ++w) L += Ll[w * 32 + x] * __expf(Ml[w * 32 + x] - M);
         Mf[x] = M;
         Lf[x] = L;
 #pragma unroll
-        for (int w = 0; w < NWA; ++w) Wl[w * 32 + x] = __expf(Ml[w * 32 + x] - M) / L;
+        for (int w = 0; w < 4; ++w) Wl[w * 32 + x] = __expf(Ml[w * 32 + x] - M) / L;
     }
     __syncthreads();
     FR_STAMP(3);
     // output: thread = (query x, group of DG channels); the band probabilities of x stay in registers.  Every LDS read is
     // unconditional (rows >= 2ws+1 of Ev are zero and their p is 0).
-    if (threadIdx.x < 256) {  // (256 threads = 32 queries x 8 channel groups, whatever the block size)
+    {
         const int x = threadIdx.x & 31, dg = threadIdx.x >> 5;
         const float M = Mf[x], Li = 1.f / Lf[x];
         float pb[NBAND];
 #pragma unroll
         for (int r = 0; r < NBAND; ++r) pb[r] = __expf(Sb[x * 32 + r] - M) * Li;
-        float w4[NWA];
+        float w4[4];
 #pragma unroll
-        for (int w = 0; w < NWA; ++w) w4[w] = Wl[w * 32 + x];
+        for (int w = 0; w < 4; ++w) w4[w] = Wl[w * 32 + x];
         OpT* out = (OpT*)a.out + ((size_t)b * T + min(q0 + x, T - 1)) * a.H + h * DK + dg * DG;
 #pragma unroll
         for (int c4 = 0; c4 < DG / 4; ++c4) {
             const int d = dg * DG + c4 * 4;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < NWA; ++w)
+            for (int w = 0; w < 4; ++w)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] += Ol[(w * 32 + x) * OS + d + e] * w4[w];
 #pragma unroll
