@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "RB_SPLIT_BIG", "UPS_NJ", "UPS_NJ_256", "UPS_VPW_256", "POST_DMA", "POST_DMA_OCC", "POST_DBG", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS", "RBF_SMALL"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "POST_DMA", "POST_DMA_OCC", "POST_DBG", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS", "RBF_SMALL"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -699,21 +699,6 @@ static void launch_conv_jobs(const ConvJobs& js, int Lq, int B, size_t smem, hip
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((Lq + 127) / 128), C / 32, (unsigned)(B * js.njobs)), dim3(256), smem, st, js);
 }
-// dev option RB_SPLIT_BIG (round 6, review item 4: "try the other decomposition of stage 0 once"): the same conv-by-conv launches with blocks
-// of 64 output channels x 256 rows (MI = 2, NJ = 2, four waves split time) for FULL-length stages: at L = 14 376 that is 57 x 4 x 3 = 684
-// blocks per launch, every weight fragment feeds two column tiles, no halo rows are recomputed; LDS 306 x 528 B = 158 KB at k = 11, dil 5.
-template <typename OpT, int C>
-static void launch_conv_jobs_big(const ConvJobs& js, int Lq, int B, size_t smem, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0};
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    auto kern = &k_conv_mfma_jobs_big<OpT, C>;
-    if (!(attr_done.load() & (1ull << (dev & 63)))) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done.fetch_or(1ull << (dev & 63));
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((Lq + 255) / 256), C / 64, (unsigned)(B * js.njobs)), dim3(256), smem, st, js);
-}
 // K-split form (nsf_kernels.hpp conv_ks_body): 32 rows x 32 channels per block, the four waves split the taps.
 constexpr int conv_ks_nj(int C) { return C == 256 ? 1 : 3; }  // rows per block / 32 (C = 128: 96-row tiles = 396 blocks for a chunk's 3100 rows)
 template <typename OpT, int C>
@@ -729,7 +714,7 @@ static void launch_conv_ks_jobs(const ConvJobs& js, int Lq, int B, size_t smem, 
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((Lq + 32 * NJ - 1) / (32 * NJ)), C / 32, (unsigned)(B * js.njobs)), dim3(256), smem, st, js);
 }
-static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvArgs* as, int nj, int B, const char* name, hipStream_t st, bool big = false) {
+static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvArgs* as, int nj, int B, const char* name, hipStream_t st) {
     ConvJobs js;
     memset(&js, 0, sizeof(js));
     js.njobs = nj;
@@ -738,7 +723,7 @@ static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvAr
     // K-split blocks (taps over the four waves, option CONV_KS, default on).  Realtime chunk, ABAB: C = 256 (310 rows, 32-row tiles = 240
     // blocks) six launches 134 -> 107 us; C = 128 (3100 rows) 113 -> 107 us with 96-row tiles (396 blocks) -- with 32-row tiles it LOST
     // (155 us: 1164 blocks that each stage 82 rows for 32 outputs).
-    const bool ks = h->opt.geti("CONV_KS", 1) != 0 && !big;
+    const bool ks = h->opt.geti("CONV_KS", 1) != 0;
     for (int j = 0; j < nj; ++j) {
         const ConvLayer& L = *Ls[j];
         ConvArgs a = as[j];
@@ -755,7 +740,7 @@ static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvAr
         a.ntaps = L.ntaps_p;
         a.roff = 0;
         const int ksr = 32 * conv_ks_nj(L.cin);
-        a.tile_rows = (ks ? ksr : (big ? 256 : 128)) + (L.ntaps_p - 1) * L.dstep;
+        a.tile_rows = (ks ? ksr : 128) + (L.ntaps_p - 1) * L.dstep;
         smem = std::max(smem, (size_t)a.tile_rows * (2 * L.cin + 16) + (ks ? (size_t)3 * (ksr / 32) * 16 * 64 * 4 : 0));  // (+ the partial sums of 3 waves)
         flops += L.flops_per_pos * (double)a.Lq * B;
         bytes += (double)B * a.Lq * L.cin * (a.in_mode == IN_OP_RAW ? 2 : 4) + (double)B * a.Lq * L.cin * (a.out_mode == OUT_ACT ? 2 : 4) +
@@ -764,11 +749,7 @@ static void run_conv_jobs(rvcmi_nsf* h, const ConvLayer* const* Ls, const ConvAr
     }
     const bool c256 = Ls[0]->cin == 256;
     h->prof.launch(name, flops, bytes, st, [&] {
-        if (big) {
-            if (smem > 160 * 1024 || !c256) RVCMI_FAIL(RVCMI_ERR_INVALID, "RB_SPLIT_BIG: tile of %zu B", smem);
-            if (h->cfg.operand == RVCMI_OPERAND_BF16) launch_conv_jobs_big<__bf16, 256>(js, as[0].Lq, B, smem, st);
-            else launch_conv_jobs_big<_Float16, 256>(js, as[0].Lq, B, smem, st);
-        } else if (ks) {
+        if (ks) {
             if (h->cfg.operand == RVCMI_OPERAND_BF16) {
                 if (c256) launch_conv_ks_jobs<__bf16, 256>(js, as[0].Lq, B, smem, st);
                 else launch_conv_ks_jobs<__bf16, 128>(js, as[0].Lq, B, smem, st);
@@ -925,8 +906,9 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
         const bool rb_split = op != RVCMI_OPERAND_F32 &&
                               ((C == 256 && (long)B * L <= RB_SPLIT_MAX_ROWS) || (C == 128 && (long)B * L <= RB_SPLIT_MAX_ROWS_128 && !h->opt.on("NO_RB_SPLIT128"))) &&
                               nk <= 3 && !h->opt.on("NO_RB_SPLIT") && rb_stream_mode(h) != 1;
-        const bool rb_big = op != RVCMI_OPERAND_F32 && !rb_split && C == 256 && nk <= 3 && h->opt.on("RB_SPLIT_BIG");  // dev: full-length stage 0 conv by conv
-        const bool x0h_stream = op != RVCMI_OPERAND_F32 && !rb_split && !rb_big && C > 64 && y_f16(h) && h->opt.geti("X0_F16", 1) != 0 && !h->opt.on("X0_F16_NOSTREAM") &&
+        // (round 6, review item 4: the same conv-by-conv launches for a FULL-length stage 0 with 64-channel x 256-row blocks -- 684 blocks per launch, no halo
+        //  recompute -- were built as a dev option, parity-green, and measured 0.61 ms against k_rb_pair<256>'s 0.284 ms; removed)
+        const bool x0h_stream = op != RVCMI_OPERAND_F32 && !rb_split && C > 64 && y_f16(h) && h->opt.geti("X0_F16", 1) != 0 && !h->opt.on("X0_F16_NOSTREAM") &&
                                 try_rb_stream_full(h, s, op, C, (int)L, B, nk, nullptr, st, lens, lm, true, true);
         const bool x0h = op != RVCMI_OPERAND_F32 && (x0_f16(h, C, maxnd0) || x0h_stream);
         char nm[48];
@@ -1046,16 +1028,12 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
                 const int v = h->opt.geti("UPS_NJ", nj);
                 if (v == 1 || v == 2 || v == 4) nj = v;
             }
-            if (s.cin == 256 && h->opt.has("UPS_NJ_256")) {  // dev: the stage whose launch is not HBM-bound (19 GFLOP in ~450 blocks)
-                const int v = h->opt.geti("UPS_NJ_256", nj);
-                if (v == 1 || v == 2 || v == 4) nj = v;
-            }
+            // (round 6: NJ 2 / 4 and vpw 1 / 2 for the C_in = 256 stage alone, 8 variants x 2, ABAB: 72-110 us against 60 -- every one loses)
             const int TQ = 32 * nj * (4 / wv);
             ua.tile_rows = TQ + (hi - lo);
             const long qtiles = (Lin + TQ - 1) / TQ;
             int vpw = (ua.nvt + wv - 1) / wv;  // everything in one block ...
             while (vpw > 1 && qtiles * B * ((ua.nvt + wv * vpw - 1) / (wv * vpw)) < 300) --vpw;  // ... unless the grid would starve
-            if (s.cin == 256 && h->opt.has("UPS_VPW_256")) vpw = std::min(std::max(1, h->opt.geti("UPS_VPW_256", vpw)), (ua.nvt + wv - 1) / wv);
             ua.vpw = vpw;
             snprintf(nm, sizeof(nm), "ups_c%d", s.cin);
             const double flops = U.flops_per_pos * (double)Lin * B + 2.0 * s.nk * (double)L * C * B;
@@ -1117,14 +1095,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
                     run_conv(h, s.rb[j][m].second, a, B, nm, st);
                     src[j] = dst;
                 }
-        } else if (rb_split || rb_big) {
-            if (rb_big) {  // (dev option: the conv1 outputs of a full-length stage; allocated on first use, outside any graph capture)
-                const size_t need = (size_t)3 * B * L * C * 2;
-                if (h->H.bytes < need) {
-                    HIP_CHECK(hipStreamSynchronize(st));
-                    h->H.alloc(need);
-                }
-            }
+        } else if (rb_split) {
             // a handful of rows (realtime chunk): conv1 / conv2 of all resblocks as two output-channel-split launches per pair level
             snprintf(nm, sizeof(nm), "rb_split_c%d", C);
             for (size_t m = 0; m < maxnd; ++m) {
@@ -1170,8 +1141,8 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
                     ++nj;
                 }
                 if (!nj) continue;
-                run_conv_jobs(h, L1, a1, nj, B, nm, st, rb_big);
-                run_conv_jobs(h, L2, a2, nj, B, nm, st, rb_big);
+                run_conv_jobs(h, L1, a1, nj, B, nm, st);
+                run_conv_jobs(h, L2, a2, nj, B, nm, st);
             }
         } else if (try_rb_stream_full(h, s, op, C, (int)L, B, nk, src, st, lens, lm, x0h_stream)) {
             // streaming fused resblocks (rb_stream_kernels.hpp): persistent blocks walk strips of the time axis
@@ -1396,33 +1367,18 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
     // ---- x = tanh(conv_post(leaky_relu(x)))                                    nsf.py:187-189
     const int nkk = c.n_resblock_kernels;
     h->prof.launch("conv_post", 2.0 * 7 * Cprev * (double)L * B, (double)B * L * (Cprev * nkk * (yhalf ? 2 : 4) + 4), st, [&] {
-        // round 6: three fp16 streams (every shipped config) through the LDS-DMA kernel: persistent blocks, next tile in flight (option POST_DMA)
+        // round 6: three fp16 streams (every shipped config) through the LDS-DMA kernel: persistent blocks, next tile in flight (option POST_DMA = 0: k_post)
         if (yhalf && y[1] && y[2] && div == 3.f && (Cprev == 32 || Cprev == 16) && h->opt.geti("POST_DMA", 1) != 0) {
-            const int depth = h->opt.geti("POST_DMA", 1) >= 2 ? 2 : 1;  // option POST_DMA: 0 = k_post, 1 = one tile ahead, 2 = two tiles ahead
             const int ntiles = (int)((L + POSTD_TT - 1) / POSTD_TT);
-            const int slots = std::max(1, num_cus() * h->opt.geti("POST_DMA_OCC", depth == 2 ? 2 : 3) / B);
+            const int slots = std::max(1, num_cus() * h->opt.geti("POST_DMA_OCC", 3) / B);
             const dim3 grid((unsigned)std::min(ntiles, slots), B);
             const int dbg = h->opt.geti("POST_DBG", 0);
-#define RVCMI_POST_DMA_LAUNCH(C_, D_)                                                                                              \
-    do {                                                                                                                           \
-        static std::atomic<unsigned long long> attr_done{0};                                                                       \
-        auto kern_ = &k_post_dma<C_, D_>;                                                                                          \
-        const size_t smem_ = post_dma_smem<C_, D_>();                                                                              \
-        int dev_ = 0;                                                                                                              \
-        HIP_CHECK(hipGetDevice(&dev_));                                                                                            \
-        if (!(attr_done.load() & (1ull << (dev_ & 63)))) {                                                                         \
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern_), hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                          160 * 1024));                                                                            \
-            attr_done.fetch_or(1ull << (dev_ & 63));                                                                               \
-        }                                                                                                                          \
-        hipLaunchKernelGGL(kern_, grid, dim3(POSTD_TT), smem_, st, (const _Float16*)y[0], (const _Float16*)y[1],                  \
-                           (const _Float16*)y[2], h->post_w.as<float>(), out, (int)L, lens, lm, dbg);                              \
-    } while (0)
-            if (Cprev == 32 && depth == 2) RVCMI_POST_DMA_LAUNCH(32, 2);
-            else if (Cprev == 32) RVCMI_POST_DMA_LAUNCH(32, 1);
-            else if (depth == 2) RVCMI_POST_DMA_LAUNCH(16, 2);
-            else RVCMI_POST_DMA_LAUNCH(16, 1);
-#undef RVCMI_POST_DMA_LAUNCH
+            if (Cprev == 32)
+                hipLaunchKernelGGL(k_post_dma<32>, grid, dim3(POSTD_TT), post_dma_smem<32>(), st, (const _Float16*)y[0], (const _Float16*)y[1],
+                                   (const _Float16*)y[2], h->post_w.as<float>(), out, (int)L, lens, lm, dbg);
+            else
+                hipLaunchKernelGGL(k_post_dma<16>, grid, dim3(POSTD_TT), post_dma_smem<16>(), st, (const _Float16*)y[0], (const _Float16*)y[1],
+                                   (const _Float16*)y[2], h->post_w.as<float>(), out, (int)L, lens, lm, dbg);
             return;
         }
         const size_t smem = (size_t)(7 * Cprev + (POST_TT + 6) * (Cprev + 4)) * 4;

@@ -448,12 +448,11 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_off) {
                  : "v"(g), "s"(lds_off)
                  : "memory");
 }
-constexpr int POSTD_TT = 128;  // output rows per tile = threads per block (two waves)
-// DEPTH = tiles in flight ahead of the one being computed (= raw buffers).  Ablations of DEPTH 1 (round 6, B = 1, `POST_DBG`): whole kernel 39 us =
-// DMA alone 24 us (113 MB at 4.7 TB/s: three blocks per CU x one 26 KB tile in flight each = 77 KB per CU against ~4 us of loaded latency) +
-// convert / conv alone ~15 us (LDS-bound: 112 ds_read_b128 per output) -- the parts ADD, because a block has nothing in flight while it converts.
-// DEPTH 2 keeps a tile in flight through the whole iteration (two blocks per CU: 75 KB of LDS each).
-template <int C, int DEPTH>
+constexpr int POSTD_TT = 128;  // output rows per tile = threads per block (two waves); three blocks per CU
+// Ablations (round 6, B = 1, option POST_DBG): whole kernel 36 us; DMA alone 23 us (113 MB at 4.9 TB/s: three blocks per CU x one 26 KB
+// tile in flight each against ~4 us of loaded latency); everything but the DMA ~15 us (LDS-bound: 112 ds_read_b128 per output).  A variant with TWO
+// tiles in flight (counted vmcnt, two 75 KB blocks per CU) was built, bit-identical, and measured 46 us: four waves per CU hide even less of the LDS phase.  Removed.
+template <int C>
 static __global__ void __launch_bounds__(POSTD_TT) k_post_dma(const _Float16* __restrict__ xa, const _Float16* __restrict__ xb,
                                                              const _Float16* __restrict__ xc, const float* __restrict__ Wp /*[7][C]*/,
                                                              float* __restrict__ out, int Lmax, const int* __restrict__ lens, int lmul,
@@ -461,12 +460,11 @@ static __global__ void __launch_bounds__(POSTD_TT) k_post_dma(const _Float16* __
     constexpr int TT = POSTD_TT, NW = TT / 64, S = C + 4, C8 = C / 8, ROWB = C * 2;
     constexpr int TILEB = (TT + 6) * ROWB;                 // bytes of one stream's rows of a tile
     constexpr int NP = (TILEB + 1023) / 1024, RAWB = NP * 1024;  // 1 KB DMA pieces per stream
-    constexpr int PPW0 = (3 * NP + NW - 1) / NW;           // pieces per tile issued by wave 0 (the other waves: PPW0 or PPW0 - 1)
-    static_assert(DEPTH == 1 || DEPTH == 2, "one or two tiles ahead");
+    constexpr int PPW0 = (3 * NP + NW - 1) / NW;           // pieces per tile issued by a wave (at most)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* w = (float*)smem_raw;                           // [7][C]
     float* tile = w + 7 * C;                               // [TT + 6][C + 4] fp32
-    char* raw0 = (char*)(tile + (TT + 6) * S);             // [DEPTH][3][RAWB] fp16 rows as they lie in HBM
+    char* raw = (char*)(tile + (TT + 6) * S);              // [3][RAWB] fp16 rows as they lie in HBM
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -475,12 +473,11 @@ static __global__ void __launch_bounds__(POSTD_TT) k_post_dma(const _Float16* __
     const size_t boff = (size_t)b * Lmax * C;
     const int nvalid = (L + TT - 1) / TT, nall = (Lmax + TT - 1) / TT;
     const char* src[3] = {(const char*)(xa + boff), (const char*)(xb + boff), (const char*)(xc + boff)};
-    const int npw = (3 * NP - wave + NW - 1) / NW;  // pieces per tile of THIS wave
+    const unsigned raw_off = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char*)raw);
 
-    auto issue = [&](int ti, const char* raw) {  // the (TT + 6) rows [t0 - 3, t0 + TT + 3) of the three streams; rows outside [0, L) are clamped here, zeroed in convert
+    auto issue = [&](int ti) {  // the (TT + 6) rows [t0 - 3, t0 + TT + 3) of the three streams; rows outside [0, L) are clamped here, zeroed in convert
         if (dbg & 1) return;
         const int t0 = ti * TT;
-        const unsigned raw_off = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) char*)raw);
 #pragma unroll
         for (int p0 = 0; p0 < PPW0; ++p0) {
             const int p = p0 * NW + wave;  // wave-uniform
@@ -494,29 +491,15 @@ static __global__ void __launch_bounds__(POSTD_TT) k_post_dma(const _Float16* __
         }
     };
 
-    int ti = blockIdx.x, it = 0;
-    if (ti < nvalid) issue(ti, raw0);
-    if (DEPTH == 2 && ti + (int)gridDim.x < nvalid) issue(ti + gridDim.x, raw0 + 3 * RAWB);
-    for (; ti < nvalid; ti += gridDim.x, ++it) {
+    int ti = blockIdx.x;
+    if (ti < nvalid) issue(ti);
+    for (; ti < nvalid; ti += gridDim.x) {
         const int t0 = ti * TT;
-        char* raw = raw0 + (DEPTH == 2 ? (it & 1) * 3 * RAWB : 0);
-        if constexpr (DEPTH == 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();  // every wave's pieces of this tile have landed; the previous tile's conv is done with `tile`
-        } else {
-            // the NEXT tile's pieces (issued after this tile's) may stay in flight: loads retire in order, so at most `npw` outstanding
-            // operations means every piece of THIS tile has landed (a still outstanding `out` store only makes the wait stricter)
-            if (ti + (int)gridDim.x < nvalid) {
-                if (npw == PPW0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW0) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW0 - 1) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            lds_barrier();  // (LDS-only barrier: __syncthreads() would drain the tile in flight)
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces THIS wave issued have landed ...
+        lds_barrier();                                   // ... and so have everybody's; the previous tile's conv is done with `tile`
         if (dbg & 2) {
             lds_barrier();
-            if (ti + DEPTH * (int)gridDim.x < nvalid) issue(ti + DEPTH * gridDim.x, raw);
+            if (ti + (int)gridDim.x < nvalid) issue(ti + gridDim.x);
             if (tid == 0) out[(size_t)b * Lmax + t0] = *(const float*)raw;
             continue;
         }
@@ -535,8 +518,8 @@ static __global__ void __launch_bounds__(POSTD_TT) k_post_dma(const _Float16* __
             *(float4*)(tile + r * S + c8 * 8) = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)(tile + r * S + c8 * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
-        lds_barrier();  // the tile is complete and this `raw` buffer is free
-        if (ti + DEPTH * (int)gridDim.x < nvalid) issue(ti + DEPTH * gridDim.x, raw);  // flies during the conv below (DEPTH 2: and the whole next iteration)
+        lds_barrier();  // the tile is complete and `raw` is free
+        if (ti + (int)gridDim.x < nvalid) issue(ti + gridDim.x);  // flies during the conv below
         const int t = t0 + tid;
         float acc = 0.f;
 #pragma unroll
@@ -559,9 +542,9 @@ static __global__ void __launch_bounds__(POSTD_TT) k_post_dma(const _Float16* __
     for (ti = blockIdx.x; ti < nall; ti += gridDim.x)  // (ragged batch) tiles behind the item's end
         if (ti >= nvalid && ti * TT + tid < Lmax) out[(size_t)b * Lmax + ti * TT + tid] = 0.f;
 }
-template <int C, int DEPTH>
+template <int C>
 static constexpr size_t post_dma_smem() {
-    return (size_t)(7 * C + (POSTD_TT + 6) * (C + 4)) * 4 + (size_t)DEPTH * 3 * (((POSTD_TT + 6) * C * 2 + 1023) / 1024) * 1024;
+    return (size_t)(7 * C + (POSTD_TT + 6) * (C + 4)) * 4 + (size_t)3 * (((POSTD_TT + 6) * C * 2 + 1023) / 1024) * 1024;
 }
 
 // ... of fp16 streams (Y_F16)
@@ -1265,14 +1248,6 @@ static __global__ void __launch_bounds__(256) k_conv_mfma_jobs(ConvJobs js) {
     // a weight ring of 4 groups (12 k-steps in flight): with one MFMA per k-step (NJ = 1) the default 2 groups cover 4 k-steps =
     // ~260 cycles, less than one L2 round trip, and the K loop ran at the latency of the weight loads (28 us per launch)
     conv_mfma_body<OpT, CIN, MI, NJ, WCO, 4, true>(js.job[j], b, smem);
-}
-
-// dev (option RB_SPLIT_BIG): the same conv with 64-channel x 256-row blocks for full-length launches (default weight ring, no weight pre-touch)
-template <typename OpT, int CIN>
-static __global__ void __launch_bounds__(256) k_conv_mfma_jobs_big(ConvJobs js) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int j = (int)blockIdx.z % js.njobs, b = (int)blockIdx.z / js.njobs;
-    conv_mfma_body<OpT, CIN, 2, 2, 1>(js.job[j], b, smem);
 }
 
 // Branch-free helpers.  lrelu as max(x, slope*x) (0 < slope < 1); row masking by AND-ing the value bits so that

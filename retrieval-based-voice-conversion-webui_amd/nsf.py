@@ -114,9 +114,8 @@ class _HipGenerator(torch.nn.Module):
 
     def set_option(self, key: str, value=None) -> None:
         """Dev / test option of this handle (``rvcmi_nsf_set_option``: e.g. ``RB_STREAM`` 0 / 1 pins the ResBlock kernel family,
-        ``RS_SMALL``, ``RS_KL``, ``Y_F16``, ``X0_F16`` / ``X0_F16_NOSTREAM``, ``UPS_BL``, ``CONV_KS``, ``RBF_SMALL``, ``DBG``; round 6: ``POST_DMA`` 0 / 1 / 2 =
-        conv_post by the register-staged kernel / LDS-DMA one tile ahead (default) / two tiles ahead, ``POST_DMA_OCC``, ``POST_DBG``, and the
-        measurement-only ``RB_SPLIT_BIG``, ``UPS_NJ_256``, ``UPS_VPW_256``; an unknown key is an error); ``None`` restores the default.  The library reads ``RVCMI_<KEY>`` only when a handle is created."""
+        ``RS_SMALL``, ``RS_KL``, ``Y_F16``, ``X0_F16`` / ``X0_F16_NOSTREAM``, ``UPS_BL``, ``CONV_KS``, ``RBF_SMALL``, ``DBG``; round 6: ``POST_DMA`` 0 / 1 =
+        conv_post by the register-staged kernel / by LDS-DMA with the next tile in flight (default), ``POST_DMA_OCC``, ``POST_DBG`` (timing ablations); an unknown key is an error); ``None`` restores the default.  The library reads ``RVCMI_<KEY>`` only when a handle is created."""
         _lib.set_option(_lib.lib().rvcmi_nsf_set_option, self._handle, key, value)  # raises on a key this handle does not honour
         if not hasattr(self, "_options"):
             self._options = {}
