@@ -853,7 +853,8 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert torch.isfinite(out_holder["o"]).all(), "non-finite generator output"
+    # (timing ablations -- RVCMI_DBG / RVCMI_POST_DBG, wrong results by construction -- set RVCMI_BENCH_ABLATION=1; such a line is never a result)
+    assert os.environ.get("RVCMI_BENCH_ABLATION") == "1" or torch.isfinite(out_holder["o"]).all(), "non-finite generator output"
 
     # ---- stability report: R more repetitions of the same K-step loop (same step, same graph), per-rank wall clock ----
     rep_stats = None

@@ -558,3 +558,69 @@ def test_blend_segments_concatenates_and_slices_like_the_per_segment_calls(monke
     assert [c[0] for c in calls] == [8, 7] and all(c[1] is None and c[3] is None for c in calls)
     for (feats, _, _, p_len), r in zip(items2, raw):
         assert torch.equal(feats[0], torch.repeat_interleave(r[0][0], 2, dim=0)[:p_len])
+
+
+def test_index_cache_of_the_rebound_pipeline(monkeypatch, tmp_path):
+    """``rvc_amd.pipeline._open_index`` keeps the parsed index of a path resident between calls (the reference re-reads the file in every
+    ``pipeline()`` call, pipeline.py:205-218): same object for an unchanged file, a new read when size / mtime change, at most
+    ``INDEX_CACHE_ENTRIES`` files resident (oldest out), ``RVCMI_INDEX_CACHE=0`` = read per call, index_rate 0 / missing file = no index."""
+    import types
+
+    import rvc_amd.pipeline as pl
+    from rvc_amd import ivf
+
+    reads = []
+    monkeypatch.setattr(ivf, "read_index", lambda path, device=None: (reads.append(path), object())[1])
+    monkeypatch.setattr(pl, "_INDEX_CACHE", {})
+    self = types.SimpleNamespace(device="cpu")
+    a, b, c = [str(tmp_path / n) for n in ("a.index", "b.index", "c.index")]
+    for p_ in (a, b, c):
+        open(p_, "wb").write(b"x" * 10)
+    assert pl._open_index(self, a, 0.0) == (None, False) and pl._open_index(self, str(tmp_path / "nope.index"), 0.75) == (None, False)
+    i1, _ = pl._open_index(self, a, 0.75)
+    i2, _ = pl._open_index(self, a, 0.75)
+    assert i1 is i2 and reads == [a]
+    open(a, "wb").write(b"y" * 11)  # another size (and mtime): a different index behind the same name
+    i3, _ = pl._open_index(self, a, 0.75)
+    assert i3 is not i1 and reads == [a, a]
+    pl._open_index(self, b, 0.75)
+    pl._open_index(self, c, 0.75)  # a third file: the oldest entry leaves
+    assert len(pl._INDEX_CACHE) == pl.INDEX_CACHE_ENTRIES and reads == [a, a, b, c]
+    assert pl._open_index(self, c, 0.75)[0] is pl._open_index(self, c, 0.75)[0] and len(reads) == 4
+    monkeypatch.setenv("RVCMI_INDEX_CACHE", "0")
+    assert pl._open_index(self, c, 0.75)[0] is not pl._open_index(self, c, 0.75)[0] and len(reads) == 6
+
+
+def test_e2e_rmvpe_proxy_has_the_reference_architecture():
+    """``tools/e2e_proxies.py`` (the stand-in ``bench.py --e2e`` times for the RMVPE network): same parameter count and the same FLOPs as the
+    reference's own ``E2E(4, 1, (2, 2))`` (rvc/f0/e2e.py, rvc/f0/models.py), output [1, T, 360] in (0, 1).  Skipped on the GPU box."""
+    ref = os.environ.get("RVC_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "rvc")):
+        pytest.skip("reference checkout not mounted")
+    import sys
+    import types
+
+    from torch.utils.flop_counter import FlopCounterMode
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, ref)
+    sys.modules.setdefault("numba", types.SimpleNamespace(jit=lambda *a, **k: (lambda f: f), njit=lambda *a, **k: (lambda f: f)))
+    try:
+        from e2e_proxies import _SalienceNet
+        from rvc.f0.e2e import E2E
+
+        theirs, ours = E2E(4, 1, (2, 2)).eval(), _SalienceNet().eval()
+        assert sum(p.numel() for p in ours.parameters()) == sum(p.numel() for p in theirs.parameters()) == 90423165
+        mel = torch.randn(1, 128, 64)
+        fl = []
+        for m in (theirs, ours):
+            with FlopCounterMode(display=False) as fc, torch.no_grad():
+                y = m(mel)
+            fl.append(fc.get_total_flops())
+            assert y.shape == (1, 64, 360) and float(y.min()) > 0 and float(y.max()) < 1
+        assert fl[0] == fl[1]
+    finally:
+        sys.path.remove(ref)
+        sys.path.remove(os.path.join(ROOT, "tools"))
+        for m in [m for m in sys.modules if m.split(".")[0] in ("rvc", "e2e_proxies")]:
+            del sys.modules[m]
