@@ -1383,7 +1383,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
         }
         const size_t smem = (size_t)(7 * Cprev + (POST_TT + 6) * (Cprev + 4)) * 4;
         hipLaunchKernelGGL(k_post, dim3((unsigned)((L + POST_TT - 1) / POST_TT), B), dim3(256), smem, st, y[0], y[1], y[2],
-                           h->post_w.as<float>(), out, (int)L, Cprev, div, yhalf ? 1 : 0, lens, lm);
+                           h->post_w.as<float>(), out, (int)L, Cprev, div, yhalf ? 1 : 0, lens, lm, h->opt.geti("POST_DBG", 0));
     });
     HIP_CHECK(hipGetLastError());
 }

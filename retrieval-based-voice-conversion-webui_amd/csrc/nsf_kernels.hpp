@@ -291,7 +291,7 @@ constexpr int POST_TT = 256;  // = blockDim: one output sample per thread (a 128
 static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ xa, const float* __restrict__ xb,
                                               const float* __restrict__ xc, const float* __restrict__ Wp /*[7][C]*/,
                                               float* __restrict__ out, int Lmax, int C, float div, int in_half,
-                                              const int* __restrict__ lens, int lmul) {
+                                              const int* __restrict__ lens, int lmul, int dbg = 0 /* timing ablation: 2 = staging only */) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* w = (float*)smem_raw;          // [7][C]
     float* tile = w + 7 * C;              // [POST_TT + 6][C + 4]
@@ -405,6 +405,11 @@ static __global__ void __launch_bounds__(256) k_post(const float* __restrict__ x
         }
         __syncthreads();
         const int t = t0 + threadIdx.x;
+        if (dbg & 2) {  // (timing ablation, wrong results: what the staging alone costs)
+            if (threadIdx.x == 0) out[(size_t)b * Lmax + t0] = tile[0];
+            __syncthreads();
+            continue;
+        }
         if (t < L) {
             float acc = 0.f;
             for (int j = 0; j < 7; ++j) {
@@ -1605,7 +1610,7 @@ static __global__ void __launch_bounds__(256, UPS_OCC) k_ups(UpsArgs a) {  // 2 
     constexpr int C8 = CIN / 8;
     constexpr int WT = 4 / WV;
     constexpr int TQ = 32 * NJ * WT;
-    constexpr int SB = 8;  // independent chunk loads (x up to 3 inputs) in flight per thread; the accumulators are not live yet
+    constexpr int SB = 5;  // chunk loads (x 3 inputs) in flight per thread: 1280 chunks per pass cover the 1056 / 1048 of the two HBM-bound stages in ONE pass (8 cost the C_in = 64 instantiation its fourth resident block: 134 registers)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.z;
     const int q0 = blockIdx.x * TQ;
@@ -1641,68 +1646,113 @@ static __global__ void __launch_bounds__(256, UPS_OCC) k_ups(UpsArgs a) {  // 2 
         for (int i = threadIdx.x; i < 2 * a.cout; i += 256) bias_l[i] = i < a.cout ? a.bias[i] : (a.bn ? a.bn[i - a.cout] : 0.f);
     }
     const int total = a.tile_rows * C8;
-    for (int base = threadIdx.x; base < total; base += SB * 256) {
-        float f[SB][8];
+    // Round 6: EVERY load of a batch is issued before the first one is used.  The loop used to read `load a; if (in_b) load b; if (in_c) load c`
+    // per chunk; hipcc compiled each conditional load into its own block with `s_waitcnt vmcnt(0)` behind it -- 24 DEPENDENT memory round trips
+    // per thread and tile, one 4 KB wave-load in flight per wave (found in the ISA after the timing ablations showed the staging alone at
+    // 46 of ups_c128's 60 us = 2.4 TB/s, against 23 us for the same bytes through k_post_dma).  Now the pointers of absent streams alias in_a
+    // (unconditional loads) and only the register adds are conditional.
+    auto convert_store = [&](int idx, float (&f)[8], bool ok) {
+        const int r = idx / C8;
+        const int c8 = idx - r * C8;
+        if (!ok) {
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int idx = min(base + u * 256, total - 1);  // past the tile: re-request its last chunk (an L1 hit), not the neighbour's rows
-            const int r = idx / C8;
-            const int c8 = idx - r * C8;
-            const int gr = g0 + r;
-            const bool ok = gr >= 0 && gr < Linb;
-            const int grc = min(max(gr, 0), Linb - 1);  // clamped address: unconditional loads
-            if (a.in_half) {  // fp16 streams: one 16-byte load per input
-                const size_t o = boff + (size_t)grc * CIN + c8 * 8;
-                unpack8_h(*(const uint4*)((const _Float16*)a.in_a + o), f[u]);
-                if (a.in_b) {
-                    float t[8];
-                    unpack8_h(*(const uint4*)((const _Float16*)a.in_b + o), t);
+            for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        }
+        frag v;
+        if (a.div == 3.f) {  // the three ResBlocks of every shipped config: the short exact quotient, one v_mul + one v_med3 lrelu
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[u][e] += t[e];
-                }
-                if (a.in_c) {
-                    float t[8];
-                    unpack8_h(*(const uint4*)((const _Float16*)a.in_c + o), t);
+            for (int e = 0; e < 8; ++e) v[e] = (OpT)lrelu_op<OpT>(div3_exact(f[e]));
+        } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[u][e] += t[e];
-                }
-            } else {
-                const size_t o = boff + (size_t)grc * CIN + c8 * 8;
-                const float4 l0 = *(const float4*)(a.in_a + o), h0 = *(const float4*)(a.in_a + o + 4);
-                f[u][0] = l0.x; f[u][1] = l0.y; f[u][2] = l0.z; f[u][3] = l0.w; f[u][4] = h0.x; f[u][5] = h0.y; f[u][6] = h0.z; f[u][7] = h0.w;
-                if (a.in_b) {
-                    const float4 l1 = *(const float4*)(a.in_b + o), h1 = *(const float4*)(a.in_b + o + 4);
-                    f[u][0] += l1.x; f[u][1] += l1.y; f[u][2] += l1.z; f[u][3] += l1.w; f[u][4] += h1.x; f[u][5] += h1.y; f[u][6] += h1.z; f[u][7] += h1.w;
-                }
-                if (a.in_c) {
-                    const float4 l2 = *(const float4*)(a.in_c + o), h2 = *(const float4*)(a.in_c + o + 4);
-                    f[u][0] += l2.x; f[u][1] += l2.y; f[u][2] += l2.z; f[u][3] += l2.w; f[u][4] += h2.x; f[u][5] += h2.y; f[u][6] += h2.z; f[u][7] += h2.w;
-                }
-            }
-            if (!ok) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[u][e] = 0.f;
+            for (int e = 0; e < 8; ++e) {
+                float x = f[e];
+                if (a.div != 1.f) x = x / a.div;
+                v[e] = to_op<OpT>(lrelu(x, 0.1f));
             }
         }
+        *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
+    };
+    if (a.in_half) {  // fp16 streams: one 16-byte load per input and chunk
+        const _Float16* pa = (const _Float16*)a.in_a;
+        const _Float16* pb = a.in_b ? (const _Float16*)a.in_b : pa;
+        const _Float16* pc = a.in_c ? (const _Float16*)a.in_c : pa;
+        for (int base = threadIdx.x; base < total; base += SB * 256) {
+            uint4 ra[SB], rb[SB], rc[SB];
+            size_t off[SB];
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int idx = base + u * 256;
-            if (idx >= total) continue;
-            const int r = idx / C8;
-            const int c8 = idx - r * C8;
-            frag v;
-            if (a.div == 3.f) {  // the three ResBlocks of every shipped config: the short exact quotient, one v_mul + one v_med3 lrelu
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (OpT)lrelu_op<OpT>(div3_exact(f[u][e]));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float x = f[u][e];
-                    if (a.div != 1.f) x = x / a.div;
-                    v[e] = to_op<OpT>(lrelu(x, 0.1f));
-                }
+            for (int u = 0; u < SB; ++u) {
+                const int idx = min(base + u * 256, total - 1);  // past the tile: re-request its last chunk (an L1 hit), not the neighbour's rows
+                const int r = idx / C8;
+                const int c8 = idx - r * C8;
+                const int grc = min(max(g0 + r, 0), Linb - 1);  // clamped address: unconditional loads
+                off[u] = boff + (size_t)grc * CIN + c8 * 8;
+                ra[u] = *(const uint4*)(pa + off[u]);
             }
-            *(frag*)(smem + (size_t)r * STRIDE + c8 * 16) = v;
+#pragma unroll
+            for (int u = 0; u < SB; ++u) rb[u] = *(const uint4*)(pb + off[u]);
+#pragma unroll
+            for (int u = 0; u < SB; ++u) rc[u] = *(const uint4*)(pc + off[u]);
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = base + u * 256;
+                if (idx >= total) continue;
+                float f[8], t[8];
+                unpack8_h(ra[u], f);
+                if (a.in_b) {
+                    unpack8_h(rb[u], t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += t[e];
+                }
+                if (a.in_c) {
+                    unpack8_h(rc[u], t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += t[e];
+                }
+                const int gr = g0 + idx / C8;
+                convert_store(idx, f, gr >= 0 && gr < Linb);
+            }
+        }
+    } else {  // fp32 streams (stage 0 reads conv_pre's output, stage 1 the fp32 streams of k_rb_pair<256>): two 16-byte loads per input and chunk
+        constexpr int SF = 4;
+        const float* pb = a.in_b ? a.in_b : a.in_a;
+        const float* pc = a.in_c ? a.in_c : a.in_a;
+        for (int base = threadIdx.x; base < total; base += SF * 256) {
+            float4 la[SF], ha[SF], lb[SF], hb[SF], lc[SF], hc[SF];
+            size_t off[SF];
+#pragma unroll
+            for (int u = 0; u < SF; ++u) {
+                const int idx = min(base + u * 256, total - 1);
+                const int r = idx / C8;
+                const int c8 = idx - r * C8;
+                const int grc = min(max(g0 + r, 0), Linb - 1);
+                off[u] = boff + (size_t)grc * CIN + c8 * 8;
+                la[u] = *(const float4*)(a.in_a + off[u]);
+                ha[u] = *(const float4*)(a.in_a + off[u] + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < SF; ++u) {
+                lb[u] = *(const float4*)(pb + off[u]);
+                hb[u] = *(const float4*)(pb + off[u] + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < SF; ++u) {
+                lc[u] = *(const float4*)(pc + off[u]);
+                hc[u] = *(const float4*)(pc + off[u] + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < SF; ++u) {
+                const int idx = base + u * 256;
+                if (idx >= total) continue;
+                float f[8] = {la[u].x, la[u].y, la[u].z, la[u].w, ha[u].x, ha[u].y, ha[u].z, ha[u].w};
+                if (a.in_b) {
+                    f[0] += lb[u].x; f[1] += lb[u].y; f[2] += lb[u].z; f[3] += lb[u].w; f[4] += hb[u].x; f[5] += hb[u].y; f[6] += hb[u].z; f[7] += hb[u].w;
+                }
+                if (a.in_c) {
+                    f[0] += lc[u].x; f[1] += lc[u].y; f[2] += lc[u].z; f[3] += lc[u].w; f[4] += hc[u].x; f[5] += hc[u].y; f[6] += hc[u].z; f[7] += hc[u].w;
+                }
+                const int gr = g0 + idx / C8;
+                convert_store(idx, f, gr >= 0 && gr < Linb);
+            }
         }
     }
     // nz_k1: fp16 copy of the excitation samples every output row of this block can touch (zero outside the signal)
