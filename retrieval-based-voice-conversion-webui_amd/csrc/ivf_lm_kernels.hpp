@@ -79,9 +79,10 @@ __global__ void __launch_bounds__(1024) k_lm_plan(const int64_t* __restrict__ as
     // the lengths of this thread's lists, requested before anything else (their latency runs under the counting pass)
     int lenr[LM_PER];
 #pragma unroll
-    for (int j = 0; j < LM_PER; ++j) {
-        const int l = min(b + j, nlist - 1);
-        lenr[j] = j < per ? (int)(list_off[l + 1] - list_off[l]) : 0;
+    for (int j = 0; j < LM_PER; ++j) {  // (unconditional, clamped loads: a `j < per ? load : 0` is a branch with its own wait per j -- 2 x 16 dependent
+        const int l = min(b + j, nlist - 1);  //  round trips at nlist = 16000 -- and the select on the VALUE costs nothing)
+        const int64_t o0 = list_off[l], o1 = list_off[l + 1];
+        lenr[j] = j < per ? (int)(o1 - o0) : 0;
     }
     for (int i = threadIdx.x; i < n1; i += 1024) cnt[i] = 0;
     __syncthreads();
