@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "POST_DMA", "POST_DMA_OCC", "POST_DBG", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS", "RBF_SMALL"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "UPS_TW", "POST_DMA", "POST_DMA_OCC", "POST_DBG", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS", "RBF_SMALL"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -448,6 +448,15 @@ static void launch_ups_inst(UpsArgs a, int nj, int B, hipStream_t st) {
         } else {
             a.out_tr = 0;
         }
+    }
+    // ... else, for one-tile waves writing fp16 (stage 1 of v2/48k: 10 phases x 128 channels, the block's output tile would be 87 KB): wave-private
+    // transposition tiles, so that the stores are whole 128-byte lines (option UPS_TW)
+    if (a.out_tw_off && !a.out_tr && a.out_half && nj == 1 && MI == 2 && a.cout % 64 == 0) {
+        smem = (smem + 15) / 16 * 16;
+        a.out_tw_off = (int)smem;
+        smem += (size_t)4 * 32 * (MI * 64 + 16);
+    } else {
+        a.out_tw_off = 0;
     }
     if (nj == 4) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 4>), grid, dim3(256), smem, st, a);
     else if (nj == 2) hipLaunchKernelGGL((k_ups<OpT, CIN, MI, WV, 2>), grid, dim3(256), smem, st, a);
@@ -976,6 +985,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             ua.out = h->X0.as<float>();
             ua.out_half = x0h ? 1 : 0;
             ua.out_tr = h->opt.geti("UPS_TR", 1) != 0 ? 1 : 0;  // (the launcher clears it where the block does not own whole rows)
+            ua.out_tw_off = h->opt.geti("UPS_TW", 1) != 0 ? 1 : 0;  // (the launcher turns it into the LDS offset where it applies)
             ua.out_bstride = L * C;
             if (c.use_f0 && s.nz_mfma) {  // noise_convs[i](har) as a 2-tap MFMA conv over frames -> NZ, added in k_ups' epilogue
                 ConvArgs na = base_args();

@@ -1581,6 +1581,9 @@ struct UpsArgs {
                    //    tile at byte offset out_tr_off of the dynamic LDS: each D-layout store touched 8 (fp16) / 16 (fp32) bytes of 32 rows --
                    //    16 partial writes per 128-byte line, 1.6 TB/s -- the row-wise stores write whole lines
     int out_tr_off;
+    int out_tw_off;  // > 0 (round 6; NJ == 1, fp16 X0, the block does NOT own whole rows -- stage 1 of v2/48k): byte offset of four wave-private
+                     //    transposition tiles [32][MI * 64 + 16 B]: a wave's virtual tile (32 rows x MI * 32 channels) is written there in D layout
+                     //    and stored from there as 16 bytes per lane, eight lanes = one whole 128-byte line of a row
     long out_bstride;
     const float* addend;  // optional [B][Lin*u][cout] fp32 added in the epilogue (noise conv done by the MFMA conv)
     const float* har;  // [B][Lh] or nullptr (no-f0 generator / addend in use)
@@ -1866,9 +1869,24 @@ static __global__ void __launch_bounds__(256, UPS_OCC) k_ups(UpsArgs a) {  // 2 
                             char* ot = smem + a.out_tr_off;
                             if (a.out_half) *(uint2*)(ot + (size_t)orow * (a.cout * 2 + 16) + co * 2) = pack4_h(v[0], v[1], v[2], v[3]);
                             else *(f32x4*)(ot + (size_t)orow * (a.cout * 4 + 16) + co * 4) = v;
+                        } else if (NJ == 1 && a.out_tw_off) {
+                            *(uint2*)(smem + a.out_tw_off + (wave * 32 + (lane & 31)) * (MI * 64 + 16) + (mi * 32 + 8 * g + 4 * (lane >> 5)) * 2) =
+                                pack4_h(v[0], v[1], v[2], v[3]);
                         } else if (a.out_half) *(uint2*)((_Float16*)a.out + (size_t)b * a.out_bstride + (size_t)t * a.cout + co) = pack4_h(v[0], v[1], v[2], v[3]);
                         else *(f32x4*)(out + (size_t)t * a.cout + co) = v;
                     }
+            }
+        }
+        if (NJ == 1 && a.out_tw_off && !(a.dbg & 16)) {
+            // (wave-private: a wave's LDS operations execute in order, no barrier; each D-layout global store touched 8 bytes of 32 different rows)
+            constexpr int TWP = MI * 64 + 16, CPR = MI * 4;
+            const char* sc = smem + a.out_tw_off + wave * 32 * TWP;
+            for (int i2 = lane; i2 < 32 * CPR; i2 += 64) {
+                const int row = i2 / CPR, c = i2 - row * CPR;
+                const int q = q0 + tw0 + row;
+                if (q < Linb)
+                    *(uint4*)((char*)((_Float16*)a.out + (size_t)b * a.out_bstride + ((size_t)q * a.u + r) * a.cout + ct0 * 32) + c * 16) =
+                        *(const uint4*)(sc + row * TWP + c * 16);
             }
         }
     }
