@@ -112,7 +112,7 @@ static void nsf_create(const rvcmi_nsf_config* cfg, const rvcmi_tensor* weights,
     rb_stream_prepare();
 
     std::unique_ptr<rvcmi_nsf> h(new rvcmi_nsf());
-    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "UPS_TW", "POST_DMA", "POST_DMA_OCC", "POST_DBG", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS", "RBF_SMALL"});
+    h->opt.load_env({"RB_STREAM", "NO_RBFULL", "NO_RB_SPLIT", "NO_RB_SPLIT128", "RB_ORDER", "UPS_NJ", "UPS_TW", "PRE_OP", "POST_DMA", "POST_DMA_OCC", "POST_DBG", "NB", "DBG", "Y_F16", "X0_F16", "UPS_TR", "UPS_BL", "X0_F16_NOSTREAM", "CONV_KS", "RBF_SMALL"});
     rb_stream_load_env(h->opt);
     h->cfg = *cfg;
     h->device = device;
@@ -872,6 +872,9 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
                            h->cond_b.as<float>(), h->condv.as<float>(), c.gin_channels, C0);
     }
     float* P = h->P.as<float>();
+    // round 6: on the MFMA path conv_pre writes the ACTIVATED OPERANDS to_op(lrelu(conv + bias + cond, 0.1)) -- the only thing stage 0's upsampler does
+    // with P is to compute exactly that while staging (12 blocks per time tile each re-read and re-converted the fp32 rows) -- unless the fp32 "pre" tap is asked for
+    const bool pre_op = op != RVCMI_OPERAND_F32 && !want("pre") && h->opt.geti("PRE_OP", 1) != 0;
     {
         ConvArgs a = base_args();
         a.in = x;
@@ -879,7 +882,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
         a.Lin = Te;
         a.in_mode = IN_F32_CF;
         a.Lq = Te;
-        a.out_mode = OUT_F32;
+        a.out_mode = pre_op ? OUT_ACT : OUT_F32;
         a.out = P;
         a.out_bstride = (long)Te * C0;
         a.out_C = C0;
@@ -960,6 +963,7 @@ static void nsf_forward(rvcmi_nsf* h, int B, int T, const int* lens, const float
             ua.in_b = y[1];
             ua.in_c = y[2];
             ua.in_half = yhalf ? 1 : 0;
+            ua.in_raw = (i == 0 && pre_op) ? 1 : 0;  // (stage 0: y[0] = P holds operands already)
             ua.lens = lens;
             ua.lmul = lm_prev;
             ua.lhmul = upp;
