@@ -189,6 +189,28 @@ def test_wn_layer_forms_agree(mode, gpu):
             assert rms(z.cpu(), z0.cpu()) <= 2e-3
 
 
+@pytest.mark.parametrize("ks", [3, 7])
+def test_wn_gate_tap_split_with_other_flow_kernel_sizes(ks, gpu):
+    """The tap-split gate launches 64 x flow_kernel_size threads (wave w = tap w); every shipped config has 5 taps, other odd sizes take the
+    generic staging helper: the front with flow_kernel_size 3 / 7 against the oracle, in the one-launch form and in the tap-split form."""
+    fcfg = FrontConfig(flow_kernel_size=ks)
+    wf = synth.make_front_weights(fcfg, 21)
+    T, B = 90, 2
+    phone = synth.make_phone(B, T, 768, 21)
+    pitch = synth.make_pitch(synth.make_f0(B, T))
+    lengths, sid = torch.tensor([T, T - 23]), torch.tensor([3, 5])
+    noise = torch.randn(B, 192, T, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        z, m1, g = front_oracle.infer_front(fcfg, wf, phone, pitch, lengths, sid, noise)
+        z = z * m1
+    fr = hip_front(fcfg, wf, "fp16", gpu, max_B=B, max_T=128)
+    for mode in (0, 2):
+        fr.set_option("FR_WN_SPLIT", mode)
+        got = fr(phone.to(gpu), pitch.to(gpu), lengths.to(gpu), g.to(gpu), 0, noise=noise.to(gpu)).cpu()
+        e = rms(got, z)
+        assert e <= Z_BAR["fp16"], "flow_kernel_size %d, FR_WN_SPLIT=%d: z RMS error %.3e" % (ks, mode, e)
+
+
 @pytest.mark.parametrize("fused_ffn", [True, False, "split", "split_nj1"])
 def test_front_large_batch_tile_height_and_unfused_ffn(fused_ffn, gpu):
     """Large batches run 64-row time tiles (pick_nj) and the FFN exists in three forms -- one fused launch (k_fr_ffn, large
