@@ -674,6 +674,9 @@ def e2e_mode(a):
                                                                    "unet_head_linear_decode": round(split["rmvpe_proxy_mel_net_decode"] - 1e3 * (sub.get("mel_stft", 0.0) + sub.get("bigru", 0.0)) / n, 3)},
                                  "long_pole": max(split, key=split.get)}
     rvc_amd.uninstall()
+    import shutil
+
+    shutil.rmtree(tmp, ignore_errors=True)  # (the synthetic index file)
     big = cases["files_%d" % a.e2e_files]
     return {"metric": "end-to-end real-time factor per GPU, Pipeline.convert_files on 10 s clips (feeders = architecture proxies on PyTorch-ROCm)",
             "value": big["rtf"], "unit": "x real-time (audio-sec/wall-sec), %d files per call" % a.e2e_files, "n_gpus": 1, "higher_is_better": True,
