@@ -1107,6 +1107,10 @@ def main():
         if roof is not None:
             line["roofline"] = roof
         if whole is not None:
+            if not a.whole:
+                # the front + x2 / protect mix as the graph runs them: the two graphs of this run differ by exactly those launches (the event-bracketed
+                # eager sum above carries ~1.5 us of event overhead per launch)
+                whole["front_and_mix_in_graph_ms"] = round(whole["ms_per_step"] - line["ms_per_step"], 4)
             line["whole_infer"] = whole
         if cpu is not None:
             line["cpu_baseline"] = cpu
