@@ -282,6 +282,7 @@ def _rmvpe_on_device(self, audio_pad, p_len, f0_up_key):
 
 INDEX_CACHE_ENTRIES = 2  # index files kept resident (a WebUI session alternates between very few voices)
 _INDEX_CACHE = {}
+_INDEX_CACHE_LOCK = __import__("threading").Lock()  # (the WebUI serves requests from worker threads)
 
 
 def _open_index(self, file_index, index_rate):
@@ -303,15 +304,18 @@ def _open_index(self, file_index, index_rate):
         dev = torch.device(self.device)
         st = os.stat(file_index)
         key = (os.path.abspath(file_index), st.st_size, st.st_mtime_ns, str(dev))
-        if os.environ.get("RVCMI_INDEX_CACHE", "1") != "0":
-            hit = _INDEX_CACHE.get(key)
+        cached = os.environ.get("RVCMI_INDEX_CACHE", "1") != "0"
+        if cached:
+            with _INDEX_CACHE_LOCK:
+                hit = _INDEX_CACHE.get(key)
             if hit is not None:
                 return hit, False
         index = ivf.read_index(file_index, device=dev)
-        if os.environ.get("RVCMI_INDEX_CACHE", "1") != "0":
-            while len(_INDEX_CACHE) >= INDEX_CACHE_ENTRIES:
-                _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))  # oldest entry out (dicts keep insertion order)
-            _INDEX_CACHE[key] = index
+        if cached:
+            with _INDEX_CACHE_LOCK:
+                while len(_INDEX_CACHE) >= INDEX_CACHE_ENTRIES:
+                    _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))  # oldest entry out (dicts keep insertion order)
+                _INDEX_CACHE[key] = index
         return index, False
     except _lib.RvcmiError as e:
         orig = getattr(pipeline_hip, "_rvcmi_original", None)
