@@ -548,6 +548,21 @@ def leg_operands(a, dev, cfg, w, index, phone_d, zd, f0d, gd, nd, out_default, o
     return res
 
 
+def _cpu_quota():
+    """CPUs the cgroup lets this process use (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(q) // int(per))
+    except Exception:  # noqa
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, q // per)
+    except Exception:  # noqa
+        return None
+
+
 def e2e_mode(a):
     """BASELINE.md section 3's end-to-end picture (`--e2e`): what a user's `VC.vc_multi` / `vc_single` costs per 10 s clip once the hot
     path is the HIP one -- `Pipeline.convert_files` (bound by `rvc_amd.install()` on the RVC-shaped skeleton of tests/skeleton) with the
@@ -572,6 +587,13 @@ def e2e_mode(a):
 
     dev = torch.device("cuda", 0)
     half = a.operand != "fp32"
+    # torch sizes its CPU thread pool by the HOST's cores (128 on the GPU box) while the container's CFS quota is 16 CPUs: once the GRU is off the
+    # critical path the conversion is host-bound, the OpenMP workers of any small CPU op spin after it, the cgroup's 100 ms quota is gone in ~20 ms and
+    # the whole process is throttled for the rest of the period (measured: 70-85 ms stalls at random places, even inside scipy's filtfilt; 98 ms per
+    # clip instead of 17).  A deployment inside a CPU quota sets OMP_NUM_THREADS to it; so does this mode.
+    quota, host_threads = _cpu_quota(), torch.get_num_threads()
+    if quota and host_threads > max(1, quota // 2):
+        torch.set_num_threads(max(1, quota // 2))
     rvc_amd.install(device=dev, operand=a.operand)
     import infer.modules.vc.pipeline as pl
     import rvc.synthesizer as rs
@@ -634,45 +656,60 @@ def e2e_mode(a):
     def convert(audios):
         return pipe.convert_files(hub, net_g, 0, [x.copy() for x in audios], [0, 0, 0], *tail)
 
-    cases = {}
-    for n, warm, reps in ((1, 3, 7), (a.e2e_files, 1, 3)):
-        audios = [synth.make_audio16k(160000, 1234 + i) for i in range(n)]
-        for _ in range(warm):
-            out = convert(audios)
-        torch.cuda.synchronize()
-        walls = []
-        for _ in range(reps):
+    def run_cases(gru_hip):
+        # (the RMVPE proxy's bidirectional GRU on torch / MIOpen -- the north star's "RMVPE on PyTorch-ROCm" taken literally -- or on csrc/gru.hip,
+        #  what rvc_amd.install() does by default: pipeline._rmvpe_on_device -> accelerate_rmvpe; RVCMI_RMVPE_GRU=0 opts out)
+        os.environ["RVCMI_RMVPE_GRU"] = "1" if gru_hip else "0"
+        pipe.f0_gen = types.SimpleNamespace(rmvpe=RmvpeProxy(dev, half=half), is_half=half, device=dev)
+        cases = {}
+        for n, warm, reps in ((1, 3, 7), (a.e2e_files, 1, 3)):
+            audios = [synth.make_audio16k(160000, 1234 + i) for i in range(n)]
+            for _ in range(warm):
+                out = convert(audios)
+            torch.cuda.synchronize()
+            walls = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = convert(audios)
+                torch.cuda.synchronize()
+                walls.append(time.perf_counter() - t0)
+            assert len(out) == n and all(np.isfinite(o).all() and o.shape[0] == 479040 for o in out), [o.shape for o in out]
+            walls.sort()
+            wall = walls[len(walls) // 2]
+            instrument(True)
+            acc.clear()
+            sub.clear()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = convert(audios)
+            convert(audios)
             torch.cuda.synchronize()
-            walls.append(time.perf_counter() - t0)
-        assert len(out) == n and all(np.isfinite(o).all() and o.shape[0] == 479040 for o in out), [o.shape for o in out]
-        walls.sort()
-        wall = walls[len(walls) // 2]
-        instrument(True)
-        acc.clear()
-        sub.clear()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        convert(audios)
-        torch.cuda.synchronize()
-        tot = time.perf_counter() - t0
-        instrument(False)
-        split = {k: round(1e3 * v / n, 3) for k, v in acc.items()}
-        split["other_host_pad_slice_python"] = round(1e3 * (tot - sum(acc.values())) / n, 3)
-        feeders = split["hubert_proxy"] + split["rmvpe_proxy_mel_net_decode"]
-        host = split["highpass_filtfilt_host"] + split["cut_points_host"] + split["other_host_pad_slice_python"] + split["index_read_file_h2d"]
-        hot = split["retrieval_blend"] + split["infer_front_generator"]
-        cases["files_%d" % n] = {"files": n, "wall_ms_per_clip": round(1e3 * wall / n, 3), "rtf": CLIP_SECONDS * n / wall, "runs": reps,
-                                 "wall_ms_per_clip_min_max": [round(1e3 * walls[0] / n, 3), round(1e3 * walls[-1] / n, 3)],
-                                 "instrumented_total_ms_per_clip": round(1e3 * tot / n, 3), "split_ms_per_clip": split,
-                                 "groups_ms_per_clip": {"feeders_pytorch_rocm_proxies": round(feeders, 3), "host": round(host, 3),
-                                                        "hip_hot_path_retrieval_infer": round(hot, 3), "finish": split["finish_rms_scale_d2h"]},
-                                 "rmvpe_proxy_parts_ms_per_clip": {"mel_stft": round(1e3 * sub.get("mel_stft", 0.0) / n, 3),
-                                                                   "bigru_384_256_bidirectional": round(1e3 * sub.get("bigru", 0.0) / n, 3),
-                                                                   "unet_head_linear_decode": round(split["rmvpe_proxy_mel_net_decode"] - 1e3 * (sub.get("mel_stft", 0.0) + sub.get("bigru", 0.0)) / n, 3)},
-                                 "long_pole": max(split, key=split.get)}
+            tot = time.perf_counter() - t0
+            instrument(False)
+            split = {k: round(1e3 * v / n, 3) for k, v in acc.items()}
+            split["other_host_pad_slice_python"] = round(1e3 * (tot - sum(acc.values())) / n, 3)
+            feeders = split["hubert_proxy"] + split["rmvpe_proxy_mel_net_decode"]
+            host = split["highpass_filtfilt_host"] + split["cut_points_host"] + split["other_host_pad_slice_python"] + split["index_read_file_h2d"]
+            hot = split["retrieval_blend"] + split["infer_front_generator"]
+            cases["files_%d" % n] = {"files": n, "wall_ms_per_clip": round(1e3 * wall / n, 3), "rtf": CLIP_SECONDS * n / wall, "runs": reps,
+                                     "wall_ms_per_clip_min_max": [round(1e3 * walls[0] / n, 3), round(1e3 * walls[-1] / n, 3)],
+                                     "instrumented_total_ms_per_clip": round(1e3 * tot / n, 3), "split_ms_per_clip": split,
+                                     "groups_ms_per_clip": {"feeders_pytorch_rocm_proxies": round(feeders, 3), "host": round(host, 3),
+                                                            "hip_hot_path_retrieval_infer": round(hot, 3), "finish": split["finish_rms_scale_d2h"]},
+                                     "rmvpe_proxy_parts_ms_per_clip": {"mel_stft": round(1e3 * sub.get("mel_stft", 0.0) / n, 3),
+                                                                       "bigru_384_256_bidirectional": round(1e3 * sub.get("bigru", 0.0) / n, 3),
+                                                                       "unet_head_linear_decode": round(split["rmvpe_proxy_mel_net_decode"] - 1e3 * (sub.get("mel_stft", 0.0) + sub.get("bigru", 0.0)) / n, 3)},
+                                     "rmvpe_gru": "csrc/gru.hip (%d module swapped)" % getattr(pipe.f0_gen.rmvpe, "_rvcmi_gru", 0) if gru_hip else "torch nn.GRU (MIOpen)",
+                                     "long_pole": max(split, key=split.get)}
+        return cases
+
+    env0 = os.environ.get("RVCMI_RMVPE_GRU")
+    cases_torch = run_cases(False)
+    cases = run_cases(True)
+    if env0 is None:
+        os.environ.pop("RVCMI_RMVPE_GRU", None)
+    else:
+        os.environ["RVCMI_RMVPE_GRU"] = env0
     rvc_amd.uninstall()
     import shutil
 
@@ -685,6 +722,8 @@ def e2e_mode(a):
             "config": {"workload": "Pipeline.convert_files via rvc_amd.install() on tests/skeleton: WebUI defaults (rmvpe, index file %dx768 index_rate %.2f, "
                                    "rms_mix_rate 0.25, protect 0.33, x_pad 1), 10 s / 16 kHz inputs -> 48 kHz" % (a.index_n, a.index_rate)},
             "cases": cases,
+            "cases_with_torch_gru": cases_torch,
+            "host": {"cpu_quota": quota, "torch_threads_default": host_threads, "torch_threads_used": torch.get_num_threads()},
             "reading": "hot path (retrieval + net_g.infer) vs everything around it: see groups_ms_per_clip; the split pass synchronises around every "
                        "stage, the wall figures do not"}
 

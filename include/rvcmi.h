@@ -354,6 +354,20 @@ int rvcmi_glue_sola(const float* infer_wav_dev, int64_t n, float* sola_buffer_de
 int rvcmi_glue_resample_poly(const float* x_dev, int64_t n, const float* kernel_dev, int orig, int new_, int K, int width,
                              float* out_dev, int64_t n_out, void* stream);
 
+/* ---- beyond SURVEY.md section 8: the recurrent layer of the RMVPE f0 network -----------------------------------------------
+ * Stands in for the `nn.GRU(384, 256, num_layers=1, batch_first=True, bidirectional=True)` of rvc/f0/e2e.py:50-67 (E2E.BiGRU, the
+ * first module of E2E.fc), which bench.py --e2e measured at 75-90 % of a whole conversion on PyTorch-ROCm / MIOpen.
+ * Weights in torch's layout and gate order (r, z, n), forward direction first: w_ih [2][3H][I], w_hh [2][3H][H], b_ih / b_hh [2][3H],
+ * fp32 on the host.  hidden_size must be 256, input_size a multiple of 16 (anything else: RVCMI_ERR_INVALID, the caller keeps torch's).
+ * Operands fp16 (x, W_ih, W_hh and the broadcast copy of h), accumulation / gates / state fp32.                                  */
+typedef struct rvcmi_gru rvcmi_gru;
+int rvcmi_gru_create(int input_size, int hidden_size, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                     int device, rvcmi_gru** out);
+int rvcmi_gru_destroy(rvcmi_gru* h);
+/* x16_dev [B][T][I] fp16; y_dev [B][T][2H] fp32 = nn.GRU's `output` with h_0 = 0; hn_dev [2][B][H] fp32 = its `h_n` (or NULL).
+ * The projection workspace grows with the largest B * T seen (a hipMalloc on such a call: not for use inside a stream capture). */
+int rvcmi_gru_forward(rvcmi_gru* h, int B, int T, const void* x16_dev, float* y_dev, float* hn_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ from .front import FrontHIP, front_config_from_reference, infer_hip
 from .nsf import GeneratorHIP, NSFGeneratorHIP, config_from_reference
 from .pipeline import retrieve_blend
 from . import glue
+from .gru import GRUHIP, accelerate_rmvpe
 from .synthesizer import accelerate_synthesizer, get_synthesizer, load_synthesizer
 from . import dist
 from .install import install, uninstall
@@ -17,5 +18,5 @@ from .realtime import PitchCache, RealtimeVC, SincResample, f0_extractor_frame, 
 
 __all__ = [
     "RvcmiError", "build", "IVFFlatHIP", "read_index", "write_index", "train_index", "reduce_features", "kmeans", "GeneratorHIP", "NSFGeneratorHIP",
-    "config_from_reference", "FrontHIP", "front_config_from_reference", "infer_hip", "retrieve_blend", "accelerate_synthesizer", "get_synthesizer", "load_synthesizer", "dist", "glue", "install", "uninstall", "RealtimeVC", "PitchCache", "f0_extractor_frame", "SincResample", "sinc_resample_kernel",
+    "config_from_reference", "FrontHIP", "front_config_from_reference", "infer_hip", "retrieve_blend", "accelerate_synthesizer", "get_synthesizer", "load_synthesizer", "dist", "glue", "install", "uninstall", "RealtimeVC", "PitchCache", "f0_extractor_frame", "SincResample", "sinc_resample_kernel", "GRUHIP", "accelerate_rmvpe",
 ]

@@ -14,7 +14,7 @@ from typing import List
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RVCMI_LIB") or os.path.join(_HERE, "librvcmi.so")  # RVCMI_LIB: dev A/B builds
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["nsf.hip", "rb_stream.hip", "ivf.hip", "front.hip", "glue.hip"]
+SOURCES = ["nsf.hip", "rb_stream.hip", "ivf.hip", "front.hip", "glue.hip", "gru.hip"]
 
 RVCMI_MAX_UPS, RVCMI_MAX_RB, RVCMI_MAX_DIL = 8, 4, 4
 RVCMI_VERSION = 2  # include/rvcmi.h; the argument lists of SYMBOLS below are those of this ABI version
@@ -109,6 +109,9 @@ SYMBOLS = [
     ("rvcmi_glue_scale_int16_range", C.c_int, [_P, C.c_int64, _P, _P]),
     ("rvcmi_glue_resample_poly", C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int64, _P]),
     ("rvcmi_glue_sola", C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P]),
+    ("rvcmi_gru_create", C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.POINTER(_P)]),
+    ("rvcmi_gru_destroy", C.c_int, [_P]),
+    ("rvcmi_gru_forward", C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
 ]
 
 
