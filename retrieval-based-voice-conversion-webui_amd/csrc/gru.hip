@@ -8,7 +8,7 @@
 //   k_gru_seq     the recurrence: ONE persistent block per (direction, sequence), the 768 x 256 recurrent matrix resident in the block's
 //                 REGISTERS as fp16 pairs (768 threads x 128 VGPRs = 393 KB of the CU's 512 KB register file), h broadcast through LDS
 //                 as fp16, fp32 accumulation (v_dot2_f32_f16), fp32 state and gates.  A step is a 1.5 k-cycle dot-product phase, an
-//                 8-lane transposing reduction, two LDS barriers: ~1 us, i.e. ~1.3 ms per 1200-frame clip and direction.
+//                 8-lane transposing reduction by DPP, two LDS barriers: ~1 us, i.e. ~1.3 ms per 1200-frame clip and direction.
 //
 // PyTorch's GRU cell (torch.nn.GRU docs; gate order r, z, n in the stacked weights):
 //   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr)      z = sigmoid(W_iz x + b_iz + W_hz h + b_hz)
@@ -56,8 +56,24 @@ static __global__ void __launch_bounds__(256) k_gru_xproj(const _Float16* __rest
     }
 }
 
-__device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + __expf(-v)); }
-__device__ __forceinline__ float tanh_f(float v) { return 2.f / (1.f + __expf(-2.f * v)) - 1.f; }
+// (v_rcp_f32, 1 ulp, instead of the IEEE division sequence: the gate chain is serial latency between the two barriers of a step)
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float tanh_f(float v) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * v)) - 1.f; }
+
+// value of lane (l ^ 1), (l ^ 2), (l ^ 4) by DPP (a VALU move, no trip through the LDS crossbar like ds_bpermute): quad permutes for 1 and 2;
+// for 4 the two row shifts, each written only to the banks (groups of 4 lanes) it is valid for
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+}
+__device__ __forceinline__ float lane_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2, 3, 0, 1]
+}
+__device__ __forceinline__ float lane_xor4(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    int r = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xF, 0x5, false);  // row_shl:4 -> banks 0, 2 (lanes with bit 2 clear read lane + 4)
+    r = __builtin_amdgcn_update_dpp(r, x, 0x114, 0xF, 0xA, false);      // row_shr:4 -> banks 1, 3 (lanes with bit 2 set read lane - 4)
+    return __builtin_bit_cast(float, r);
+}
 
 // grid (2 directions, B sequences).  whh: fp16 pairs packed [dir][thread][8 rows][16 pairs]; gx [dir][B * T][GR]; bhn [dir][GH];
 // y [B][T][2 * GH] fp32; hn [2][B][GH] fp32 (final states, may be null)
@@ -120,7 +136,7 @@ static __global__ void __launch_bounds__(GNT) k_gru_seq(const half2v* __restrict
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float keep = up ? a[4 + i] : a[i], send = up ? a[i] : a[4 + i];
-                    c4[i] = keep + __shfl_xor(send, 4, 64);
+                    c4[i] = keep + lane_xor4(send);
                 }
             }
             {
@@ -128,13 +144,13 @@ static __global__ void __launch_bounds__(GNT) k_gru_seq(const half2v* __restrict
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const float keep = up ? c4[2 + i] : c4[i], send = up ? c4[i] : c4[2 + i];
-                    c2[i] = keep + __shfl_xor(send, 2, 64);
+                    c2[i] = keep + lane_xor2(send);
                 }
             }
             {
                 const bool up = ks & 1;
                 const float keep = up ? c2[1] : c2[0], send = up ? c2[0] : c2[1];
-                c1 = keep + __shfl_xor(send, 1, 64);
+                c1 = keep + lane_xor1(send);
             }
             gh[tid] = c1;  // (thread tid = 8 * group + ks holds row 8 * group + ks)
             __syncthreads();
