@@ -91,3 +91,22 @@ def accelerate_rmvpe(model: torch.nn.Module) -> int:
                 setattr(parent, name, GRUHIP(child))
                 n += 1
     return n
+
+
+def accelerate_f0_rmvpe(rmvpe) -> int:
+    """What the rebound ``Pipeline.pipeline`` / ``RVC.infer`` do with the ``RMVPE`` object (rvc/f0/rmvpe.py) of their f0 generator, once:
+    ``accelerate_rmvpe(rmvpe.model)`` unless ``RVCMI_RMVPE_GRU=0``.  The count is remembered on the object (``_rvcmi_gru``)."""
+    import os
+
+    n = getattr(rmvpe, "_rvcmi_gru", None)
+    if n is None:
+        n = 0
+        net = getattr(rmvpe, "model", None)
+        if os.environ.get("RVCMI_RMVPE_GRU", "1") != "0" and isinstance(net, torch.nn.Module):
+            n = accelerate_rmvpe(net)
+        try:
+            rmvpe._rvcmi_gru = n
+        except Exception:  # noqa  (an object without a __dict__: try again next time)
+            pass
+    return n
+

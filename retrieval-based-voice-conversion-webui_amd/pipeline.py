@@ -273,17 +273,11 @@ def _rmvpe_on_device(self, audio_pad, p_len, f0_up_key):
     r = gen.rmvpe
     if not (hasattr(r, "mel_extractor") and hasattr(r, "_mel2hidden")) or "privateuseone" in str(getattr(r, "device", "")):
         return None
-    if not hasattr(r, "_rvcmi_gru"):
-        # (beyond SURVEY.md section 8) the network's bidirectional GRU -- 75-90 % of a conversion as MIOpen runs it, bench.py --e2e -- on the
-        # persistent HIP kernel; everything else of RMVPE stays on PyTorch-ROCm.  RVCMI_RMVPE_GRU=0 keeps torch's GRU.
-        import os
+    # (beyond SURVEY.md section 8) the network's bidirectional GRU -- 75-90 % of a conversion as MIOpen runs it, bench.py --e2e -- on the
+    # persistent HIP kernel, once per RMVPE object; everything else of RMVPE stays on PyTorch-ROCm.  RVCMI_RMVPE_GRU=0 keeps torch's GRU.
+    from .gru import accelerate_f0_rmvpe
 
-        r._rvcmi_gru = 0
-        net = getattr(r, "model", None)
-        if os.environ.get("RVCMI_RMVPE_GRU", "1") != "0" and isinstance(net, torch.nn.Module):
-            from .gru import accelerate_rmvpe
-
-            r._rvcmi_gru = accelerate_rmvpe(net)
+    accelerate_f0_rmvpe(r)
     wav = torch.as_tensor(audio_pad)
     with torch.no_grad():
         mel = r.mel_extractor(wav.float().to(r.device).unsqueeze(0), center=True)

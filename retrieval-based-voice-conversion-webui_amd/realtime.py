@@ -203,5 +203,10 @@ def rvc_infer_hip(self, input_wav: torch.Tensor, block_frame_16k, skip_head, ret
     pitch = pitchf = None
     if self.if_f0 == 1:                                             # rtrvc.py:203-212
         n = f0_extractor_frame(block_frame_16k, f0method, self.window)
+        if f0method == "rmvpe" and getattr(getattr(self, "f0_gen", None), "rmvpe", None) is not None:
+            # (beyond SURVEY 8) the f0 network's GRU on the HIP kernel, once the generator has loaded it: ~6 ms -> 0.1 ms of every chunk
+            from .gru import accelerate_f0_rmvpe
+
+            accelerate_f0_rmvpe(self.f0_gen.rmvpe)
         pitch, pitchf = self._get_f0(input_wav[-n:], self.f0_up_key - self.formant_shift, method=f0method)
     return rt.infer(feats, int(input_wav.shape[0]), block_frame_16k, skip_head, return_length, pitch=pitch, pitchf=pitchf, protect=protect)

@@ -120,3 +120,20 @@ def test_rebound_pipeline_swaps_the_gru_once_and_honours_the_opt_out(gpu, monkey
         assert pitch.shape[-1] == p_len and pitchf.shape[-1] == p_len and torch.isfinite(pitchf).all()
         rp._rmvpe_on_device(me, audio, p_len, 0)  # (second call: nothing left to swap)
         assert r._rvcmi_gru == want
+
+
+def test_accelerate_f0_rmvpe_is_idempotent_and_tolerates_foreign_objects(gpu, monkeypatch):
+    """The helper both rebound callers use (``Pipeline.pipeline`` and the realtime ``RVC.infer``): swaps once, remembers the count, leaves an
+    object without a torch network alone."""
+    import types
+
+    from rvc_amd.gru import accelerate_f0_rmvpe
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from e2e_proxies import RmvpeProxy
+
+    monkeypatch.delenv("RVCMI_RMVPE_GRU", raising=False)
+    r = RmvpeProxy(gpu, half=False)
+    assert accelerate_f0_rmvpe(r) == 1 and accelerate_f0_rmvpe(r) == 1 and r._rvcmi_gru == 1
+    onnx_like = types.SimpleNamespace(model=object())
+    assert accelerate_f0_rmvpe(onnx_like) == 0 and onnx_like._rvcmi_gru == 0
