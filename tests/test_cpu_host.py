@@ -619,6 +619,13 @@ def test_e2e_rmvpe_proxy_has_the_reference_architecture():
             fl.append(fc.get_total_flops())
             assert y.shape == (1, 64, 360) and float(y.min()) > 0 and float(y.max()) < 1
         assert fl[0] == fl[1]
+        # the one layer that runs on csrc/gru.hip: the reference's own E2E holds it where accelerate_rmvpe looks (fc[0].gru), in a shape GRUHIP
+        # supports; on a CPU model nothing is swapped
+        from rvc_amd.gru import accelerate_rmvpe, supports
+
+        g = theirs.fc[0].gru
+        assert supports(g) and (g.input_size, g.hidden_size) == (384, 256) and supports(ours.gru)
+        assert accelerate_rmvpe(theirs) == 0 and theirs.fc[0].gru is g
     finally:
         sys.path.remove(ref)
         sys.path.remove(os.path.join(ROOT, "tools"))
