@@ -725,7 +725,8 @@ def e2e_mode(a):
             "cases_with_torch_gru": cases_torch,
             "host": {"cpu_quota": quota, "torch_threads_default": host_threads, "torch_threads_used": torch.get_num_threads()},
             "reading": "hot path (retrieval + net_g.infer) vs everything around it: see groups_ms_per_clip; the split pass synchronises around every "
-                       "stage, the wall figures do not"}
+                       "stage, the wall figures do not.  `cases` / `value` = what rvc_amd.install() runs by default (RMVPE's GRU on csrc/gru.hip, the rest of "
+                       "RMVPE and HuBERT on PyTorch-ROCm); `cases_with_torch_gru` = the north star's 'RMVPE on PyTorch-ROCm' taken literally (RVCMI_RMVPE_GRU=0)"}
 
 
 _REAL_STDOUT = None
