@@ -204,7 +204,8 @@ def rvc_infer_hip(self, input_wav: torch.Tensor, block_frame_16k, skip_head, ret
     if self.if_f0 == 1:                                             # rtrvc.py:203-212
         n = f0_extractor_frame(block_frame_16k, f0method, self.window)
         if f0method == "rmvpe" and getattr(getattr(self, "f0_gen", None), "rmvpe", None) is not None:
-            # (beyond SURVEY 8) the f0 network's GRU on the HIP kernel, once the generator has loaded it: ~6 ms -> 0.1 ms of every chunk
+            # (beyond SURVEY 8) the f0 network's GRU on the HIP kernel, once the generator has loaded it: 3.7 / 7.2 ms -> 0.06 / 0.10 ms of every
+            # chunk for its 32- / 64-frame window (tools/gru_time.py)
             from .gru import accelerate_f0_rmvpe
 
             accelerate_f0_rmvpe(self.f0_gen.rmvpe)
