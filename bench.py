@@ -330,7 +330,7 @@ def _time_chunks(fn, n=300, warm=30, graph=True):
     return _percentiles(lat), captured
 
 
-def stream_mode(a, chunks=300, warm=30, index=None, breakdown=True):
+def stream_mode(a, chunks=300, warm=30, index=None, breakdown=True, feeders=False):
     """Realtime chunk latency (gui.py geometry): block 0.256 s -> decoder T=31 frames
     (n_res = 31, no formant shift), retrieval on the last 16 HuBERT frames; v1/40k generator, 768-d index.
     p50 / p90 / p99 over `chunks` chunks after `warm` warm-ups (--stream: 300 / 30; the `stream` object of the default line: 200 / 20,
@@ -417,6 +417,51 @@ def stream_mode(a, chunks=300, warm=30, index=None, breakdown=True):
         if breakdown:
             st2 = dict(st2, kernels_us_per_chunk=kernel_breakdown(whole, [index, front, gen]))
         line["whole_chunk"] = dict(st2, what="retrieval (16 rows, guarded) + x2 + protect + enc_p(282) + flow(56) + decode(31) + SOLA", hipgraph=cap2)
+        if feeders:
+            # (--stream only) what the realtime loop runs AHEAD of that per block, as architecture proxies on PyTorch-ROCm (tools/e2e_proxies.py, eager): HuBERT
+            # on the 2.82 s rolling window (rtrvc.py:142-162) and RMVPE on its f0 window (rtrvc.py:203-207: 4960 samples for a 4096-sample block) incl. the
+            # salience decode -- with the network's GRU on torch / MIOpen and on csrc/gru.hip (what the rebound RVC.infer does, realtime.rvc_infer_hip)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from e2e_proxies import HubertProxy, RmvpeProxy
+            from rvc_amd.gru import accelerate_f0_rmvpe
+            from rvc_amd.realtime import f0_extractor_frame
+
+            half = True
+            hubp = HubertProxy(dev, half=half)
+            win = torch.randn(1, 45120, device=dev).half()
+            nf0 = f0_extractor_frame(4096, "rmvpe", 160)
+            wav_f0 = torch.randn(1, nf0, device=dev)
+            fd = {}
+            for label in ("torch_gru", "hip_gru"):
+                rm = RmvpeProxy(dev, half=half)
+                if label == "hip_gru":
+                    accelerate_f0_rmvpe(rm)
+
+                def feed():
+                    with torch.no_grad():
+                        hubp.extract_features(win, None, 9)
+                        hid = rm._mel2hidden(rm.mel_extractor(wav_f0, center=True))
+                    return rvc_amd.glue.rmvpe_f0(hid.squeeze(0).float(), int(hid.shape[1]), 0, 0.03)
+
+                def hubert_only():
+                    with torch.no_grad():
+                        hubp.extract_features(win, None, 9)
+
+                run_whole = whole
+                if cap2:
+                    gw_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gw_):
+                        whole()
+                    run_whole = gw_.replay
+
+                def chunk():
+                    feed()
+                    run_whole()
+
+                stf, _ = _time_chunks(chunk, n=min(chunks, 100), warm=10, graph=False)
+                sth, _ = _time_chunks(hubert_only, n=50, warm=5, graph=False)
+                fd[label] = dict(stf, hubert_proxy_p50_ms=sth["p50_ms"], rmvpe_proxy_p50_ms=round(stf["p50_ms"] - sth["p50_ms"] - st2["p50_ms"], 4))
+            line["chunk_with_feeders"] = dict(fd, what="HuBERT proxy (45120 samples) + RMVPE proxy (%d samples -> 32 frames) + salience decode, eager, then the whole chunk above" % nf0)
     return line
 
 
@@ -769,7 +814,7 @@ def main():
         _REAL_STDOUT = os.fdopen(os.dup(1), "w")
         os.dup2(2, 1)
     if a.stream:
-        return emit(stream_mode(a))
+        return emit(stream_mode(a, feeders=True))
     if a.e2e:
         return emit(e2e_mode(a))
     if a.dist_selftest:

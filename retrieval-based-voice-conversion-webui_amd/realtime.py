@@ -203,11 +203,23 @@ def rvc_infer_hip(self, input_wav: torch.Tensor, block_frame_16k, skip_head, ret
     pitch = pitchf = None
     if self.if_f0 == 1:                                             # rtrvc.py:203-212
         n = f0_extractor_frame(block_frame_16k, f0method, self.window)
-        if f0method == "rmvpe" and getattr(getattr(self, "f0_gen", None), "rmvpe", None) is not None:
-            # (beyond SURVEY 8) the f0 network's GRU on the HIP kernel, once the generator has loaded it: 3.7 / 7.2 ms -> 0.06 / 0.10 ms of every
-            # chunk for its 32- / 64-frame window (tools/gru_time.py)
-            from .gru import accelerate_f0_rmvpe
+        key = self.f0_up_key - self.formant_shift
+        got = None
+        if f0method == "rmvpe" and float(key).is_integer() and getattr(self, "f0_gen", None) is not None:
+            # RMVPE stays on the device from the waveform to (pitch, pitchf): the reference's Generator.calculate (rvc/f0/gen.py:58-59, 103-113) copies
+            # the window to the host, the salience back, and decodes it in numpy with a python loop over frames; pipeline._rmvpe_on_device is the same
+            # chain (mel, network, rvcmi_glue_rmvpe_f0 = _decode + _resize_f0 + _interpolate_f0 + post_process, golden-tested against the reference's)
+            # without a host hop, and swaps the network's GRU for the HIP one (3.7 / 7.2 ms -> 0.06 / 0.10 ms for a 32- / 64-frame window,
+            # tools/gru_time.py).  The integer key is the C ABI's; a fractional key (formant slider) takes the reference's own method below.
+            from .pipeline import _rmvpe_on_device
 
-            accelerate_f0_rmvpe(self.f0_gen.rmvpe)
-        pitch, pitchf = self._get_f0(input_wav[-n:], self.f0_up_key - self.formant_shift, method=f0method)
+            got = _rmvpe_on_device(self, input_wav[-n:], int(input_wav[-n:].shape[0]) // self.window, int(key))
+        if got is not None:
+            pitch, pitchf = got[0][0], got[1][0]
+        else:
+            if f0method == "rmvpe" and getattr(getattr(self, "f0_gen", None), "rmvpe", None) is not None:
+                from .gru import accelerate_f0_rmvpe
+
+                accelerate_f0_rmvpe(self.f0_gen.rmvpe)   # (beyond SURVEY 8) at least the network's GRU, once the generator has loaded it
+            pitch, pitchf = self._get_f0(input_wav[-n:], key, method=f0method)
     return rt.infer(feats, int(input_wav.shape[0]), block_frame_16k, skip_head, return_length, pitch=pitch, pitchf=pitchf, protect=protect)

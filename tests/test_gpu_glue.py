@@ -263,3 +263,51 @@ def test_change_rms_matches_the_pipeline_expression(rate, gpu):
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
     assert np.allclose(got, ref, rtol=2e-6, atol=1e-9), "max rel %.2e" % np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-9))
+
+
+def test_realtime_entry_keeps_rmvpe_f0_on_the_device(gpu):
+    """``rvc_infer_hip`` (the rebound ``RVC.infer``, rtrvc.py:134-260) with f0method "rmvpe": the f0 window goes waveform -> mel -> network ->
+    ``rvcmi_glue_rmvpe_f0`` on the device (what the estimator's host path -- ``_get_f0``, which fails this test if called -- computes, see the
+    golden test of the decode chain above); a fractional key (formant slider) takes the reference's own method."""
+    import types
+
+    from rvc_amd import glue
+    from rvc_amd.realtime import f0_extractor_frame, rvc_infer_hip
+
+    seen, host_calls = {}, []
+
+    class Net:
+        def infer(self, phone, lengths, sid, pitch=None, pitchf=None, skip_head=None, return_length=None, return_length2=None):
+            seen.update(pitch=pitch.cpu(), pitchf=pitchf.cpu())
+            n = (return_length2 or return_length) * 480
+            return torch.zeros(1, 1, n, device=phone.device)
+
+    block16k, win = 4096, 160
+    n_in = 160 * 118
+    fake = synth.FakeRMVPE(gpu, 77)
+
+    def host_f0(x, key, method="rmvpe"):
+        host_calls.append(float(key))
+        m = int(x.shape[0]) // win
+        pf = synth.make_f0(1, m)[0]
+        return synth.make_pitch(pf[None])[0].to(gpu), pf.to(gpu)
+
+    me = types.SimpleNamespace(index=None, net_g=Net(), index_rate=0.0, device=gpu, if_f0=1, tgt_sr=48000, f0_up_key=2, formant_shift=0, window=win,
+                               is_half=False, version="v2", hubert=synth.FakeHubert(768, 5), f0_gen=types.SimpleNamespace(rmvpe=fake, is_half=False, device=gpu),
+                               _get_f0=host_f0)
+    wav_in = torch.from_numpy(synth.make_audio16k(n_in, 3)).to(gpu)
+    out = rvc_infer_hip(me, wav_in, block16k, 40, 25, "rmvpe", 1.0)
+    assert out.shape == (25 * 480,) and host_calls == [] and fake.model.calls == 1
+    n = f0_extractor_frame(block16k, "rmvpe", win)
+    m = n // win
+    with torch.no_grad():
+        hid = fake._mel2hidden(fake.mel_extractor(wav_in[-n:].unsqueeze(0), center=True))
+    pitch, pitchf = glue.rmvpe_f0(hid.squeeze(0).float(), m, 2, 0.03)
+    p_len = n_in // win
+    # the cache window the decoder saw ends with the estimator's frames 3 .. m - 2 (rtrvc.py:213-217)
+    assert torch.equal(seen["pitch"][0, p_len - (m - 4):], pitch[0, 3:-1].cpu())
+    assert torch.allclose(seen["pitchf"][0, p_len - (m - 4):], pitchf[0, 3:-1].cpu(), rtol=1e-6, atol=0)  # ((x * rl2) / rl on the device, rtrvc.py:218-219)
+    assert float(pitchf.max()) > 0
+    me.formant_shift = 0.5  # key 1.5: not the C ABI's integer -> the object's own _get_f0
+    rvc_infer_hip(me, wav_in, block16k, 40, 25, "rmvpe", 1.0)
+    assert host_calls == [1.5]
