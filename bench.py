@@ -432,14 +432,21 @@ def stream_mode(a, chunks=300, warm=30, index=None, breakdown=True, feeders=Fals
             nf0 = f0_extractor_frame(4096, "rmvpe", 160)
             wav_f0 = torch.randn(1, nf0, device=dev)
             fd = {}
-            for label in ("torch_gru", "hip_gru"):
+            import types
+
+            from rvc_amd.realtime import _rmvpe_f0_graphed
+
+            for label in ("torch_gru", "hip_gru", "hip_gru_f0_graph"):
                 rm = RmvpeProxy(dev, half=half)
-                if label == "hip_gru":
+                if label != "torch_gru":
                     accelerate_f0_rmvpe(rm)
+                holder = types.SimpleNamespace(f0_gen=types.SimpleNamespace(rmvpe=rm, is_half=half, device=dev))
 
                 def feed():
                     with torch.no_grad():
                         hubp.extract_features(win, None, 9)
+                        if label == "hip_gru_f0_graph":  # what realtime.rvc_infer_hip does: the f0 chain replayed from a hipGraph after 3 eager blocks
+                            return _rmvpe_f0_graphed(holder, wav_f0[0], nf0 // 160, 0)
                         hid = rm._mel2hidden(rm.mel_extractor(wav_f0, center=True))
                     return rvc_amd.glue.rmvpe_f0(hid.squeeze(0).float(), int(hid.shape[1]), 0, 0.03)
 

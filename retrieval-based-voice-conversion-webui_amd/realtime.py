@@ -172,6 +172,50 @@ class RealtimeVC:
         return audio.squeeze()
 
 
+RT_GRAPH_AFTER = 3  # eager calls of one (window length, key) before its f0 chain is captured (MIOpen / rocFFT pick their algorithms and plans first)
+
+
+def _rmvpe_f0_graphed(self, wav: torch.Tensor, p_len: int, key: int):
+    """``pipeline._rmvpe_on_device`` for the realtime loop, whose f0 window has the SAME length block after block (rtrvc.py:203-207): the chain
+    waveform -> mel -> RMVPE -> salience decode is ~400 launches for a 32-frame input -- 7 ms of host time eager, 90 M parameters of U-Net at a
+    tiny size -- so after ``RT_GRAPH_AFTER`` eager calls it is captured ONCE per (window length, key) into a hipGraph with a static input buffer
+    and replayed (the launch-bound inner loop the design captures everywhere else too).  Same kernels, same results.  ``RVCMI_RT_GRAPH=0``, a
+    capture that fails (an op that cannot be captured in this build), or a CPU / foreign estimator keep the eager call.  -> (pitch, pitchf)
+    [1, p_len] like ``_rmvpe_on_device`` (tensors the next replay overwrites: the caller copies them into its pitch cache at once), or None."""
+    import os
+
+    from .pipeline import _rmvpe_on_device
+
+    if os.environ.get("RVCMI_RT_GRAPH", "1") == "0" or not (torch.is_tensor(wav) and wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 1):
+        return _rmvpe_on_device(self, wav, p_len, key)
+    cache = self.__dict__.setdefault("_rvcmi_f0_graphs", {})
+    k = (int(wav.shape[0]), int(p_len), int(key), str(wav.device))
+    e = cache.setdefault(k, {"calls": 0})
+    if "graph" in e:
+        e["in"].copy_(wav)
+        e["graph"].replay()
+        return e["out"]
+    out = _rmvpe_on_device(self, wav, p_len, key)
+    e["calls"] += 1
+    if out is not None and e["calls"] == RT_GRAPH_AFTER:
+        try:
+            static_in = wav.clone()
+            torch.cuda.synchronize(wav.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                o = _rmvpe_on_device(self, static_in, p_len, key)
+            if o is None:
+                raise RuntimeError("no device f0 inside the capture")
+            e.update(graph=g, out=o)
+            e["in"] = static_in
+        except Exception as ex:  # noqa  (keeps the eager path; never tried again for this key)
+            import warnings
+
+            warnings.warn("rvc_amd: the realtime f0 chain could not be captured into a hipGraph (%s: %s); running it eager" % (type(ex).__name__, ex))
+            torch.cuda.synchronize(wav.device)
+    return out
+
+
 def rvc_infer_hip(self, input_wav: torch.Tensor, block_frame_16k, skip_head, return_length, f0method, protect: float = 1.0):
     """Drop-in ``RVC.infer`` (infer/lib/rtrvc.py:134-260; bound by ``rvc_amd.install()``): HuBERT and the f0 estimator are the
     object's own PyTorch modules, everything after them runs on the device through a ``RealtimeVC`` that lives on the object.
@@ -210,10 +254,10 @@ def rvc_infer_hip(self, input_wav: torch.Tensor, block_frame_16k, skip_head, ret
             # the window to the host, the salience back, and decodes it in numpy with a python loop over frames; pipeline._rmvpe_on_device is the same
             # chain (mel, network, rvcmi_glue_rmvpe_f0 = _decode + _resize_f0 + _interpolate_f0 + post_process, golden-tested against the reference's)
             # without a host hop, and swaps the network's GRU for the HIP one (3.7 / 7.2 ms -> 0.06 / 0.10 ms for a 32- / 64-frame window,
-            # tools/gru_time.py).  The integer key is the C ABI's; a fractional key (formant slider) takes the reference's own method below.
-            from .pipeline import _rmvpe_on_device
-
-            got = _rmvpe_on_device(self, input_wav[-n:], int(input_wav[-n:].shape[0]) // self.window, int(key))
+            # tools/gru_time.py), replayed from a hipGraph after the first blocks (_rmvpe_f0_graphed).  The integer key is the C ABI's; a fractional key (formant
+            # slider) takes the reference's own method below.
+            w_f0 = input_wav[-n:]
+            got = _rmvpe_f0_graphed(self, w_f0.contiguous() if torch.is_tensor(w_f0) else w_f0, int(w_f0.shape[0]) // self.window, int(key))
         if got is not None:
             pitch, pitchf = got[0][0], got[1][0]
         else:

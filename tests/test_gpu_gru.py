@@ -137,3 +137,61 @@ def test_accelerate_f0_rmvpe_is_idempotent_and_tolerates_foreign_objects(gpu, mo
     assert accelerate_f0_rmvpe(r) == 1 and accelerate_f0_rmvpe(r) == 1 and r._rvcmi_gru == 1
     onnx_like = types.SimpleNamespace(model=object())
     assert accelerate_f0_rmvpe(onnx_like) == 0 and onnx_like._rvcmi_gru == 0
+
+
+def test_realtime_f0_chain_replayed_from_a_hipgraph_equals_the_eager_chain(gpu, monkeypatch):
+    """``realtime._rmvpe_f0_graphed``: the fixed-length f0 window of the realtime loop (mel STFT -> the RMVPE architecture proxy incl. the HIP
+    GRU -> salience decode) is captured after three eager blocks and replayed; every replay must give what the eager chain gives for the same
+    waveform (same kernels; to the network's own run-to-run noise).  ``RVCMI_RT_GRAPH=0`` never captures."""
+    import types
+
+    import rvc_amd.pipeline as rp
+    from rvc_amd import realtime as rt
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from e2e_proxies import RmvpeProxy
+
+    monkeypatch.delenv("RVCMI_RMVPE_GRU", raising=False)
+    monkeypatch.delenv("RVCMI_RT_GRAPH", raising=False)
+    n = rt.f0_extractor_frame(4096, "rmvpe", 160)
+    p_len = n // 160
+    me = types.SimpleNamespace(f0_gen=types.SimpleNamespace(rmvpe=RmvpeProxy(gpu, half=True), is_half=True, device=gpu))
+    g = torch.Generator().manual_seed(1)
+    for i in range(7):
+        wav = (0.2 * torch.randn(n, generator=g)).to(gpu)
+        pitch, pitchf = rt._rmvpe_f0_graphed(me, wav, p_len, 0)
+        pitch, pitchf = pitch.clone(), pitchf.clone()
+        entry = next(iter(me._rvcmi_f0_graphs.values()))
+        assert ("graph" in entry) == (i >= rt.RT_GRAPH_AFTER - 1), (i, list(entry))
+        want = rp._rmvpe_on_device(me, wav, p_len, 0)
+        # (two EAGER runs of this network already differ in the last bits -- MIOpen's convolutions are not run-to-run deterministic -- so: to 1e-3)
+        assert pitch.shape == (1, p_len) and int((pitch - want[0]).abs().max()) <= 1, "block %d: coarse pitch differs" % i
+        assert torch.allclose(pitchf, want[1], rtol=1e-3, atol=0) and float(pitchf.max()) > 0, "block %d: replay differs from the eager chain" % i
+    assert len(me._rvcmi_f0_graphs) == 1
+
+    # the replay must follow its INPUT (the proxy's random weights make a nearly input-independent salience): the same mel front end in front of a
+    # parameter-free 'network' whose salience peak moves with the signal's level
+    class Tiny(torch.nn.Module):
+        def forward(self, mel):  # [1, 128, T] log-mel -> [1, T, 360]: a salience bump whose bin follows the frame's level
+            c = 180.0 + 25.0 * mel.float().mean(dim=1)
+            bins = torch.arange(360, device=mel.device, dtype=torch.float32)
+            return torch.exp(-0.5 * ((bins[None, None, :] - c[..., None]) / 3.0) ** 2).to(mel.dtype)
+
+    tiny = RmvpeProxy(gpu, half=False)
+    tiny.model = Tiny().to(gpu)
+    me3 = types.SimpleNamespace(f0_gen=types.SimpleNamespace(rmvpe=tiny, is_half=False, device=gpu))
+    outs = []
+    for i in range(6):
+        t = torch.arange(n, device=gpu) / 16000.0
+        wav = 0.05 * (i + 1) * torch.sin(2 * torch.pi * 220.0 * t)
+        pitch, pitchf = rt._rmvpe_f0_graphed(me3, wav, p_len, 0)
+        want = rp._rmvpe_on_device(me3, wav, p_len, 0)
+        assert torch.allclose(pitchf, want[1], rtol=1e-4, atol=0) and int((pitch - want[0]).abs().max()) <= 1, "tiny network, block %d" % i
+        outs.append(pitchf.clone())
+    assert "graph" in next(iter(me3._rvcmi_f0_graphs.values()))
+    assert not torch.allclose(outs[-1], outs[-2], rtol=1e-2), "two replays with different inputs gave the same f0: the static input is not read"
+    monkeypatch.setenv("RVCMI_RT_GRAPH", "0")
+    me2 = types.SimpleNamespace(f0_gen=types.SimpleNamespace(rmvpe=RmvpeProxy(gpu, half=True), is_half=True, device=gpu))
+    for i in range(5):
+        rt._rmvpe_f0_graphed(me2, wav, p_len, 0)
+    assert not getattr(me2, "_rvcmi_f0_graphs", None)
