@@ -11,6 +11,7 @@ python bench.py --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline -
 python bench.py --whole --batch 16 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-gpu-torch-baseline > gpurun_out/${TAG}_bench_whole_b16_T1198.json 2>/dev/null
 python bench.py --stream > gpurun_out/${TAG}_bench_stream_v1_40k.json 2>/dev/null
 python bench.py --e2e > gpurun_out/${TAG}_bench_e2e.json 2>gpurun_out/${TAG}_bench_e2e.err
+python tools/gru_time.py > gpurun_out/${TAG}_gru_time.txt 2>/dev/null   # GRUHIP vs torch nn.GRU (MIOpen) at the realtime and clip window sizes
 # the K loop's own ceiling on THIS chip, re-measured every round (bench.py parses the newest profiles/rNN_ubench_kloop2_issue_model.txt)
 [ -x tools/ubench/kloop2 ] && (cd tools/ubench && timeout 300 ./kloop2) > gpurun_out/${TAG}_ubench_kloop2_issue_model.txt 2>&1
 # the RCCL path at world size 1 (the one-GPU lease): configs[1] and configs[3] (64 clips, 1M x 256 index built on the GPU, ONE timed broadcast, agreement check)
