@@ -831,6 +831,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP hot path has no CPU fallback)")
+    # torch sizes its CPU pool by the host's cores, not by the container's CFS quota (128 threads on a 16-CPU quota here): N ranks of spinning OpenMP
+    # workers exhaust the quota and the kernel throttles the whole cgroup for the rest of each 100 ms period (see e2e_mode).  Cap the pool to this
+    # rank's share; the cpu_baseline leg sets its own thread counts.
+    quota = _cpu_quota()
+    if quota and torch.get_num_threads() > max(1, quota // max(1, world)):
+        torch.set_num_threads(max(1, quota // max(1, world)))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
