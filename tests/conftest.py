@@ -11,8 +11,27 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _cpu_quota():
+    """CPUs the cgroup lets this process use, None when unlimited / unknown (cgroup v2 cpu.max, v1 cfs quota)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(q) // int(per))
+    except Exception:  # noqa
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        return None if q <= 0 else max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))
+    except Exception:  # noqa
+        return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch sizes its CPU pool by the HOST's cores (128 threads on the GPU box, whose container has a 16-CPU CFS quota): the oracle legs then spin
+    # the quota away and the whole process is throttled for most of every 100 ms period (DESIGN.md 8.3).  The results do not depend on it.
+    quota = _cpu_quota()
+    if quota and torch.get_num_threads() > quota:
+        torch.set_num_threads(quota)
 
 
 def golden_names(prefix="dec_"):
