@@ -248,6 +248,9 @@ def torch_gpu_baseline_worker(a):
     of 5, inputs resident on the device, torch.cuda.synchronize() around each forward."""
     from oracle import nsf_oracle, synth
 
+    quota = _cpu_quota()  # (the same CPU-pool cap as the main mode: the baseline must not be the one that gets throttled)
+    if quota and torch.get_num_threads() > quota:
+        torch.set_num_threads(quota)
     dev = torch.device("cuda", 0)
     cfg = nsf_oracle.CONFIGS["v2_48k"]
     w = synth.make_dec_weights(cfg, 1234)
